@@ -1,0 +1,93 @@
+"""ctypes binding of libcabinet_hip.so (the C ABI declared in include/cabinet_hip.h).
+
+There is no fallback: if the library is missing, was built for another ABI
+version, or a call returns an error code, a ``RuntimeError`` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libcabinet_hip.so")
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers
+_INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/cabinet_hip.h one to one
+SIGNATURES = {
+    "cabinet_abi_version": (_INT, []),
+    "cabinet_last_error": (ctypes.c_char_p, []),
+    "cabinet_cab_attn_fwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_cab_attn_fwd": (_INT, [_PTR, _PTR, _PTR, _FLT, _INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _SZ, _PTR]),
+    "cabinet_cab_attn_bwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_cab_attn_bwd": (_INT, [_PTR] * 6 + [_FLT] + [_INT] * 4 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
+    "cabinet_ffm_fwd_workspace_bytes": (_SZ, [_INT] * 7),
+    "cabinet_ffm_fwd": (_INT, [_PTR] * 9 + [_INT] * 7 + [_INT, _FLT, _FLT] + [_PTR] * 6 + [_PTR, _SZ, _PTR]),
+    "cabinet_ffm_bwd_workspace_bytes": (_SZ, [_INT] * 7),
+    "cabinet_ffm_bwd": (_INT, [_PTR] * 13 + [_INT] * 7 + [_INT] + [_PTR] * 7 + [_PTR, _SZ, _PTR]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _preload_hip_runtime():
+    """Make sure ONE libamdhip64.so.7 is in the process before ours resolves it.
+
+    Inside a PyTorch process that is PyTorch's bundled runtime (so streams, events and
+    allocations are shared with torch); otherwise the system ROCm one.
+    """
+    import sys
+
+    cands = []
+    if "torch" in sys.modules:
+        cands.append(os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "libamdhip64.so"))
+    cands += ["libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7"]
+    for c in cands:
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            return c
+        except OSError:
+            continue
+    raise RuntimeError("cabinet_amd: no HIP runtime (libamdhip64.so.7) could be loaded")
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError when unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"cabinet_amd: {LIB_PATH} is missing -- build it with `python -m cabinet_amd.build` "
+                "(there is no non-HIP fallback for device tensors)")
+        _preload_hip_runtime()
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise RuntimeError(f"cabinet_amd: {LIB_PATH} does not export {name}") from e
+            fn.restype, fn.argtypes = res, args
+        got = lib.cabinet_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"cabinet_amd: ABI version {got} != expected {ABI_VERSION}; rebuild the library")
+        _lib = lib
+    return _lib
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().cabinet_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"cabinet_amd: {what} failed (code {rc}): {msg}")

@@ -1,0 +1,288 @@
+// K2 -- backward of the fused CAB attention core (reference src/models/cab.py:149-154
+// as differentiated by autograd).  Given g = dL/dctx, with P recomputed from q, k, lse:
+//   D_i   = sum_c g[c][i] ctx[c][i]
+//   dv    = P^T-weighted sum of g          dv[c][j] = sum_i P[i][j] g[c][i]
+//   dP    = g^T v                          dS[i][j] = P[i][j] (dP[i][j] - D_i)
+//   dq    = scale * dS k                   dk[c][j] = scale * sum_i dS[i][j] q[c][i]
+//
+// Two kernels, no atomics, bitwise deterministic:
+//   K2a  dq   : workgroup = 32 queries, 4 waves split the keys     (+ writes D_i)
+//   K2b  dk,dv: workgroup = 32 keys,    4 waves split the queries
+// Each recomputes S and dP for its tiles (2n^2(4Kc+3Vc) executed vs 2n^2(3Kc+2Vc)
+// algorithmic) -- the price of not summing dq across workgroups with float atomics
+// (1.3 TB/s chip-wide on MI355X would bound the pass at ~100 us for config 3).
+//
+// Layout trick shared with the forward kernel: the tile index that is NOT contracted
+// sits on the lane, so every accumulator is directly the B operand of the next product
+// and only the operand that must be read "channel on lane" crosses LDS, in 32-channel
+// chunks through a small wave-private double buffer (no workgroup barrier in the loop).
+#include "common.hpp"
+
+namespace cabinet {
+
+constexpr int TSTR = 33;            // padded row stride of a transposed chunk
+constexpr int TCHUNK = 32 * TSTR;   // one 32-channel x 32-position chunk
+
+// Stage a 32-channel chunk src[c0 .. c0+31][pos] (lane: pos = li, channel parity h) into
+// a wave-private LDS chunk laid out [channel][pos] with stride 33.
+__device__ __forceinline__ void stage_chunk(float* tb, const float* __restrict__ src, size_t row_stride,
+                                            int li, int h) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) tb[(2 * s + h) * TSTR + li] = src[(size_t)(2 * s) * row_stride];
+}
+
+// ------------------------------------------------------------------------------------ K2a: dq
+template <int KC, int VC>
+__global__ __launch_bounds__(256) void cab_attn_bwd_dq_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
+    const float* __restrict__ v, const float* __restrict__ ctx, const float* __restrict__ lse,
+    float* __restrict__ dq, float* __restrict__ delta, int n, float scale) {
+    constexpr int KB = KC / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qt = smem;                 // [KC][32]  q * scale*log2e   (B operand of S^T)
+    float* gt = qt + KC * 32;         // [VC][32]  g                 (B operand of dP^T)
+    float* tbuf = gt + VC * 32;       // [4 waves][2][TCHUNK]
+    float* red = tbuf + 8 * TCHUNK;   // [KC][32]  cross-wave reduction of dq
+    float* s_part = red + KC * 32;    // [8][32]   partial D_i
+    float* s_delta = s_part + 256;    // [32]
+    float* s_lse = s_delta + 32;      // [32]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, i0 = blockIdx.x * 32;
+    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+    const float qscale = scale * LOG2E_F;
+
+    // ---- prologue: stage the query-side operands, compute D_i ----
+    {
+        const int i = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts over channels
+        const int ig = min(i0 + i, n - 1);
+        for (int c = part; c < KC; c += 8) qt[c * 32 + i] = q[qk_base + (size_t)c * n + ig] * qscale;
+        float acc = 0.f;
+        for (int c = part; c < VC; c += 8) {
+            const float gv = g[v_base + (size_t)c * n + ig];
+            gt[c * 32 + i] = gv;
+            acc += gv * ctx[v_base + (size_t)c * n + ig];
+        }
+        s_part[part * 32 + i] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float d = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) d += s_part[p * 32 + threadIdx.x];
+        s_delta[threadIdx.x] = d;
+        const int ig = i0 + threadIdx.x;
+        if (ig < n) delta[(size_t)b * n + ig] = d;
+        s_lse[threadIdx.x] = lse[(size_t)b * n + min(ig, n - 1)] * LOG2E_F;
+    }
+    __syncthreads();
+    const float my_delta = s_delta[li], my_lse2 = s_lse[li];
+
+    f32x16 acc[KB];
+#pragma unroll
+    for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    float* tb = tbuf + wave * 2 * TCHUNK;
+
+    const int NT = (n + 31) >> 5;
+    for (int t = wave; t < NT; t += 4) {
+        const int j0 = t * 32;
+        const int jk = min(j0 + li, n - 1);
+        const float* kp = k + qk_base + (size_t)h * n + jk;
+        const float* vp = v + v_base + (size_t)h * n + jk;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kp[(size_t)(2 * c2) * n], qt[(2 * c2 + h) * 32 + li], s);
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(vp[(size_t)(2 * c2) * n], gt[(2 * c2 + h) * 32 + li], dp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = j0 + acc_row(r) + 4 * h < n;
+            const float p = valid ? fast_exp2(s[r] - my_lse2) : 0.f;
+            s[r] = p * (dp[r] - my_delta);  // dS^T[key][query]
+        }
+        // dq^T[c][i] += sum_j k[c][j] dS^T[j][i] : A = k chunk (channel on lane) via LDS
+#pragma unroll
+        for (int cb = 0; cb < KB; ++cb) {
+            float* tc = tb + (cb & 1) * TCHUNK;
+            stage_chunk(tc, kp + (size_t)(cb * 32) * n, n, li, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[cb] = mfma32(tc[li * TSTR + acc_row(r) + 4 * h], s[r], acc[cb]);
+        }
+    }
+
+    // ---- reduce the 4 waves' partial dq through LDS (ordered -> deterministic) ----
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    red[idx] = (w == 0) ? acc[cb][r] : red[idx] + acc[cb][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
+        const int c = idx >> 5, i = idx & 31;
+        if (i0 + i < n) dq[qk_base + (size_t)c * n + i0 + i] = red[idx] * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------- K2b: dk, dv
+template <int KC, int VC>
+__global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
+    const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dk, float* __restrict__ dv, int n, float scale) {
+    constexpr int KB = KC / 32, VB = VC / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* kt = smem;                  // [KC][32] raw k tile   (B operand of S)
+    float* vt = kt + KC * 32;          // [VC][32] raw v tile   (B operand of dP)
+    float* tbuf = vt + VC * 32;        // [4 waves][2][TCHUNK]
+    float* red = tbuf + 8 * TCHUNK;    // [(KC+VC)][32]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, j0 = blockIdx.x * 32;
+    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+    const float qscale = scale * LOG2E_F;
+    {
+        const int j = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int jg = min(j0 + j, n - 1);
+        for (int c = part; c < KC; c += 8) kt[c * 32 + j] = k[qk_base + (size_t)c * n + jg];
+        for (int c = part; c < VC; c += 8) vt[c * 32 + j] = v[v_base + (size_t)c * n + jg];
+    }
+    __syncthreads();
+
+    f32x16 dka[KB], dva[VB];
+#pragma unroll
+    for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dka[cb][r] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dva[cb][r] = 0.f;
+    float* tb = tbuf + wave * 2 * TCHUNK;
+
+    const int NT = (n + 31) >> 5;
+    for (int t = wave; t < NT; t += 4) {
+        const int i0 = t * 32;
+        const int ii = min(i0 + li, n - 1);
+        const float* qp = q + qk_base + (size_t)h * n + ii;
+        const float* gp = g + v_base + (size_t)h * n + ii;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+        // S[i][j] = q^T k : A = q (query on lane), B = k tile (key on lane) -> key on the lane
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(qp[(size_t)(2 * c2) * n], kt[(2 * c2 + h) * 32 + li], s);
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(gp[(size_t)(2 * c2) * n], vt[(2 * c2 + h) * 32 + li], dp);
+        f32x16 p;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int irow = i0 + acc_row(r) + 4 * h;
+            const bool valid = irow < n;
+            const size_t si = (size_t)b * n + min(irow, n - 1);
+            const float l2 = lse[si] * LOG2E_F, dl = delta[si];
+            p[r] = valid ? fast_exp2(s[r] * qscale - l2) : 0.f;  // P[query][key]
+            s[r] = p[r] * (dp[r] - dl);                           // dS[query][key]
+        }
+        // dv[c][j] += sum_i g[c][i] P[i][j] ; dk[c][j] += sum_i q[c][i] dS[i][j]
+#pragma unroll
+        for (int cb = 0; cb < VB; ++cb) {
+            float* tc = tb + (cb & 1) * TCHUNK;
+            stage_chunk(tc, gp + (size_t)(cb * 32) * n, n, li, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dva[cb] = mfma32(tc[li * TSTR + acc_row(r) + 4 * h], p[r], dva[cb]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < KB; ++cb) {
+            float* tc = tb + ((cb + VB) & 1) * TCHUNK;
+            stage_chunk(tc, qp + (size_t)(cb * 32) * n, n, li, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dka[cb] = mfma32(tc[li * TSTR + acc_row(r) + 4 * h], s[r], dka[cb]);
+        }
+    }
+
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    red[idx] = (w == 0) ? dka[cb][r] : red[idx] + dka[cb][r];
+                }
+#pragma unroll
+            for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (KC + cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    red[idx] = (w == 0) ? dva[cb][r] : red[idx] + dva[cb][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
+        const int c = idx >> 5, j = idx & 31;
+        if (j0 + j < n) dk[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
+    }
+    for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
+        const int c = idx >> 5, j = idx & 31;
+        if (j0 + j < n) dv[v_base + (size_t)c * n + j0 + j] = red[KC * 32 + idx];
+    }
+}
+
+template <int KC, int VC>
+static hipError_t launch_bwd(const float* g, const float* q, const float* k, const float* v, const float* ctx,
+                             const float* lse, float scale, int B, int n, float* dq, float* dk, float* dv,
+                             float* delta, hipStream_t stream) {
+    const size_t lds_dq = (size_t)((KC + VC) * 32 + 8 * TCHUNK + KC * 32 + 256 + 64) * sizeof(float);
+    const size_t lds_kv = (size_t)((KC + VC) * 32 + 8 * TCHUNK + (KC + VC) * 32) * sizeof(float);
+    auto k_dq = cab_attn_bwd_dq_kernel<KC, VC>;
+    auto k_kv = cab_attn_bwd_dkdv_kernel<KC, VC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dq),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_kv);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid((n + 31) / 32, 1, B);
+    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, dq, delta, n, scale);
+    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale);
+    return hipGetLastError();
+}
+
+size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
+    (void)Kc;
+    (void)Vc;
+    return align_up((size_t)B * n * sizeof(float), 256);  // D_i
+}
+
+hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, const float* v,
+                             const float* ctx, const float* lse, float scale, int B, int Kc, int Vc, int n,
+                             float* dq, float* dk, float* dv, void* ws, hipStream_t stream) {
+    float* delta = static_cast<float*>(ws);
+    if (Kc == 128 && Vc == 128)
+        return launch_bwd<128, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
+    if (Kc == 256 && Vc == 128)
+        return launch_bwd<256, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
+    if (Kc == 64 && Vc == 64)
+        return launch_bwd<64, 64>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cabinet

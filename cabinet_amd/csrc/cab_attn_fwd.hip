@@ -1,0 +1,225 @@
+// K1 -- fused CAB attention forward: affinity -> online softmax -> aggregation.
+//
+// Replaces reference src/models/cab.py:149-154 (bmm, scale, softmax(dim=-1), bmm,
+// transpose+view).  Inputs stay in the NCHW-flattened layout the producers emit:
+//   q, k : (B, KC, n)   v : (B, VC, n)   ->   ctx : (B, VC, n),  lse : (B, n)
+//
+// Design (MI355X, exact fp32 via v_mfma_f32_32x32x2_f32):
+//  * "query on the lane" throughout.  One workgroup = 32 queries x 4 waves; the 4
+//    waves split the KEYS (wave w takes key tiles t == w mod 4), so there is no
+//    barrier in the main loop and a 8x32x32 image still fills 256 CUs with one
+//    wave per SIMD (512-VGPR budget: Q, O and the streamed K tile live in VGPRs).
+//  * S^T tile (32 keys x 32 queries) = K^T Q:  A = K[c][j] (key on lane),
+//    B = Q[c][i] (query on lane): both are contiguous 128-B reads of NCHW rows.
+//    The accumulator then has the query on the lane and 16 keys in registers,
+//    which is exactly the B operand of O^T += V P^T, so P never leaves registers
+//    and the softmax row statistics are per-lane scalars (one cross-half swap).
+//  * V needs the channel on the lane (contraction over keys), i.e. a transpose of
+//    the NCHW row: each wave stages its V tile through a private, padded LDS
+//    image (stride 33 floats: conflict-free both ways); no workgroup barrier.
+//  * Rescaling of O is deferred (only when the running max grows by > 2^12), so
+//    the common tile is MFMA + 16 exp2 per lane.
+//  * The four per-wave partial results are merged through LDS at the end; with
+//    kvsplit > 1 (small batches) partials go to a workspace and a tiny second
+//    kernel merges them, so the grid always covers the chip.
+#include "common.hpp"
+
+namespace cabinet {
+
+constexpr float kRescaleThreshold = 12.0f;  // log2 units
+
+template <int KC, int VC>
+__global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit) {
+    constexpr int VB = VC / 32;
+    constexpr int VSTR = 33;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    float* vs = smem + wave * (VC * VSTR);
+    float* s_m = smem + 4 * VC * VSTR;  // [4][32] running max per wave / query
+    float* s_l = s_m + 128;             // [4][32] running sum
+    float* s_f = s_l + 128;             // [4][32] merge factors
+
+    const int b = blockIdx.z, split = blockIdx.y, i0 = blockIdx.x * 32;
+    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+
+    // Q operand: lane (li,h) holds q[2s+h][i0+li] * scale*log2(e) for s = 0..KC/2-1
+    float qreg[KC / 2];
+    {
+        const float* qp = q + qk_base + (size_t)h * n + min(i0 + li, n - 1);
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) qreg[s] = qp[(size_t)(2 * s) * n] * qscale;
+    }
+
+    f32x16 o[VB];
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const int NT = (n + 31) >> 5;
+    for (int t = split * 4 + wave; t < NT; t += 4 * kvsplit) {
+        const int j0 = t * 32;
+        const int jk = min(j0 + li, n - 1);
+
+        // ---- S^T = K^T Q  (keys in accumulator rows, query on the lane) ----
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+            const float* kp = k + qk_base + (size_t)h * n + jk;
+#pragma unroll
+            for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kp[(size_t)(2 * c2) * n], qreg[c2], s);
+        }
+        // ---- V tile -> wave-private LDS image vs[c][key] ----
+        {
+            const float* vp = v + v_base + (size_t)h * n + jk;
+#pragma unroll
+            for (int c2 = 0; c2 < VC / 2; ++c2) vs[(2 * c2 + h) * VSTR + li] = vp[(size_t)(2 * c2) * n];
+        }
+        if (j0 + 32 > n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row(r) + 4 * h >= n) s[r] = -INFINITY;
+        }
+        // ---- online softmax, statistics per lane (= per query) ----
+        float mt = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, swap_half(mt));
+        if (__any(mt > m + kRescaleThreshold)) {
+            const float mn = (mt > m + kRescaleThreshold) ? mt : m;
+            const float alpha = fast_exp2(m - mn);  // m == -inf -> 0
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fast_exp2(s[r] - m);
+            rs += s[r];
+        }
+        l += rs;
+        // ---- O^T += V P^T : A = V[c][key] (channel on lane), B = P^T regs ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = acc_row(r) + 4 * h;
+#pragma unroll
+            for (int cb = 0; cb < VB; ++cb) o[cb] = mfma32(vs[(cb * 32 + li) * VSTR + key], s[r], o[cb]);
+        }
+    }
+
+    // ---- merge the 4 waves (disjoint key subsets) ----
+    l += swap_half(l);
+    if (h == 0) {
+        s_m[wave * 32 + li] = m;
+        s_l[wave * 32 + li] = l;
+    }
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vs[(cb * 32 + acc_row(r) + 4 * h) * 32 + li] = o[cb][r];
+    __syncthreads();
+    float ms = -INFINITY, lt = 0.f;
+    if (threadIdx.x < 128) {
+        const int i = threadIdx.x & 31, w = threadIdx.x >> 5;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) ms = fmaxf(ms, s_m[ww * 32 + i]);
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) lt += s_l[ww * 32 + i] * fast_exp2(s_m[ww * 32 + i] - ms);
+        // a (split of a) query row with no key at all cannot happen (host keeps
+        // kvsplit <= NT/4), but stay finite if it does
+        s_f[w * 32 + i] = (lt > 0.f) ? fast_exp2(s_m[w * 32 + i] - ms) / lt : 0.f;
+    }
+    __syncthreads();
+    const size_t out_base = ((size_t)split * gridDim.z + b) * VC * n;
+    for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
+        const int c = idx >> 5, i = idx & 31;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += smem[w * (VC * VSTR) + c * 32 + i] * s_f[w * 32 + i];
+        if (i0 + i < n) ctx[out_base + (size_t)c * n + i0 + i] = acc;
+    }
+    if (threadIdx.x < 32 && i0 + threadIdx.x < n)
+        lse[((size_t)split * gridDim.z + b) * n + i0 + threadIdx.x] =
+            (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
+}
+
+// merge kvsplit partial results: lse = logsumexp_s(lse_s), ctx = sum_s exp(lse_s - lse) ctx_s
+__global__ void cab_attn_fwd_merge_kernel(const float* __restrict__ part_ctx,
+                                          const float* __restrict__ part_lse,
+                                          float* __restrict__ ctx, float* __restrict__ lse,
+                                          int B, int VC, int n, int kvsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+    if (i >= n) return;
+    float mx = -INFINITY;
+    for (int s = 0; s < kvsplit; ++s) mx = fmaxf(mx, part_lse[((size_t)s * B + b) * n + i]);
+    float sum = 0.f;
+    for (int s = 0; s < kvsplit; ++s) sum += expf(part_lse[((size_t)s * B + b) * n + i] - mx);
+    const float total = mx + logf(sum);
+    if (blockIdx.y == 0) lse[(size_t)b * n + i] = total;
+    for (int c = blockIdx.y; c < VC; c += gridDim.y) {
+        float acc = 0.f;
+        for (int s = 0; s < kvsplit; ++s)
+            acc += part_ctx[(((size_t)s * B + b) * VC + c) * n + i] *
+                   expf(part_lse[((size_t)s * B + b) * n + i] - total);
+        ctx[((size_t)b * VC + c) * n + i] = acc;
+    }
+}
+
+template <int KC, int VC>
+static hipError_t launch_fwd(const float* q, const float* k, const float* v, float scale, int B, int n,
+                             float* ctx, float* lse, float* part_ctx, float* part_lse, int kvsplit,
+                             hipStream_t stream) {
+    const size_t lds = (size_t)(4 * VC * 33 + 3 * 128) * sizeof(float);
+    auto kern = cab_attn_fwd_kernel<KC, VC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid((n + 31) / 32, kvsplit, B);
+    if (kvsplit == 1) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q, k, v, ctx, lse, n, scale * LOG2E_F, 1);
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q, k, v, part_ctx, part_lse, n,
+                           scale * LOG2E_F, kvsplit);
+        dim3 mgrid((n + 255) / 256, VC < 32 ? VC : 32, B);
+        hipLaunchKernelGGL(cab_attn_fwd_merge_kernel, mgrid, dim3(256), 0, stream, part_ctx, part_lse, ctx,
+                           lse, B, VC, n, kvsplit);
+    }
+    return hipGetLastError();
+}
+
+int attn_fwd_kvsplit(int B, int n) {
+    const int nt = (n + 31) / 32;
+    int wgs = nt * B, split = 1;
+    while (wgs * split < 256 && split * 2 * 4 <= nt && split < 8) split *= 2;
+    return split;
+}
+
+bool attn_shape_supported(int Kc, int Vc) {
+    return (Kc == 128 && Vc == 128) || (Kc == 256 && Vc == 128) || (Kc == 64 && Vc == 64);
+}
+
+hipError_t attn_fwd_dispatch(const float* q, const float* k, const float* v, float scale, int B, int Kc,
+                             int Vc, int n, float* ctx, float* lse, float* part_ctx, float* part_lse,
+                             int kvsplit, hipStream_t stream) {
+    if (Kc == 128 && Vc == 128)
+        return launch_fwd<128, 128>(q, k, v, scale, B, n, ctx, lse, part_ctx, part_lse, kvsplit, stream);
+    if (Kc == 256 && Vc == 128)
+        return launch_fwd<256, 128>(q, k, v, scale, B, n, ctx, lse, part_ctx, part_lse, kvsplit, stream);
+    if (Kc == 64 && Vc == 64)
+        return launch_fwd<64, 64>(q, k, v, scale, B, n, ctx, lse, part_ctx, part_lse, kvsplit, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cabinet

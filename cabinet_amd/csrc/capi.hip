@@ -1,0 +1,182 @@
+// C ABI of libcabinet_hip.so: argument checking, workspace carving, dispatch.
+// Declarations and the reference lines each entry point replaces: include/cabinet_hip.h
+#include "../../include/cabinet_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace cabinet {
+// cab_attn_fwd.hip
+int attn_fwd_kvsplit(int B, int n);
+bool attn_shape_supported(int Kc, int Vc);
+hipError_t attn_fwd_dispatch(const float* q, const float* k, const float* v, float scale, int B, int Kc,
+                             int Vc, int n, float* ctx, float* lse, float* part_ctx, float* part_lse,
+                             int kvsplit, hipStream_t stream);
+// cab_attn_bwd.hip
+size_t attn_bwd_workspace(int B, int Kc, int Vc, int n);
+hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, const float* v,
+                             const float* ctx, const float* lse, float scale, int B, int Kc, int Vc, int n,
+                             float* dq, float* dk, float* dv, void* ws, hipStream_t stream);
+// ffm.hip
+struct FfmShape {
+    int B, Cs, Cc, Co, Cm, H, W;
+};
+size_t ffm_fwd_workspace(const FfmShape& s);
+size_t ffm_bwd_workspace(const FfmShape& s);
+hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, const float* w_blk,
+                       const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                       const float* w1, const float* w2, int training, float momentum, float eps, float* out,
+                       float* z, float* save_mean, float* save_invstd, float* pooled, float* gate, void* ws,
+                       hipStream_t stream);
+hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, const float* fcp,
+                       const float* w_blk, const float* bn_w, const float* bn_b, const float* w1,
+                       const float* w2, const float* z, const float* save_mean, const float* save_invstd,
+                       const float* pooled, const float* gate, int training, float* dfsp, float* dfcp,
+                       float* dw_blk, float* dbn_w, float* dbn_b, float* dw1, float* dw2, void* ws,
+                       hipStream_t stream);
+}  // namespace cabinet
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return CABINET_OK;
+    return fail(CABINET_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+extern "C" {
+
+int cabinet_abi_version(void) { return CABINET_ABI_VERSION; }
+const char* cabinet_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ attention
+static int check_attn_shape(int B, int Kc, int Vc, int n) {
+    if (B <= 0 || Kc <= 0 || Vc <= 0 || n <= 0)
+        return fail(CABINET_ERR_INVALID_ARG, "cab_attn: non-positive dimension B=%d Kc=%d Vc=%d n=%d", B, Kc,
+                    Vc, n);
+    if (!cabinet::attn_shape_supported(Kc, Vc))
+        return fail(CABINET_ERR_UNSUPPORTED,
+                    "cab_attn: (Kc=%d, Vc=%d) has no gfx950 instantiation; built: (128,128) (256,128) (64,64)",
+                    Kc, Vc);
+    if (B > 65535) return fail(CABINET_ERR_UNSUPPORTED, "cab_attn: B=%d exceeds grid.z", B);
+    return CABINET_OK;
+}
+
+size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n) {
+    if (B <= 0 || Kc <= 0 || Vc <= 0 || n <= 0) return 0;
+    const int split = cabinet::attn_fwd_kvsplit(B, n);
+    if (split == 1) return 0;
+    return align_up((size_t)split * B * Vc * n * sizeof(float), 256) +
+           align_up((size_t)split * B * n * sizeof(float), 256);
+}
+
+int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float scale, int B, int Kc, int Vc,
+                         int n, float* ctx, float* lse, void* workspace, size_t workspace_bytes,
+                         cabinet_stream_t stream) {
+    if (int rc = check_attn_shape(B, Kc, Vc, n)) return rc;
+    if (!q || !k || !v || !ctx || !lse) return fail(CABINET_ERR_INVALID_ARG, "cab_attn_fwd: null tensor pointer");
+    const size_t need = cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "cab_attn_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    const int split = cabinet::attn_fwd_kvsplit(B, n);
+    float* part_ctx = static_cast<float*>(workspace);
+    float* part_lse = split > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) +
+                                                           align_up((size_t)split * B * Vc * n * sizeof(float), 256))
+                                : nullptr;
+    return hip_status(cabinet::attn_fwd_dispatch(q, k, v, scale, B, Kc, Vc, n, ctx, lse, part_ctx, part_lse,
+                                                 split, static_cast<hipStream_t>(stream)),
+                      "cab_attn_fwd launch");
+}
+
+size_t cabinet_cab_attn_bwd_workspace_bytes(int B, int Kc, int Vc, int n) {
+    if (B <= 0 || Kc <= 0 || Vc <= 0 || n <= 0) return 0;
+    return cabinet::attn_bwd_workspace(B, Kc, Vc, n);
+}
+
+int cabinet_cab_attn_bwd(const float* dctx, const float* q, const float* k, const float* v, const float* ctx,
+                         const float* lse, float scale, int B, int Kc, int Vc, int n, float* dq, float* dk,
+                         float* dv, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_attn_shape(B, Kc, Vc, n)) return rc;
+    if (!dctx || !q || !k || !v || !ctx || !lse || !dq || !dk || !dv)
+        return fail(CABINET_ERR_INVALID_ARG, "cab_attn_bwd: null tensor pointer");
+    const size_t need = cabinet_cab_attn_bwd_workspace_bytes(B, Kc, Vc, n);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "cab_attn_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::attn_bwd_dispatch(dctx, q, k, v, ctx, lse, scale, B, Kc, Vc, n, dq, dk, dv,
+                                                 workspace, static_cast<hipStream_t>(stream)),
+                      "cab_attn_bwd launch");
+}
+
+// ------------------------------------------------------------------------ FFM
+static int check_ffm_shape(int B, int Cs, int Cc, int Co, int Cm, int H, int W) {
+    if (B <= 0 || Cs <= 0 || Cc <= 0 || Co <= 0 || Cm <= 0 || H <= 0 || W <= 0)
+        return fail(CABINET_ERR_INVALID_ARG, "ffm: non-positive dimension");
+    if (Cs % 32 || Cc % 32 || Co % 32)
+        return fail(CABINET_ERR_UNSUPPORTED, "ffm: Cs=%d Cc=%d Co=%d must be multiples of 32", Cs, Cc, Co);
+    if (Cm > 256 || Co > 1024)
+        return fail(CABINET_ERR_UNSUPPORTED, "ffm: Cm=%d (max 256) / Co=%d (max 1024) too large", Cm, Co);
+    if (B > 65535) return fail(CABINET_ERR_UNSUPPORTED, "ffm: B=%d exceeds grid limits", B);
+    return CABINET_OK;
+}
+
+size_t cabinet_ffm_fwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W) {
+    if (B <= 0 || Cs <= 0 || Cc <= 0 || Co <= 0 || Cm <= 0 || H <= 0 || W <= 0) return 0;
+    return cabinet::ffm_fwd_workspace({B, Cs, Cc, Co, Cm, H, W});
+}
+
+int cabinet_ffm_fwd(const float* fsp, const float* fcp, const float* w_blk, const float* bn_weight,
+                    const float* bn_bias, float* running_mean, float* running_var, const float* w1,
+                    const float* w2, int B, int Cs, int Cc, int Co, int Cm, int H, int W, int training,
+                    float momentum, float eps, float* out, float* z, float* save_mean, float* save_invstd,
+                    float* pooled, float* gate, void* workspace, size_t workspace_bytes,
+                    cabinet_stream_t stream) {
+    if (int rc = check_ffm_shape(B, Cs, Cc, Co, Cm, H, W)) return rc;
+    if (!fsp || !fcp || !w_blk || !bn_weight || !bn_bias || !running_mean || !running_var || !w1 || !w2 ||
+        !out || !z || !save_mean || !save_invstd || !pooled || !gate)
+        return fail(CABINET_ERR_INVALID_ARG, "ffm_fwd: null tensor pointer");
+    const size_t need = cabinet_ffm_fwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "ffm_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::ffm_fwd_run({B, Cs, Cc, Co, Cm, H, W}, fsp, fcp, w_blk, bn_weight, bn_bias,
+                                           running_mean, running_var, w1, w2, training, momentum, eps, out, z,
+                                           save_mean, save_invstd, pooled, gate, workspace,
+                                           static_cast<hipStream_t>(stream)),
+                      "ffm_fwd launch");
+}
+
+size_t cabinet_ffm_bwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W) {
+    if (B <= 0 || Cs <= 0 || Cc <= 0 || Co <= 0 || Cm <= 0 || H <= 0 || W <= 0) return 0;
+    return cabinet::ffm_bwd_workspace({B, Cs, Cc, Co, Cm, H, W});
+}
+
+int cabinet_ffm_bwd(const float* dout, const float* fsp, const float* fcp, const float* w_blk,
+                    const float* bn_weight, const float* bn_bias, const float* w1, const float* w2,
+                    const float* z, const float* save_mean, const float* save_invstd, const float* pooled,
+                    const float* gate, int B, int Cs, int Cc, int Co, int Cm, int H, int W, int training,
+                    float* dfsp, float* dfcp, float* dw_blk, float* dbn_weight, float* dbn_bias, float* dw1,
+                    float* dw2, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_ffm_shape(B, Cs, Cc, Co, Cm, H, W)) return rc;
+    if (!dout || !fsp || !fcp || !w_blk || !bn_weight || !bn_bias || !w1 || !w2 || !z || !save_mean ||
+        !save_invstd || !pooled || !gate || !dfsp || !dfcp || !dw_blk || !dbn_weight || !dbn_bias || !dw1 ||
+        !dw2)
+        return fail(CABINET_ERR_INVALID_ARG, "ffm_bwd: null tensor pointer");
+    const size_t need = cabinet_ffm_bwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "ffm_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::ffm_bwd_run({B, Cs, Cc, Co, Cm, H, W}, dout, fsp, fcp, w_blk, bn_weight, bn_bias,
+                                           w1, w2, z, save_mean, save_invstd, pooled, gate, training, dfsp,
+                                           dfcp, dw_blk, dbn_weight, dbn_bias, dw1, dw2, workspace,
+                                           static_cast<hipStream_t>(stream)),
+                      "ffm_bwd launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libcabinet_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stddef.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA, D(32x32) += A(32x2) * B(2x32).
+//   lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
+//   accumulator register r of lane l is D[row = acc_row(r) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ constexpr int acc_row(int r) { return (r & 3) + 8 * (r >> 2); }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// exchange with the other 32-lane half of the wave
+__device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32, 64); }
+
+// sum / max over the 32 lanes of this lane's half (result in every lane of the half)
+__device__ __forceinline__ float half_sum(float x) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+#define LOG2E_F 1.4426950408889634f
+#define LN2_F 0.6931471805599453f
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,200 @@
+"""Autograd operators of the hot path, backed by libcabinet_hip.so on HIP tensors.
+
+``cab_attention``  replaces reference src/models/cab.py:149-154
+``ffm_fused``      replaces reference src/models/cabinet.py:142-153
+
+Device tensors ALWAYS go through the hand-written HIP kernels (RuntimeError if the
+library is absent or rejects the shape -- never a silent PyTorch fallback).  Host (CPU)
+tensors take the composite ATen path below so the modules stay usable for
+checkpoint surgery, EMA copies and CPU unit tests, exactly like any nn.Module.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream_handle(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None, 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws, nbytes
+
+
+def _f32c(t):
+    """Borrowed inputs must be dense fp32 (same rule the C ABI documents)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- attention core
+
+
+def attn_fwd_hip(q, k, v, scale):
+    """q,k (B,Kc,n), v (B,Vc,n) fp32 device tensors -> ctx (B,Vc,n), lse (B,n)."""
+    lib = _lib.load()
+    B, Kc, n = q.shape
+    Vc = v.shape[1]
+    ctx = torch.empty((B, Vc, n), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B, n), dtype=torch.float32, device=q.device)
+    ws, nbytes = _workspace(lib.cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n), q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.cabinet_cab_attn_fwd(_ptr(q), _ptr(k), _ptr(v), float(scale), B, Kc, Vc, n, _ptr(ctx), _ptr(lse),
+                                      _ptr(ws), nbytes, _stream_handle(q.device))
+    _lib.check(rc, "cabinet_cab_attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd_hip(g, q, k, v, ctx, lse, scale):
+    lib = _lib.load()
+    B, Kc, n = q.shape
+    Vc = v.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws, nbytes = _workspace(lib.cabinet_cab_attn_bwd_workspace_bytes(B, Kc, Vc, n), q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.cabinet_cab_attn_bwd(_ptr(g), _ptr(q), _ptr(k), _ptr(v), _ptr(ctx), _ptr(lse), float(scale),
+                                      B, Kc, Vc, n, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), nbytes,
+                                      _stream_handle(q.device))
+    _lib.check(rc, "cabinet_cab_attn_bwd")
+    return dq, dk, dv
+
+
+class _CabAttention(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, q, k, v, scale):
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        out, lse = attn_fwd_hip(q, k, v, scale)
+        fn_ctx.save_for_backward(q, k, v, out, lse)
+        fn_ctx.scale = scale
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        q, k, v, out, lse = fn_ctx.saved_tensors
+        dq, dk, dv = attn_bwd_hip(_f32c(g), q, k, v, out, lse, fn_ctx.scale)
+        return dq, dk, dv, None
+
+
+def cab_attention(q, k, v, scale):
+    """ctx[b,c,i] = sum_j softmax_j(scale * <q[b,:,i], k[b,:,j]>) v[b,c,j].
+
+    q,k: (B,Kc,n)  v: (B,Vc,n)  ->  (B,Vc,n).   Reference: cab.py:149-154.
+    """
+    if q.dim() != 3 or k.shape != q.shape or v.dim() != 3 or v.shape[0] != q.shape[0] or v.shape[2] != q.shape[2]:
+        raise RuntimeError(f"cab_attention: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if q.is_cuda:
+        return _CabAttention.apply(q, k, v, float(scale))
+    # host tensors: composite ATen ops
+    attn = torch.bmm(q.transpose(1, 2), k) * scale
+    attn = F.softmax(attn, dim=-1)
+    return torch.bmm(v, attn.transpose(1, 2))
+
+
+# --------------------------------------------------------------------------- FFM
+
+
+def _ffm_dims(fsp, fcp, w_blk, w1):
+    B, Cs, H, W = fsp.shape
+    Cc = fcp.shape[1]
+    Co = w_blk.shape[0]
+    Cm = w1.shape[0]
+    return B, Cs, Cc, Co, Cm, H, W
+
+
+def ffm_fwd_hip(fsp, fcp, w_blk, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps):
+    lib = _lib.load()
+    dims = _ffm_dims(fsp, fcp, w_blk, w1)
+    B, Cs, Cc, Co, Cm, H, W = dims
+    dev = fsp.device
+    out = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
+    z = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
+    save_mean = torch.empty(Co, dtype=torch.float32, device=dev)
+    save_invstd = torch.empty(Co, dtype=torch.float32, device=dev)
+    pooled = torch.empty((B, Co), dtype=torch.float32, device=dev)
+    gate = torch.empty((B, Co), dtype=torch.float32, device=dev)
+    ws, nbytes = _workspace(lib.cabinet_ffm_fwd_workspace_bytes(*dims), dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ffm_fwd(_ptr(fsp), _ptr(fcp), _ptr(w_blk), _ptr(bn_w), _ptr(bn_b), _ptr(run_mean),
+                                 _ptr(run_var), _ptr(w1), _ptr(w2), *dims, int(training), float(momentum),
+                                 float(eps), _ptr(out), _ptr(z), _ptr(save_mean), _ptr(save_invstd),
+                                 _ptr(pooled), _ptr(gate), _ptr(ws), nbytes, _stream_handle(dev))
+    _lib.check(rc, "cabinet_ffm_fwd")
+    return out, z, save_mean, save_invstd, pooled, gate
+
+
+def ffm_bwd_hip(g, fsp, fcp, w_blk, bn_w, bn_b, w1, w2, z, save_mean, save_invstd, pooled, gate, training):
+    lib = _lib.load()
+    dims = _ffm_dims(fsp, fcp, w_blk, w1)
+    dev = fsp.device
+    dfsp, dfcp = torch.empty_like(fsp), torch.empty_like(fcp)
+    dw_blk = torch.empty_like(w_blk)
+    dbn_w, dbn_b = torch.empty_like(bn_w), torch.empty_like(bn_b)
+    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    ws, nbytes = _workspace(lib.cabinet_ffm_bwd_workspace_bytes(*dims), dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ffm_bwd(_ptr(g), _ptr(fsp), _ptr(fcp), _ptr(w_blk), _ptr(bn_w), _ptr(bn_b), _ptr(w1),
+                                 _ptr(w2), _ptr(z), _ptr(save_mean), _ptr(save_invstd), _ptr(pooled),
+                                 _ptr(gate), *dims, int(training), _ptr(dfsp), _ptr(dfcp), _ptr(dw_blk),
+                                 _ptr(dbn_w), _ptr(dbn_b), _ptr(dw1), _ptr(dw2), _ptr(ws), nbytes,
+                                 _stream_handle(dev))
+    _lib.check(rc, "cabinet_ffm_bwd")
+    return dfsp, dfcp, dw_blk, dbn_w, dbn_b, dw1, dw2
+
+
+class _FfmFused(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, fsp, fcp, w_blk, bn_w, bn_b, w1, w2, run_mean, run_var, training, momentum, eps):
+        fsp, fcp = _f32c(fsp), _f32c(fcp)
+        w_blk2 = _f32c(w_blk).view(w_blk.shape[0], -1)
+        w1_2 = _f32c(w1).view(w1.shape[0], -1)
+        w2_2 = _f32c(w2).view(w2.shape[0], -1)
+        bn_w, bn_b = _f32c(bn_w), _f32c(bn_b)
+        out, z, mean, invstd, pooled, gate = ffm_fwd_hip(fsp, fcp, w_blk2, bn_w, bn_b, run_mean, run_var,
+                                                         w1_2, w2_2, training, momentum, eps)
+        fn_ctx.save_for_backward(fsp, fcp, w_blk2, bn_w, bn_b, w1_2, w2_2, z, mean, invstd, pooled, gate)
+        fn_ctx.training = training
+        fn_ctx.w_shapes = (w_blk.shape, w1.shape, w2.shape)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        fsp, fcp, w_blk, bn_w, bn_b, w1, w2, z, mean, invstd, pooled, gate = fn_ctx.saved_tensors
+        dfsp, dfcp, dw_blk, dbn_w, dbn_b, dw1, dw2 = ffm_bwd_hip(
+            _f32c(g), fsp, fcp, w_blk, bn_w, bn_b, w1, w2, z, mean, invstd, pooled, gate, fn_ctx.training)
+        s_blk, s1, s2 = fn_ctx.w_shapes
+        return (dfsp, dfcp, dw_blk.view(s_blk), dbn_w, dbn_b, dw1.view(s1), dw2.view(s2),
+                None, None, None, None, None)
+
+
+def ffm_fused(fsp, fcp, conv_w, bn, w1, w2):
+    """FeatureFusionModule.forward on HIP tensors (reference cabinet.py:142-153).
+
+    ``bn`` is the nn.BatchNorm2d that owns the affine parameters and running buffers;
+    its buffers are updated in place in training mode like nn.BatchNorm2d would.
+    """
+    if not (bn.affine and bn.track_running_stats):
+        raise RuntimeError("ffm_fused: BatchNorm2d must be affine with running statistics")
+    training = bn.training
+    if training:
+        bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    else:
+        momentum = 0.0
+    return _FfmFused.apply(fsp, fcp, conv_w, bn.weight, bn.bias, w1, w2, bn.running_mean, bn.running_var,
+                           training, momentum, bn.eps)

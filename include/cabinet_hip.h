@@ -1,0 +1,114 @@
+/*
+ * cabinet_hip.h -- C ABI of libcabinet_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the CABiNet hot path.  The reference (dronefreak/CABiNet)
+ * is pure Python/PyTorch and has no native interface; each entry point below
+ * replaces a span of ATen calls inside a reference nn.Module.forward (cited
+ * per function, paths relative to the reference repo) plus the autograd
+ * backward of that span.  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add at those lines.
+ *
+ * Conventions
+ *  - All tensors are dense fp32, NCHW-contiguous, resident on the current HIP
+ *    device.  Pointers are borrowed; nothing is retained after the call returns.
+ *  - Every call is asynchronous on `stream` (a hipStream_t; NULL = the default
+ *    stream).  No call synchronises, allocates device memory or uses a private
+ *    stream, so calls are hipGraph-capturable and re-entrant.
+ *  - Scratch memory is caller-provided: query the size with the matching
+ *    *_workspace_bytes() and pass a buffer at least that large (256-byte
+ *    aligned).  A too-small buffer is an error, never an overflow.
+ *  - Return value: CABINET_OK (0) or a negative CABINET_ERR_* code; the
+ *    message for the calling thread is available from cabinet_last_error().
+ *    Mirrors how the ATen ops they replace raise RuntimeError on bad
+ *    shape/dtype/device.
+ */
+#ifndef CABINET_HIP_H_
+#define CABINET_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CABINET_ABI_VERSION 1
+
+#define CABINET_OK 0
+#define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
+#define CABINET_ERR_UNSUPPORTED (-2) /* shape outside what the kernels implement  */
+#define CABINET_ERR_WORKSPACE (-3)   /* workspace missing or too small            */
+#define CABINET_ERR_HIP (-4)         /* a HIP runtime call failed                 */
+
+typedef void* cabinet_stream_t; /* hipStream_t */
+
+int cabinet_abi_version(void);
+const char* cabinet_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * CAB attention core: affinity matmul -> softmax over keys -> aggregation.
+ * Replaces src/models/cab.py:149-154
+ *     attn = torch.bmm(query, key); attn = attn * (key.shape[1] ** -0.5)
+ *     attn = F.softmax(attn, dim=-1); context = torch.bmm(attn, value)
+ *     context = context.transpose(1, 2).view(B, -1, Hd, Wd)
+ * with q,k: (B,Kc,n) and v: (B,Vc,n) being the NCHW-flattened outputs of
+ * to_query / psp_key / psp_value (cab.py:137-146) -- no transposes needed.
+ *   ctx[b,c,i] = sum_j softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]) v[b,c,j]
+ *   lse[b,i]   = log sum_j exp(scale * S[b,i,j])       (saved for backward)
+ * The n x n affinity matrix is never written to memory.
+ * Kc must be even, Vc a multiple of 32; n >= 1 arbitrary.
+ * ------------------------------------------------------------------------- */
+size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n);
+int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float scale,
+                         int B, int Kc, int Vc, int n,
+                         float* ctx /* (B,Vc,n) */, float* lse /* (B,n) */,
+                         void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+/* Backward of the span above (what autograd derives for cab.py:149-154).
+ * Recomputes the affinity tiles from q, k and lse; dctx is dL/dctx (B,Vc,n). */
+size_t cabinet_cab_attn_bwd_workspace_bytes(int B, int Kc, int Vc, int n);
+int cabinet_cab_attn_bwd(const float* dctx, const float* q, const float* k, const float* v,
+                         const float* ctx, const float* lse, float scale,
+                         int B, int Kc, int Vc, int n,
+                         float* dq /* (B,Kc,n) */, float* dk /* (B,Kc,n) */, float* dv /* (B,Vc,n) */,
+                         void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Feature Fusion Module.
+ * Replaces src/models/cabinet.py:142-153 (FeatureFusionModule.forward) incl.
+ * its ConvBNReLU (cabinet.py:42-44):
+ *     fcat = cat([fsp, fcp], 1); feat = relu(bn(conv1x1(fcat)))
+ *     atten = sigmoid(conv2(relu(conv1(avg_pool(feat))))); return feat*atten + feat
+ * fsp: (B,Cs,H,W)  fcp: (B,Cc,H,W)  w_blk: (Co,Cs+Cc)  w1: (Cm,Co)  w2: (Co,Cm)
+ * The concat is never materialised.  training != 0: BatchNorm uses batch
+ * statistics and updates running_mean / running_var in place (momentum, unbiased
+ * variance) exactly like nn.BatchNorm2d; training == 0: running statistics.
+ * Saved for backward: z = pre-BN conv output (B,Co,H,W), save_mean / save_invstd
+ * (Co), pooled (B,Co) = spatial mean of feat, gate (B,Co) = sigmoid output.
+ * Requires Cs, Cc, Co multiples of 32, Cm <= 256.
+ * ------------------------------------------------------------------------- */
+size_t cabinet_ffm_fwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W);
+int cabinet_ffm_fwd(const float* fsp, const float* fcp, const float* w_blk,
+                    const float* bn_weight, const float* bn_bias,
+                    float* running_mean, float* running_var,
+                    const float* w1, const float* w2,
+                    int B, int Cs, int Cc, int Co, int Cm, int H, int W,
+                    int training, float momentum, float eps,
+                    float* out, float* z, float* save_mean, float* save_invstd,
+                    float* pooled, float* gate,
+                    void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+size_t cabinet_ffm_bwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W);
+int cabinet_ffm_bwd(const float* dout, const float* fsp, const float* fcp, const float* w_blk,
+                    const float* bn_weight, const float* bn_bias,
+                    const float* w1, const float* w2,
+                    const float* z, const float* save_mean, const float* save_invstd,
+                    const float* pooled, const float* gate,
+                    int B, int Cs, int Cc, int Co, int Cm, int H, int W, int training,
+                    float* dfsp, float* dfcp, float* dw_blk, float* dbn_weight, float* dbn_bias,
+                    float* dw1, float* dw2,
+                    void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CABINET_HIP_H_ */

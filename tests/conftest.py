@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def rel_err(a, b):
+    """||a-b|| / ||b|| per tensor (trap 5)."""
+    import torch
+
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    den = b.norm()
+    return float((a - b).norm() / den) if den > 0 else float((a - b).norm())
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
