@@ -34,6 +34,15 @@ def rel_err(a, b):
     return float((a - b).norm() / den) if den > 0 else float((a - b).norm())
 
 
+def assert_close(a, b, tol, name="", atol=1e-6):
+    """||a-b|| <= tol*||b|| + atol*sqrt(numel): relative per tensor, with an absolute floor
+    so that exactly-zero references (e.g. dq when n == 1) stay well posed."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err, den = float((a - b).norm()), float(b.norm())
+    assert err <= tol * den + atol * (b.numel() ** 0.5), f"{name}: |a-b|={err:.3e} |b|={den:.3e} rel={err / max(den, 1e-300):.3e} tol={tol}"
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

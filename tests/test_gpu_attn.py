@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, rel_err
+from conftest import GOLDEN, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3  # north_star: 1e-3 relative (||a-b||/||b|| per tensor), fp32
@@ -34,3 +34,92 @@ def test_attn_fwd_golden(path):
     # fp32 HIP should sit as close to the fp64 truth as the fp32 reference does (few ulp)
     ctx64, _ = attn_core_fwd(q.double().cpu(), k.double().cpu(), v.double().cpu(), scale)
     assert rel_err(ctx, ctx64) < 2e-5
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_attn_*.npz"))), ids=os.path.basename)
+def test_attn_bwd_golden(path):
+    from cabinet_amd.functional import attn_bwd_hip, attn_fwd_hip
+
+    g = _load(path)
+    q, k, v, dctx = (g[n].flatten(2).cuda() for n in ("q", "k", "v", "g"))
+    scale = float(g["scale"])
+    ctx, lse = attn_fwd_hip(q, k, v, scale)
+    dq, dk, dv = attn_bwd_hip(dctx, q, k, v, ctx, lse, scale)
+    torch.cuda.synchronize()
+    for name, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert rel_err(got, g[name].flatten(2)) < TOL, name
+
+
+@pytest.mark.parametrize("B,Kc,Vc,n", [(1, 128, 128, 1), (1, 128, 128, 31), (2, 128, 128, 33), (3, 64, 64, 130),
+                                       (4, 128, 128, 256), (1, 256, 128, 2048), (8, 128, 128, 1024),
+                                       (2, 128, 128, 2048)])
+def test_attn_autograd_vs_oracle(B, Kc, Vc, n):
+    """cab_attention (autograd Function over the C ABI) vs the explicit-formula oracle, fp64 truth."""
+    from cabinet_amd.functional import cab_attention
+    from oracle.cab_math import attn_core_bwd, attn_core_fwd
+
+    gen = torch.Generator().manual_seed(1000 + n)
+    q = torch.randn(B, Kc, n, generator=gen).relu()
+    k = torch.randn(B, Kc, n, generator=gen)
+    v = torch.randn(B, Vc, n, generator=gen)
+    g = torch.randn(B, Vc, n, generator=gen)
+    scale = Kc ** -0.5
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    ctx = cab_attention(qd, kd, vd, scale)
+    ctx.backward(g.cuda())
+    torch.cuda.synchronize()
+    ctx_ref, lse_ref = attn_core_fwd(q, k, v, scale)  # fp32 CPU oracle
+    dq_ref, dk_ref, dv_ref = attn_core_bwd(g, q, k, v, ctx_ref, lse_ref, scale)
+    assert_close(ctx, ctx_ref, TOL, "ctx")
+    assert_close(qd.grad, dq_ref, TOL, "dq")
+    assert_close(kd.grad, dk_ref, TOL, "dk")
+    assert_close(vd.grad, dv_ref, TOL, "dv")
+    if B * n * n <= 4 * 1024 * 1024:  # fp64 truth where it is cheap
+        ctx64, lse64 = attn_core_fwd(q.double(), k.double(), v.double(), scale)
+        d64 = attn_core_bwd(g.double(), q.double(), k.double(), v.double(), ctx64, lse64, scale)
+        assert_close(ctx, ctx64, 2e-5, "ctx vs fp64")
+        for nm, got, want in zip(("dq", "dk", "dv"), (qd.grad, kd.grad, vd.grad), d64):
+            assert_close(got, want, 5e-5, nm + " vs fp64")
+
+
+def test_attn_properties_full_size():
+    """Size-independent properties at BASELINE config-3 size (B=8, n=1024)."""
+    from cabinet_amd.functional import attn_fwd_hip
+
+    B, Kc, Vc, n = 8, 128, 128, 1024
+    gen = torch.Generator().manual_seed(7)
+    q = torch.randn(B, Kc, n, generator=gen).relu().cuda()
+    k = torch.randn(B, Kc, n, generator=gen).cuda()
+    v = torch.randn(B, Vc, n, generator=gen).cuda()
+    scale = Kc ** -0.5
+    ctx, lse = attn_fwd_hip(q, k, v, scale)
+    # rows of P sum to one: a constant value field is reproduced
+    ones = torch.ones_like(v)
+    c1, _ = attn_fwd_hip(q, k, ones, scale)
+    assert (c1 - 1).abs().max() < 1e-5
+    # linear in v
+    v2 = torch.randn(B, Vc, n, generator=gen).cuda()
+    ca, _ = attn_fwd_hip(q, k, v + 2 * v2, scale)
+    cb, _ = attn_fwd_hip(q, k, v2, scale)
+    assert rel_err(ca, ctx + 2 * cb) < 1e-5
+    # permuting the keys (and values alike) leaves ctx and lse unchanged
+    perm = torch.randperm(n, generator=gen).cuda()
+    cp, lp = attn_fwd_hip(q, k[:, :, perm].contiguous(), v[:, :, perm].contiguous(), scale)
+    assert rel_err(cp, ctx) < 1e-5 and rel_err(lp, lse) < 1e-6
+    # zero keys -> uniform attention: ctx = mean_j v, lse = log n
+    c0, l0 = attn_fwd_hip(q, torch.zeros_like(k), v, scale)
+    assert rel_err(c0, v.mean(dim=2, keepdim=True).expand_as(v)) < 1e-5
+    assert (l0 - float(np.log(n))).abs().max() < 1e-5
+    # bitwise reproducible
+    c2, l2 = attn_fwd_hip(q, k, v, scale)
+    assert torch.equal(c2, ctx) and torch.equal(l2, lse)
+
+
+def test_attn_rejects_bad_input():
+    from cabinet_amd.functional import attn_fwd_hip, cab_attention
+
+    q = torch.randn(1, 48, 64).cuda()
+    with pytest.raises(RuntimeError, match="no gfx950 instantiation"):
+        attn_fwd_hip(q, q, q, 1.0)
+    with pytest.raises(RuntimeError, match="bad shapes"):
+        cab_attention(q, q[:, :, :32], q, 1.0)
