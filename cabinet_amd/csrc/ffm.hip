@@ -1,9 +1,698 @@
-// placeholder until K3/K4 land
+// K3 / K4 -- Feature Fusion Module forward and backward on gfx950.
+//
+// Replaces reference src/models/cabinet.py:142-153 (+ ConvBNReLU, cabinet.py:42-44):
+//   z = W_blk . cat(fsp, fcp)      1x1 conv == GEMM  (Co x Cin) x (Cin x B*H*W)
+//   feat = relu(BN(z));  m = mean_hw(feat);  a = sigmoid(W2 relu(W1 m));  out = feat * (1 + a)
+//
+// HBM plan (fp32, P = H*W pixels per image; the concat is never materialised and feat is
+// never written -- z is the one saved activation, feat is recomputed where needed):
+//   fwd  : G1 GEMM      read fsp,fcp (Cin*P)   write z (Co*P)   + BN partial sums in epilogue
+//          pool         read z                                   (needs global BN stats first)
+//          gate         read z                  write out
+//   bwd  : reduce       read dout, z            5 sums per (b,c)
+//          small        SE-MLP backward, BN coefficient algebra  (one workgroup)
+//          dz           read dout, z            write dz
+//          G2 GEMM      read dz                 write dfsp, dfcp  (dX = W^T dz)
+//          G3 GEMM      read dz, fsp, fcp       split-K partials -> dW_blk
+// GEMMs run on v_mfma_f32_32x32x2_f32 (exact fp32).  Every operand is read with the
+// contiguous (pixel or output-channel) index on the lane: G1/G2 are "K-major" products
+// (A_t[k][m], B[k][p]) that need no transposition at all; G3 contracts over pixels, so both
+// operands go through padded (stride 33) LDS images.
 #include "common.hpp"
+
 namespace cabinet {
-struct FfmShape { int B, Cs, Cc, Co, Cm, H, W; };
-size_t ffm_fwd_workspace(const FfmShape&) { return 0; }
-size_t ffm_bwd_workspace(const FfmShape&) { return 0; }
-hipError_t ffm_fwd_run(const FfmShape&, const float*, const float*, const float*, const float*, const float*, float*, float*, const float*, const float*, int, float, float, float*, float*, float*, float*, float*, float*, void*, hipStream_t) { return hipErrorNotSupported; }
-hipError_t ffm_bwd_run(const FfmShape&, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, float*, float*, float*, float*, float*, float*, float*, void*, hipStream_t) { return hipErrorNotSupported; }
+
+struct FfmShape {
+    int B, Cs, Cc, Co, Cm, H, W;
+};
+
+// =====================================================================================
+// G1 / G2:  D[m][p] = sum_k At[k][m] * Bm[k][p]   per image
+// =====================================================================================
+struct GemmKArgs {
+    const float* at;   // [K][M], M contiguous (shared by all images)
+    int M, K;
+    const float* src0; // B-operand rows k <  K0 : (B, K0, P)
+    const float* src1; // B-operand rows k >= K0 : (B, K-K0, P)
+    int K0;
+    float* dst0;       // output rows m <  M0 : (B, M0, P)
+    float* dst1;       // output rows m >= M0 : (B, M-M0, P)
+    int M0;
+    int P;
+    float* stat_part;  // nullptr or [B*gridDim.x][2][M] per-tile (sum, sum of squares) over pixels
+};
+
+constexpr int GK_BK = 16;   // k-chunk
+constexpr int GK_NT = 128;  // pixels per tile (2 waves x 2 blocks x 32)
+
+template <int WM>  // 32-row blocks per wave along m; tile = 4 waves x WM x 32 rows
+__global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
+    constexpr int MT = 128 * WM;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                    // [2][BK][MT]
+    float* Bs = smem + 2 * GK_BK * MT;   // [2][BK][NT]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z, p0 = blockIdx.x * GK_NT, m0 = blockIdx.y * MT;
+    const int P = a.P, M = a.M, K = a.K;
+    const bool vec_ok = (P & 3) == 0;
+
+    f32x16 acc[WM][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging registers: WM float4 of A and one float4 of B per thread and chunk
+    f32x4 ra[WM], rb;
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int idx = tid + i * 512, kk = idx / (MT / 4), c4 = idx % (MT / 4);
+            const int m = m0 + c4 * 4;
+            if (m < M)
+                ra[i] = *reinterpret_cast<const f32x4*>(a.at + (size_t)(k0 + kk) * M + m);
+            else
+                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            const int kk = tid >> 5, c4 = tid & 31, k = k0 + kk, p = p0 + c4 * 4;
+            const float* row = (k < a.K0) ? a.src0 + ((size_t)b * a.K0 + k) * P
+                                          : a.src1 + ((size_t)b * (K - a.K0) + (k - a.K0)) * P;
+            if (vec_ok && p + 3 < P) {
+                rb = *reinterpret_cast<const f32x4*>(row + p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[e] = (p + e < P) ? row[p + e] : 0.f;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int idx = tid + i * 512;
+            *reinterpret_cast<f32x4*>(As + (size_t)buf * GK_BK * MT + idx * 4) = ra[i];
+        }
+        *reinterpret_cast<f32x4*>(Bs + (size_t)buf * GK_BK * GK_NT + tid * 4) = rb;
+    };
+
+    const int nchunks = K / GK_BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunks) load_chunk((kc + 1) * GK_BK);
+        const float* Ab = As + (size_t)buf * GK_BK * MT + wm * (WM * 32) + li;
+        const float* Bb = Bs + (size_t)buf * GK_BK * GK_NT + wn * 64 + li;
+#pragma unroll
+        for (int kk = 0; kk < GK_BK; kk += 2) {
+            float av[WM], bv[2];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = Ab[(kk + h) * MT + i * 32];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bb[(kk + h) * GK_NT + j * 32];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+        }
+        if (kc + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: store D; optional per-row (sum, sumsq) over this tile's valid pixels ----
+    float* s_stat = smem;  // [2 (wn)][2][MT], aliases As after the final barrier
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h;  // row inside the tile
+            const int m = m0 + ml;
+            float s1 = 0.f, s2 = 0.f;
+            float* drow = nullptr;
+            if (m < M)
+                drow = (m < a.M0) ? a.dst0 + ((size_t)b * a.M0 + m) * P
+                                  : a.dst1 + ((size_t)b * (M - a.M0) + (m - a.M0)) * P;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = p0 + wn * 64 + j * 32 + li;
+                const float val = acc[i][j][r];
+                if (p < P) {
+                    if (drow) drow[p] = val;
+                    s1 += val;
+                    s2 += val * val;
+                }
+            }
+            if (a.stat_part) {
+                s1 = half_sum(s1);
+                s2 = half_sum(s2);
+                if (li == 0) {
+                    s_stat[(wn * 2 + 0) * MT + ml] = s1;
+                    s_stat[(wn * 2 + 1) * MT + ml] = s2;
+                }
+            }
+        }
+    }
+    if (a.stat_part) {
+        __syncthreads();
+        float* part = a.stat_part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * M;
+        for (int ml = tid; ml < MT; ml += 512) {
+            const int m = m0 + ml;
+            if (m < M) {
+                part[m] = s_stat[0 * MT + ml] + s_stat[2 * MT + ml];
+                part[M + m] = s_stat[1 * MT + ml] + s_stat[3 * MT + ml];
+            }
+        }
+    }
+}
+
+template <int WM>
+static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
+    constexpr int MT = 128 * WM;
+    const size_t lds = (size_t)(2 * GK_BK * MT + 2 * GK_BK * GK_NT) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid(ceil_div(a.P, GK_NT), ceil_div(a.M, MT), B);
+    hipLaunchKernelGGL(gemm_kmajor_kernel<WM>, grid, dim3(512), lds, stream, a);
+}
+
+static void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
+    if (a.M > 256 && a.M <= 384)
+        launch_gemm_k<3>(a, B, stream);
+    else
+        launch_gemm_k<2>(a, B, stream);
+}
+
+// =====================================================================================
+// G3:  dW[o][c] = sum_{b,p} dz[b][o][p] * X[b][c][p]      (contraction over pixels, split-K)
+// =====================================================================================
+constexpr int G3_T = 128;    // output tile (o and c)
+constexpr int G3_BK = 32;    // pixels per chunk
+constexpr int G3_STR = 33;
+
+__global__ __launch_bounds__(256) void gemm_dw_kernel(const float* __restrict__ dz, const float* __restrict__ fsp,
+                                                       const float* __restrict__ fcp, float* __restrict__ part,
+                                                       int B, int Co, int Cs, int Cc, int P, int chunks_per_img,
+                                                       int chunks_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Az = smem;                         // [2][128][33]   dz rows (o) x pixels
+    float* Bx = smem + 2 * G3_T * G3_STR;     // [2][128][33]   X rows (c) x pixels
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wo = wave >> 1, wc = wave & 1;
+    const int o0 = blockIdx.x * G3_T, c0 = blockIdx.y * G3_T, split = blockIdx.z;
+    const int Cin = Cs + Cc;
+    const int chunk_lo = split * chunks_per_split;
+    const int chunk_hi = min(chunk_lo + chunks_per_split, B * chunks_per_img);
+    const bool vec_ok = (P & 3) == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: each operand chunk is 128 rows x 32 px = 1024 float4 -> 4 per thread
+    f32x4 rz[4], rx[4];
+    auto load_chunk = [&](int chunk) {
+        const int b = chunk / chunks_per_img, p0 = (chunk % chunks_per_img) * G3_BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, p = p0 + (idx & 7) * 4;
+            const int o = o0 + row, c = c0 + row;
+            const float* zr = (o < Co) ? dz + ((size_t)b * Co + o) * P : nullptr;
+            const float* xr = (c < Cs)    ? fsp + ((size_t)b * Cs + c) * P
+                              : (c < Cin) ? fcp + ((size_t)b * Cc + (c - Cs)) * P
+                                          : nullptr;
+            if (vec_ok && p + 3 < P) {
+                rz[i] = zr ? *reinterpret_cast<const f32x4*>(zr + p) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rx[i] = xr ? *reinterpret_cast<const f32x4*>(xr + p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rz[i][e] = (zr && p + e < P) ? zr[p + e] : 0.f;
+                    rx[i][e] = (xr && p + e < P) ? xr[p + e] : 0.f;
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, col = (idx & 7) * 4;
+            float* za = Az + (size_t)buf * G3_T * G3_STR + row * G3_STR + col;
+            float* xa = Bx + (size_t)buf * G3_T * G3_STR + row * G3_STR + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                za[e] = rz[i][e];
+                xa[e] = rx[i][e];
+            }
+        }
+    };
+
+    if (chunk_lo < chunk_hi) {
+        load_chunk(chunk_lo);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+        const int buf = (chunk - chunk_lo) & 1;
+        if (chunk + 1 < chunk_hi) load_chunk(chunk + 1);
+        const float* Ab = Az + (size_t)buf * G3_T * G3_STR + (wo * 64 + li) * G3_STR + h;
+        const float* Bb = Bx + (size_t)buf * G3_T * G3_STR + (wc * 64 + li) * G3_STR + h;
+#pragma unroll
+        for (int kk = 0; kk < G3_BK; kk += 2) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = Ab[i * 32 * G3_STR + kk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = Bb[j * 32 * G3_STR + kk];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+        }
+        if (chunk + 1 < chunk_hi) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    // partial slab: part[split][Co][Cin]
+    float* slab = part + (size_t)split * Co * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wo * 64 + i * 32 + acc_row(r) + 4 * h;
+                const int c = c0 + wc * 64 + j * 32 + li;
+                if (o < Co && c < Cin) slab[(size_t)o * Cin + c] = acc[i][j][r];
+            }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, int count, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * count + i];
+    out[i] = s;
+}
+
+static int dw_nsplit(int total_chunks) { return total_chunks < 64 ? total_chunks : 64; }
+
+// =====================================================================================
+// small kernels
+// =====================================================================================
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (x < cols && y0 + j < rows) tile[j][threadIdx.x] = in[(size_t)(y0 + j) * cols + x];
+    __syncthreads();
+    const int ox = blockIdx.y * 32 + threadIdx.x, oy0 = blockIdx.x * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (ox < rows && oy0 + j < cols) out[(size_t)(oy0 + j) * rows + ox] = tile[threadIdx.x][j];
+}
+
+// BN statistics: training -> reduce per-tile partials, update running buffers; eval -> running stats
+__global__ void bn_finalize_kernel(const float* __restrict__ stat_part, int ntiles, int C, long long count,
+                                   int training, float momentum, float eps, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ save_mean,
+                                   float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < ntiles; ++t) {
+            s1 += (double)stat_part[(size_t)t * 2 * C + c];
+            s2 += (double)stat_part[(size_t)t * 2 * C + C + c];
+        }
+        const double mean = s1 / (double)count;
+        double var = s2 / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unbiased = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    } else {
+        save_mean[c] = running_mean[c];
+        save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return t;
+}
+
+// pooled[b][c] = mean_p relu(bn(z[b][c][p]))        one workgroup per (b,c) row
+__global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                        float* __restrict__ pooled, int C, int P) {
+    __shared__ float s_red[4];
+    const int row = blockIdx.x, c = row % C;
+    const float sc = bn_w[c] * invstd[c], sh = bn_b[c] - mean[c] * sc;
+    const float* zr = z + (size_t)row * P;
+    float acc = 0.f;
+    if ((P & 3) == 0) {
+        for (int p = threadIdx.x * 4; p < P; p += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(zr + p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += fmaxf(fmaf(v[e], sc, sh), 0.f);
+        }
+    } else {
+        for (int p = threadIdx.x; p < P; p += 256) acc += fmaxf(fmaf(zr[p], sc, sh), 0.f);
+    }
+    acc = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0) pooled[row] = acc / (float)P;
+}
+
+// gate[b][c] = sigmoid(W2 relu(W1 pooled[b]))                 one workgroup per image
+__global__ __launch_bounds__(256) void ffm_se_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                      const float* __restrict__ w2, float* __restrict__ gate, int Co,
+                                                      int Cm) {
+    extern __shared__ float sm[];
+    float* m = sm;        // [Co]
+    float* r = sm + Co;   // [Cm]
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < Co; c += 256) m[c] = pooled[(size_t)b * Co + c];
+    __syncthreads();
+    for (int j = wave; j < Cm; j += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < Co; c += 64) acc += w1[(size_t)j * Co + c] * m[c];
+        acc = wave_sum(acc);
+        if (lane == 0) r[j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Co; c += 256) {
+        float acc = 0.f;
+        for (int j = 0; j < Cm; ++j) acc += w2[(size_t)c * Cm + j] * r[j];
+        gate[(size_t)b * Co + c] = 1.f / (1.f + expf(-acc));
+    }
+}
+
+// out = relu(bn(z)) * (1 + gate)                                 rows of P pixels
+__global__ __launch_bounds__(256) void ffm_gate_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                        const float* __restrict__ gate, float* __restrict__ out, int C,
+                                                        int P, int chunks_per_row) {
+    const int row = blockIdx.x / chunks_per_row, chunk = blockIdx.x % chunks_per_row, c = row % C;
+    const float sc = bn_w[c] * invstd[c], sh = bn_b[c] - mean[c] * sc, ga = 1.f + gate[row];
+    const float* zr = z + (size_t)row * P;
+    float* orow = out + (size_t)row * P;
+    const int lo = chunk * 4096, hi = min(lo + 4096, P);
+    if ((P & 3) == 0) {
+        for (int p = lo + threadIdx.x * 4; p < hi; p += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(zr + p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc, sh), 0.f) * ga;
+            *reinterpret_cast<f32x4*>(orow + p) = v;
+        }
+    } else {
+        for (int p = lo + threadIdx.x; p < hi; p += 256) orow[p] = fmaxf(fmaf(zr[p], sc, sh), 0.f) * ga;
+    }
+}
+
+// backward reduction: per (b,c) row five sums over pixels
+//   S1 = sum g*feat   S2 = sum g*mask   S3 = sum g*mask*xhat   S4 = sum mask   S5 = sum mask*xhat
+__global__ __launch_bounds__(256) void ffm_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ bn_w,
+                                                              const float* __restrict__ bn_b, float* __restrict__ sums,
+                                                              int C, int P) {
+    __shared__ float s_red[4];
+    const int row = blockIdx.x, c = row % C;
+    const float mu = mean[c], is = invstd[c], gw = bn_w[c], gb = bn_b[c];
+    const float* zr = z + (size_t)row * P;
+    const float* gr = g + (size_t)row * P;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
+    auto body = [&](float zv, float gv) {
+        const float xh = (zv - mu) * is;
+        const float y = fmaf(xh, gw, gb);
+        if (y > 0.f) {
+            s1 += gv * y;
+            s2 += gv;
+            s3 += gv * xh;
+            s4 += 1.f;
+            s5 += xh;
+        }
+    };
+    if ((P & 3) == 0) {
+        for (int p = threadIdx.x * 4; p < P; p += 1024) {
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(zr + p);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gr + p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) body(zv[e], gv[e]);
+        }
+    } else {
+        for (int p = threadIdx.x; p < P; p += 256) body(zr[p], gr[p]);
+    }
+    s1 = block_sum_256(s1, s_red);
+    s2 = block_sum_256(s2, s_red);
+    s3 = block_sum_256(s3, s_red);
+    s4 = block_sum_256(s4, s_red);
+    s5 = block_sum_256(s5, s_red);
+    if (threadIdx.x == 0) {
+        float* o = sums + (size_t)row * 5;
+        o[0] = s1, o[1] = s2, o[2] = s3, o[3] = s4, o[4] = s5;
+    }
+}
+
+// SE-MLP backward + BN coefficient algebra; one workgroup, images processed in order
+// (deterministic).  Outputs dw1, dw2, dbn_w, dbn_b and the per-(b,c) / per-c coefficients of dz.
+__global__ __launch_bounds__(256) void ffm_bwd_small_kernel(
+    const float* __restrict__ sums, const float* __restrict__ pooled, const float* __restrict__ gate,
+    const float* __restrict__ w1, const float* __restrict__ w2, int B, int Co, int Cm, int P, int training,
+    float* __restrict__ dw1, float* __restrict__ dw2, float* __restrict__ dbn_w, float* __restrict__ dbn_b,
+    float* __restrict__ coef_a1, float* __restrict__ coef_a2, float* __restrict__ mean_dy,
+    float* __restrict__ mean_dyx) {
+    extern __shared__ float sm[];
+    float* m = sm;            // [Co] pooled
+    float* a = m + Co;        // [Co] gate
+    float* ds = a + Co;       // [Co]
+    float* u = ds + Co;       // [Cm]
+    float* du = u + Cm;       // [Cm]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < Co * Cm; i += 256) dw1[i] = 0.f, dw2[i] = 0.f;
+    for (int c = tid; c < Co; c += 256) dbn_w[c] = 0.f, dbn_b[c] = 0.f;
+    const float inv_p = 1.f / (float)P;
+    for (int b = 0; b < B; ++b) {
+        for (int c = tid; c < Co; c += 256) {
+            const float av = gate[(size_t)b * Co + c];
+            m[c] = pooled[(size_t)b * Co + c];
+            a[c] = av;
+            ds[c] = sums[((size_t)b * Co + c) * 5 + 0] * av * (1.f - av);
+        }
+        __syncthreads();
+        for (int j = wave; j < Cm; j += 4) {  // u = W1 m ;  dr = W2^T ds
+            float acc = 0.f, dr = 0.f;
+            for (int c = lane; c < Co; c += 64) {
+                acc += w1[(size_t)j * Co + c] * m[c];
+                dr += w2[(size_t)c * Cm + j] * ds[c];
+            }
+            acc = wave_sum(acc);
+            dr = wave_sum(dr);
+            if (lane == 0) {
+                u[j] = acc;
+                du[j] = acc > 0.f ? dr : 0.f;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < Co * Cm; i += 256) {
+            {   // dw2[c][j] += ds[c] * relu(u[j])
+                const int c = i / Cm, j = i % Cm;
+                dw2[i] += ds[c] * fmaxf(u[j], 0.f);
+            }
+            {   // dw1[j][c] += du[j] * m[c]
+                const int j = i / Co, c = i % Co;
+                dw1[i] += du[j] * m[c];
+            }
+        }
+        for (int c = tid; c < Co; c += 256) {
+            float dm = 0.f;
+            for (int j = 0; j < Cm; ++j) dm += w1[(size_t)j * Co + c] * du[j];
+            const float a1 = 1.f + a[c], a2 = dm * inv_p;
+            const float* s = sums + ((size_t)b * Co + c) * 5;
+            coef_a1[(size_t)b * Co + c] = a1;
+            coef_a2[(size_t)b * Co + c] = a2;
+            dbn_b[c] += a1 * s[1] + a2 * s[3];
+            dbn_w[c] += a1 * s[2] + a2 * s[4];
+        }
+        __syncthreads();
+    }
+    const float inv_count = 1.f / ((float)B * (float)P);
+    for (int c = tid; c < Co; c += 256) {
+        mean_dy[c] = training ? dbn_b[c] * inv_count : 0.f;
+        mean_dyx[c] = training ? dbn_w[c] * inv_count : 0.f;
+    }
+}
+
+// dz = gamma*invstd * (dy - mean_dy - xhat*mean_dyx),  dy = mask * (g*a1 + a2)
+__global__ __launch_bounds__(256) void ffm_dz_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ bn_w, const float* __restrict__ bn_b,
+                                                      const float* __restrict__ coef_a1,
+                                                      const float* __restrict__ coef_a2,
+                                                      const float* __restrict__ mean_dy,
+                                                      const float* __restrict__ mean_dyx, float* __restrict__ dz, int C,
+                                                      int P, int chunks_per_row) {
+    const int row = blockIdx.x / chunks_per_row, chunk = blockIdx.x % chunks_per_row, c = row % C;
+    const float mu = mean[c], is = invstd[c], gw = bn_w[c], gb = bn_b[c];
+    const float a1 = coef_a1[row], a2 = coef_a2[row], mdy = mean_dy[c], mdyx = mean_dyx[c], gi = gw * is;
+    const float* zr = z + (size_t)row * P;
+    const float* gr = g + (size_t)row * P;
+    float* dr = dz + (size_t)row * P;
+    const int lo = chunk * 4096, hi = min(lo + 4096, P);
+    auto body = [&](float zv, float gv) {
+        const float xh = (zv - mu) * is;
+        const float y = fmaf(xh, gw, gb);
+        const float dy = y > 0.f ? fmaf(gv, a1, a2) : 0.f;
+        return gi * (dy - mdy - xh * mdyx);
+    };
+    if ((P & 3) == 0) {
+        for (int p = lo + threadIdx.x * 4; p < hi; p += 1024) {
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(zr + p);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gr + p);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = body(zv[e], gv[e]);
+            *reinterpret_cast<f32x4*>(dr + p) = o;
+        }
+    } else {
+        for (int p = lo + threadIdx.x; p < hi; p += 256) dr[p] = body(zr[p], gr[p]);
+    }
+}
+
+// =====================================================================================
+// host drivers
+// =====================================================================================
+static size_t wt_bytes(const FfmShape& s) { return align_up((size_t)(s.Cs + s.Cc) * s.Co * sizeof(float), 256); }
+static int fwd_tiles(const FfmShape& s) { return s.B * ceil_div(s.H * s.W, GK_NT); }
+
+size_t ffm_fwd_workspace(const FfmShape& s) {
+    return wt_bytes(s) + align_up((size_t)fwd_tiles(s) * 2 * s.Co * sizeof(float), 256);
+}
+
+hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, const float* w_blk,
+                       const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                       const float* w1, const float* w2, int training, float momentum, float eps, float* out,
+                       float* z, float* save_mean, float* save_invstd, float* pooled, float* gate, void* ws,
+                       hipStream_t stream) {
+    const int P = s.H * s.W, Cin = s.Cs + s.Cc;
+    float* wt = static_cast<float*>(ws);
+    float* stat_part = reinterpret_cast<float*>(static_cast<char*>(ws) + wt_bytes(s));
+    // W_blk (Co x Cin) -> Wt (Cin x Co): the K-major A operand of G1
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
+                       s.Co, Cin);
+    GemmKArgs a{};
+    a.at = wt, a.M = s.Co, a.K = Cin;
+    a.src0 = fsp, a.src1 = fcp, a.K0 = s.Cs;
+    a.dst0 = z, a.dst1 = z, a.M0 = s.Co;
+    a.P = P;
+    a.stat_part = training ? stat_part : nullptr;
+    gemm_kmajor(a, s.B, stream);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(s.Co, 256)), dim3(256), 0, stream, stat_part, fwd_tiles(s),
+                       s.Co, (long long)s.B * P, training, momentum, eps, run_mean, run_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w, bn_b,
+                       pooled, s.Co, P);
+    hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(256), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
+                       w2, gate, s.Co, s.Cm);
+    const int cpr = ceil_div(P, 4096);
+    hipLaunchKernelGGL(ffm_gate_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w,
+                       bn_b, gate, out, s.Co, P, cpr);
+    return hipGetLastError();
+}
+
+struct BwdWs {
+    size_t sums, a1, a2, mdy, mdyx, dz, part, total;
+};
+static BwdWs bwd_layout(const FfmShape& s) {
+    const int P = s.H * s.W, Cin = s.Cs + s.Cc;
+    const int total_chunks = s.B * ceil_div(P, G3_BK);
+    BwdWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    w.sums = take((size_t)s.B * s.Co * 5 * sizeof(float));
+    w.a1 = take((size_t)s.B * s.Co * sizeof(float));
+    w.a2 = take((size_t)s.B * s.Co * sizeof(float));
+    w.mdy = take((size_t)s.Co * sizeof(float));
+    w.mdyx = take((size_t)s.Co * sizeof(float));
+    w.dz = take((size_t)s.B * s.Co * P * sizeof(float));
+    w.part = take((size_t)dw_nsplit(total_chunks) * s.Co * Cin * sizeof(float));
+    w.total = off;
+    return w;
+}
+
+size_t ffm_bwd_workspace(const FfmShape& s) { return bwd_layout(s).total; }
+
+hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, const float* fcp,
+                       const float* w_blk, const float* bn_w, const float* bn_b, const float* w1,
+                       const float* w2, const float* z, const float* save_mean, const float* save_invstd,
+                       const float* pooled, const float* gate, int training, float* dfsp, float* dfcp,
+                       float* dw_blk, float* dbn_w, float* dbn_b, float* dw1, float* dw2, void* ws,
+                       hipStream_t stream) {
+    const int P = s.H * s.W, Cin = s.Cs + s.Cc;
+    const BwdWs L = bwd_layout(s);
+    char* base = static_cast<char*>(ws);
+    float* sums = reinterpret_cast<float*>(base + L.sums);
+    float* a1 = reinterpret_cast<float*>(base + L.a1);
+    float* a2 = reinterpret_cast<float*>(base + L.a2);
+    float* mdy = reinterpret_cast<float*>(base + L.mdy);
+    float* mdyx = reinterpret_cast<float*>(base + L.mdyx);
+    float* dz = reinterpret_cast<float*>(base + L.dz);
+    float* part = reinterpret_cast<float*>(base + L.part);
+
+    hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
+                       bn_w, bn_b, sums, s.Co, P);
+    hipLaunchKernelGGL(ffm_bwd_small_kernel, dim3(1), dim3(256), (size_t)(3 * s.Co + 2 * s.Cm) * sizeof(float), stream,
+                       sums, pooled, gate, w1, w2, s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, a1, a2, mdy,
+                       mdyx);
+    const int cpr = ceil_div(P, 4096);
+    hipLaunchKernelGGL(ffm_dz_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
+                       bn_w, bn_b, a1, a2, mdy, mdyx, dz, s.Co, P, cpr);
+    // G2: dX[c][p] = sum_o W[o][c] dz[o][p]   (A_t = W_blk as stored: [o][c], c contiguous)
+    GemmKArgs a{};
+    a.at = w_blk, a.M = Cin, a.K = s.Co;
+    a.src0 = dz, a.src1 = dz, a.K0 = s.Co;
+    a.dst0 = dfsp, a.dst1 = dfcp, a.M0 = s.Cs;
+    a.P = P;
+    a.stat_part = nullptr;
+    gemm_kmajor(a, s.B, stream);
+    // G3: dW = dz X^T, split over pixel chunks, then an ordered slab reduction
+    const int chunks_per_img = ceil_div(P, G3_BK), total_chunks = s.B * chunks_per_img;
+    const int nsplit = dw_nsplit(total_chunks), cps = ceil_div(total_chunks, nsplit);
+    const size_t lds = (size_t)(4 * G3_T * G3_STR) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_dw_kernel, dim3(ceil_div(s.Co, G3_T), ceil_div(Cin, G3_T), nsplit), dim3(256), lds, stream,
+                       dz, fsp, fcp, part, s.B, s.Co, s.Cs, s.Cc, P, chunks_per_img, cps);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(s.Co * Cin, 256)), dim3(256), 0, stream, part, dw_blk,
+                       s.Co * Cin, nsplit);
+    return hipGetLastError();
+}
+
 }  // namespace cabinet

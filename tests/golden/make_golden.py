@@ -95,7 +95,7 @@ def _grads(mod):
 
 
 def _state(mod, prefix, buffers_only=False):
-    return {f"{prefix}.{k}": v for k, v in mod.state_dict().items()
+    return {f"{prefix}.{k}": v.detach().clone() for k, v in mod.state_dict().items()
             if not buffers_only or k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
 
 

@@ -1,0 +1,110 @@
+"""HIP Feature Fusion Module (K3/K4, through the C ABI) vs golden vectors and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # north_star: 1e-3 relative (||a-b||/||b|| per tensor), fp32
+
+
+def _golden():
+    d = np.load(os.path.join(GOLDEN, "g3_ffm.npz"))
+    return {k: torch.from_numpy(d[k]) for k in d.files}
+
+
+def _bn_from(state, prefix, device):
+    bn = torch.nn.BatchNorm2d(state[prefix + "weight"].numel())
+    with torch.no_grad():
+        bn.weight.copy_(state[prefix + "weight"])
+        bn.bias.copy_(state[prefix + "bias"])
+        bn.running_mean.copy_(state[prefix + "running_mean"])
+        bn.running_var.copy_(state[prefix + "running_var"])
+        bn.num_batches_tracked.copy_(state[prefix + "num_batches_tracked"])
+    return bn.to(device)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_ffm_golden(mode):
+    from cabinet_amd.functional import ffm_fused
+
+    g = _golden()
+    init = {k[len("init."):]: v for k, v in g.items() if k.startswith("init.")}
+    bn = _bn_from(init, "convblk.bn.", "cuda")
+    bn.train(mode == "train")
+    fsp = g["fsp"].cuda().requires_grad_(True)
+    fcp = g["fcp"].cuda().requires_grad_(True)
+    wb = init["convblk.conv.weight"].cuda().requires_grad_(True)
+    w1 = init["conv1.weight"].cuda().requires_grad_(True)
+    w2 = init["conv2.weight"].cuda().requires_grad_(True)
+    out = ffm_fused(fsp, fcp, wb, bn, w1, w2)
+    out.backward(g["g"].cuda())
+    torch.cuda.synchronize()
+    assert_close(out, g[f"{mode}.out"], TOL, "out")
+    assert_close(fsp.grad, g[f"{mode}.dfsp"], TOL, "dfsp")
+    assert_close(fcp.grad, g[f"{mode}.dfcp"], TOL, "dfcp")
+    assert_close(wb.grad, g[f"{mode}.grad.convblk.conv.weight"], TOL, "dw_blk")
+    assert_close(bn.weight.grad, g[f"{mode}.grad.convblk.bn.weight"], TOL, "dbn_w")
+    assert_close(bn.bias.grad, g[f"{mode}.grad.convblk.bn.bias"], TOL, "dbn_b")
+    assert_close(w1.grad, g[f"{mode}.grad.conv1.weight"], TOL, "dw1")
+    assert_close(w2.grad, g[f"{mode}.grad.conv2.weight"], TOL, "dw2")
+    if mode == "train":
+        assert_close(bn.running_mean, g["after.convblk.bn.running_mean"], 1e-5, "running_mean")
+        assert_close(bn.running_var, g["after.convblk.bn.running_var"], 1e-5, "running_var")
+        assert int(bn.num_batches_tracked) == int(g["after.convblk.bn.num_batches_tracked"])
+    else:
+        assert_close(bn.running_mean, init["convblk.bn.running_mean"], 0.0, "running_mean untouched", atol=0)
+
+
+@pytest.mark.parametrize("B,Cs,Cc,Co,Cm,H,W,training", [
+    (1, 128, 256, 256, 64, 1, 1, False),      # single pixel (train-mode BN is undefined for one value)
+    (2, 128, 256, 256, 64, 1, 3, True),       # three pixels per image
+    (2, 128, 256, 256, 64, 5, 7, True),       # odd P (scalar load path), P < tile
+    (2, 128, 256, 256, 64, 32, 32, False),    # config-1/2 like
+    (4, 128, 256, 256, 64, 64, 64, True),     # BASELINE config 2 FFM shape
+    (3, 32, 64, 96, 24, 20, 13, True),        # generic channel counts, M not a tile multiple
+    (1, 256, 256, 512, 128, 16, 16, True),    # Co > 384 -> two m-tiles
+])
+def test_ffm_vs_oracle(B, Cs, Cc, Co, Cm, H, W, training):
+    from cabinet_amd.functional import ffm_fused
+    from oracle.cab_math import ffm_bwd, ffm_fwd
+
+    gen = torch.Generator().manual_seed(B * 1000 + H)
+    fsp = torch.randn(B, Cs, H, W, generator=gen)
+    fcp = torch.randn(B, Cc, H, W, generator=gen)
+    wb = torch.randn(Co, Cs + Cc, 1, 1, generator=gen) * (2.0 / (Cs + Cc)) ** 0.5
+    w1 = torch.randn(Cm, Co, 1, 1, generator=gen) * 0.1
+    w2 = torch.randn(Co, Cm, 1, 1, generator=gen) * 0.1
+    g = torch.randn(B, Co, H, W, generator=gen)
+    bn = torch.nn.BatchNorm2d(Co)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=gen)
+        bn.bias.uniform_(-0.3, 0.3, generator=gen)
+        bn.running_mean.uniform_(-0.2, 0.2, generator=gen)
+        bn.running_var.uniform_(0.5, 1.5, generator=gen)
+    bn.train(training)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    ref = ffm_fwd(fsp.double(), fcp.double(), wb.flatten(1).double(), bn.weight.detach().double(),
+                  bn.bias.detach().double(), rm0.double(), rv0.double(), w1.flatten(1).double(),
+                  w2.flatten(1).double(), training)
+    gr = ffm_bwd(g.double(), ref, wb.flatten(1).double(), bn.weight.detach().double(), w1.flatten(1).double(),
+                 w2.flatten(1).double(), training, Cs)
+    bn = bn.cuda()
+    t = [x.cuda().requires_grad_(True) for x in (fsp, fcp, wb, w1, w2)]
+    out = ffm_fused(t[0], t[1], t[2], bn, t[3], t[4])
+    out.backward(g.cuda())
+    torch.cuda.synchronize()
+    # B*P == 1 in train mode: variance of one sample, everything collapses; still must agree
+    assert_close(out, ref["out"], TOL, "out")
+    assert_close(t[0].grad, gr["dfsp"], TOL, "dfsp")
+    assert_close(t[1].grad, gr["dfcp"], TOL, "dfcp")
+    assert_close(t[2].grad.flatten(1), gr["dw_blk"], TOL, "dw_blk")
+    assert_close(bn.weight.grad, gr["dbn_w"], TOL, "dbn_w")
+    assert_close(bn.bias.grad, gr["dbn_b"], TOL, "dbn_b")
+    assert_close(t[3].grad.flatten(1), gr["dw1"], TOL, "dw1")
+    assert_close(t[4].grad.flatten(1), gr["dw2"], TOL, "dw2")
+    assert_close(bn.running_mean, ref["new_running_mean"], 1e-5, "running_mean")
+    assert_close(bn.running_var, ref["new_running_var"], 1e-5, "running_var")
