@@ -1,0 +1,186 @@
+"""CABiNet -- host-side mirror of reference ``src/models/cabinet.py``.
+
+Drop-in for ``from src.models.cabinet import CABiNet``: same constructor signature,
+``forward`` contract ``(final_logit, high_res_logit_up)``, ``get_params()`` grouping,
+sub-module names and ``state_dict`` keys.  On HIP tensors ``FeatureFusionModule.forward``
+(reference cabinet.py:142-153) runs as the fused gfx950 pipeline behind
+:func:`cabinet_amd.functional.ffm_fused` and the CAB attention core as one fused
+kernel (see ``cab.py``); backbone, spatial branch and heads stay on stock PyTorch-ROCm
+as BASELINE.json's north_star prescribes.
+"""
+
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..functional import ffm_fused
+from .cab import ContextAggregationBlock
+from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
+from .mobilenetv3 import MobileNetV3
+
+logger = logging.getLogger(__name__)
+
+
+def _resize(x, size):
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+class ConvBNReLU(nn.Module):
+    """conv -> BN -> ReLU, kaiming(a=1) conv init (reference cabinet.py:19-51)."""
+
+    def __init__(self, in_chan: int, out_chan: int, kernel_size: int = 3, stride: int = 1, padding: int = 1,
+                 dilation: int = 1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_chan, out_chan, kernel_size, stride, padding, dilation=dilation, bias=False)
+        self.bn = nn.BatchNorm2d(out_chan)
+        self.relu = nn.ReLU(inplace=True)
+        self.init_weight()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.relu(self.bn(self.conv(x)))
+
+    def init_weight(self) -> None:
+        nn.init.kaiming_normal_(self.conv.weight, a=1)
+        if self.conv.bias is not None:
+            nn.init.constant_(self.conv.bias, 0)
+
+
+class AttentionBranch(nn.Module):
+    """conva -> CAB -> convb, plus the cat -> 3x3 -> BN -> ReLU -> 1x1 head (reference cabinet.py:54-105)."""
+
+    def __init__(self, inplanes: int, interplanes: int, outplanes: int, num_classes: int):
+        super().__init__()
+        self.conva = nn.Sequential(nn.Conv2d(inplanes, interplanes, 3, padding=1, bias=False),
+                                   nn.BatchNorm2d(interplanes), nn.ReLU(True))
+        self.a2block = ContextAggregationBlock(interplanes, interplanes // 2)
+        self.convb = nn.Conv2d(interplanes, outplanes, kernel_size=1, bias=True)
+        self.b1 = nn.Conv2d(inplanes + outplanes, outplanes, 3, padding=1, bias=False)
+        self.b2 = nn.BatchNorm2d(outplanes)
+        self.b3 = nn.ReLU(True)
+        self.b4 = nn.Conv2d(outplanes, num_classes, kernel_size=1, bias=True)
+        self.init_weight()
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        feat = self.a2block(self.conva(x))
+        low_res_out = self.convb(feat)
+        high_res_out = self.b4(self.b3(self.b2(self.b1(torch.cat([x, feat], dim=1)))))
+        return low_res_out, high_res_out
+
+    def init_weight(self) -> None:
+        # walks EVERY conv below, including the CAB's zero-initialised project_out (cabinet.py:96-105)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+
+class SpatialBranch(nn.Module):
+    """7x7/2 -> 3x3/2 -> 3x3/2 -> 1x1: 128 channels at 1/8 resolution (reference cabinet.py:108-129)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvBNReLU(3, 64, kernel_size=7, stride=2, padding=3)
+        self.conv2 = ConvBNReLU(64, 64, kernel_size=3, stride=2, padding=1)
+        self.conv3 = ConvBNReLU(64, 64, kernel_size=3, stride=2, padding=1)
+        self.conv_out = ConvBNReLU(64, 128, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv_out(self.conv3(self.conv2(self.conv1(x))))
+
+
+class FeatureFusionModule(nn.Module):
+    """cat -> 1x1 conv -> BN -> ReLU -> channel gate (reference cabinet.py:132-153)."""
+
+    def __init__(self, in_chan: int, out_chan: int):
+        super().__init__()
+        self.convblk = ConvBNReLU(in_chan, out_chan, kernel_size=1, stride=1, padding=0)
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv1 = nn.Conv2d(out_chan, out_chan // 4, kernel_size=1, bias=False)
+        self.relu = nn.ReLU(True)
+        self.conv2 = nn.Conv2d(out_chan // 4, out_chan, kernel_size=1, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, fsp: torch.Tensor, fcp: torch.Tensor) -> torch.Tensor:
+        if fsp.is_cuda:  # fused gfx950 pipeline (K3/K4); raises if the HIP library is unusable
+            return ffm_fused(fsp, fcp, self.convblk.conv.weight, self.convblk.bn, self.conv1.weight,
+                             self.conv2.weight)
+        feat = self.convblk(torch.cat([fsp, fcp], dim=1))
+        atten = self.sigmoid(self.conv2(self.relu(self.conv1(self.avg_pool(feat)))))
+        return feat * atten + feat
+
+
+class CABiNetOutput(nn.Module):
+    """3x3 ConvBNReLU -> 1x1 classifier (reference cabinet.py:156-172)."""
+
+    def __init__(self, in_chan: int, mid_chan: int, n_classes: int):
+        super().__init__()
+        self.conv = ConvBNReLU(in_chan, mid_chan, kernel_size=3, padding=1)
+        self.conv_out = nn.Conv2d(mid_chan, n_classes, kernel_size=1, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv_out(self.conv(x))
+
+
+_DECODER_CHILDREN = ("ffm", "conv_out", "ab")
+
+
+class CABiNet(nn.Module):
+    """reference cabinet.py:175-300."""
+
+    def __init__(self, n_classes: int, backbone_weights: Optional[Path] = None, cfgs=None, mode="large"):
+        super().__init__()
+        if cfgs is None and mode in MOBILENETV3_CFGS:
+            cfgs = MOBILENETV3_CFGS[mode]  # convenience: the reference requires cfgs from its YAML
+        self.mobile = MobileNetV3(cfgs=cfgs, mode=mode, num_classes=n_classes, weights=backbone_weights)
+        config = MODEL_CONFIG.get(mode)
+        if config is None:
+            raise ValueError(f"Invalid mode: {mode}. Must be 'large' or 'small'")
+        self.attention_planes = config["attention_planes"]
+        if backbone_weights is not None:
+            logger.info(f"Backbone weights loaded from {backbone_weights} via MobileNetV3")
+        self.ab = AttentionBranch(self.attention_planes, 256, 256, n_classes)
+        self.sb = SpatialBranch()
+        self.ffm = FeatureFusionModule(128 + 256, 256)
+        self.conv_out = CABiNetOutput(256, 256, n_classes)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        size = x.shape[2:]
+        feat_sb = self.sb(x)                      # (B,128,H/8,W/8)
+        low, high = self.ab(self.mobile(x))       # (B,256,H/32,W/32), (B,ncls,H/32,W/32)
+        low_up = _resize(low, feat_sb.shape[2:])
+        high_up = _resize(high, feat_sb.shape[2:])
+        final = self.conv_out(self.ffm(feat_sb, low_up))
+        return _resize(final, size), _resize(high_up, size)
+
+    def get_params(self):
+        """(wd, no_wd, lr_mul_wd, lr_mul_no_wd) with the reference's type-based rule (cabinet.py:249-300):
+        Conv2d weights decay, Conv2d biases / BatchNorm / anything else (e.g. CAB.gamma) do not; the
+        children ``ffm``, ``conv_out`` and ``ab`` form the x10-LR decoder groups."""
+        groups = {False: ([], []), True: ([], [])}
+        for name, child in self.named_children():
+            decay, no_decay = groups[name in _DECODER_CHILDREN]
+            seen = set()
+            for m in child.modules():
+                if isinstance(m, nn.Conv2d):
+                    decay.append(m.weight)
+                    seen.add(id(m.weight))
+                    if m.bias is not None:
+                        no_decay.append(m.bias)
+                        seen.add(id(m.bias))
+                elif isinstance(m, nn.BatchNorm2d):
+                    for p in m.parameters():
+                        no_decay.append(p)
+                        seen.add(id(p))
+            no_decay.extend(p for p in child.parameters() if id(p) not in seen)
+        (wd, nowd), (lr_wd, lr_nowd) = groups[False], groups[True]
+        return wd, nowd, lr_wd, lr_nowd

@@ -1,0 +1,76 @@
+"""Training-step harness: the reference's ``train_step`` (src/scripts/train.py:429-441)
+around the MI355X-native model, single GPU or data-parallel over one node.
+
+The reference script itself cannot run here (Hydra / torchvision are absent and its
+Python never travels to the GPU box), so the step recipe is restated:
+
+* ``n_min = max(1, B*H*W // 16)`` per process, two ``OhemCELoss(0.7, n_min, 255)``
+  (train.py:329-349), ``loss = crit_p(out, lb) + crit_16(out16, lb)``, ``loss.backward()``;
+* fp32 end to end.  (The reference wraps the step in autocast; the parity contract of
+  BASELINE.json is against the fp32 CPU forward/backward, so autocast is off by default.)
+* under torchrun: gradients are averaged with :class:`cabinet_amd.ddp.BucketedGradReducer`.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .loss import OhemCELoss
+from .models.cabinet import CABiNet
+from .models.constants import DEFAULT_IGNORE_LABEL, DEFAULT_SCORE_THRESHOLD, MOBILENETV3_CFGS, OHEM_DIVISOR
+
+
+def build_model(mode="large", n_classes=8, device="cpu", seed=0, gamma=None, freeze_unused=True):
+    """Random-init CABiNet (model seed as in BASELINE.md); ``gamma`` overrides CAB's zero-init scale so
+    the attention kernels influence logits and gradients (parity trap 1)."""
+    torch.manual_seed(seed)
+    net = CABiNet(n_classes=n_classes, cfgs=MOBILENETV3_CFGS[mode], mode=mode)
+    if gamma is not None:
+        with torch.no_grad():
+            net.ab.a2block.gamma.fill_(float(gamma))
+    if freeze_unused:
+        # mobile.classifier never runs in forward (reference mobilenetv3.py:202-205): no grads, so
+        # keep it out of the gradient buckets (DDP pitfall 1)
+        for p in net.mobile.classifier.parameters():
+            p.requires_grad_(False)
+    return net.to(device)
+
+
+def make_criteria(batch, height, width, device, thresh=DEFAULT_SCORE_THRESHOLD, ignore=DEFAULT_IGNORE_LABEL):
+    n_min = max(1, batch * height * width // OHEM_DIVISOR)
+    return (OhemCELoss(thresh, n_min, ignore).to(device), OhemCELoss(thresh, n_min, ignore).to(device))
+
+
+class TrainStep:
+    """fwd + 2x OHEM-CE + bwd (+ gradient all-reduce when a reducer is given)."""
+
+    def __init__(self, net, criteria, reducer=None, optimizer=None, autocast=False):
+        self.net, (self.crit_p, self.crit_16) = net, criteria
+        self.reducer, self.optimizer, self.autocast = reducer, optimizer, autocast
+
+    def zero_grad(self):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            for p in self.net.parameters():
+                p.grad = None
+
+    def __call__(self, im, lb):
+        self.zero_grad()
+        with torch.amp.autocast(device_type=im.device.type, enabled=self.autocast):
+            out, out16 = self.net(im)
+            loss = self.crit_p(out, lb) + self.crit_16(out16, lb)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss.detach()
+
+
+def synthetic_batch(batch, height, width, n_classes, device, seed=1):
+    """Inputs of BASELINE.md section 2: images ~ N(0,1), labels uniform over classes, no ignore pixels."""
+    g = torch.Generator().manual_seed(seed)
+    im = torch.randn(batch, 3, height, width, generator=g)
+    lb = torch.randint(0, n_classes, (batch, height, width), generator=g)
+    return im.to(device), lb.to(device)
