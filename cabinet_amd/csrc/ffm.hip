@@ -39,7 +39,7 @@ struct GemmKArgs {
     float* dst1;       // output rows m >= M0 : (B, M-M0, P)
     int M0;
     int P;
-    float* stat_part;  // nullptr or [B*gridDim.x][2][M] per-tile (sum, sum of squares) over pixels
+    float* stat_part;  // nullptr or [2][M][B*gridDim.x] per-tile (sum, sum of squares) over pixels
 };
 
 constexpr int GK_BK = 16;   // k-chunk
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
     }
     if (a.stat_part) {
         __syncthreads();
-        float* part = a.stat_part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * M;
+        const size_t ntiles = (size_t)gridDim.x * gridDim.z, tile = (size_t)b * gridDim.x + blockIdx.x;
         for (int ml = tid; ml < MT; ml += 512) {
             const int m = m0 + ml;
             if (m < M) {
-                part[m] = s_stat[0 * MT + ml] + s_stat[2 * MT + ml];
-                part[M + m] = s_stat[1 * MT + ml] + s_stat[3 * MT + ml];
+                a.stat_part[(size_t)m * ntiles + tile] = s_stat[0 * MT + ml] + s_stat[2 * MT + ml];
+                a.stat_part[((size_t)M + m) * ntiles + tile] = s_stat[1 * MT + ml] + s_stat[3 * MT + ml];
             }
         }
     }
@@ -321,19 +321,43 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
         if (ox < rows && oy0 + j < cols) out[(size_t)(oy0 + j) * rows + ox] = tile[threadIdx.x][j];
 }
 
-// BN statistics: training -> reduce per-tile partials, update running buffers; eval -> running stats
-__global__ void bn_finalize_kernel(const float* __restrict__ stat_part, int ntiles, int C, long long count,
-                                   int training, float momentum, float eps, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ save_mean,
-                                   float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (training) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int t = 0; t < ntiles; ++t) {
-            s1 += (double)stat_part[(size_t)t * 2 * C + c];
-            s2 += (double)stat_part[(size_t)t * 2 * C + C + c];
+// BN statistics, one workgroup per channel: training -> reduce the per-tile partials (double),
+// update the running buffers; eval -> running statistics.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stat_part, int ntiles, int C,
+                                                           long long count, int training, float momentum, float eps,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd) {
+    __shared__ double s_red[2][4];
+    const int c = blockIdx.x;
+    if (!training) {
+        if (threadIdx.x == 0) {
+            save_mean[c] = running_mean[c];
+            save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
         }
+        return;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    const float* p1 = stat_part + (size_t)c * ntiles;
+    const float* p2 = stat_part + ((size_t)C + c) * ntiles;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        s1 += (double)p1[t];
+        s2 += (double)p2[t];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[0][threadIdx.x >> 6] = s1;
+        s_red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1 = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        s2 = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
         const double mean = s1 / (double)count;
         double var = s2 / (double)count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -342,9 +366,6 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stat_part, int ntil
         const double unbiased = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
         running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
         running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
-    } else {
-        save_mean[c] = running_mean[c];
-        save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
     }
 }
 
@@ -473,72 +494,87 @@ __global__ __launch_bounds__(256) void ffm_bwd_reduce_kernel(const float* __rest
     }
 }
 
-// SE-MLP backward + BN coefficient algebra; one workgroup, images processed in order
-// (deterministic).  Outputs dw1, dw2, dbn_w, dbn_b and the per-(b,c) / per-c coefficients of dz.
-__global__ __launch_bounds__(256) void ffm_bwd_small_kernel(
+// SE-MLP backward + BN coefficient algebra, stage 1: one workgroup per image.  Writes the dz
+// coefficients a1 = 1 + gate, a2 = dm / P and this image's contributions to dw1, dw2, dbn_w, dbn_b.
+__global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
     const float* __restrict__ sums, const float* __restrict__ pooled, const float* __restrict__ gate,
-    const float* __restrict__ w1, const float* __restrict__ w2, int B, int Co, int Cm, int P, int training,
-    float* __restrict__ dw1, float* __restrict__ dw2, float* __restrict__ dbn_w, float* __restrict__ dbn_b,
-    float* __restrict__ coef_a1, float* __restrict__ coef_a2, float* __restrict__ mean_dy,
-    float* __restrict__ mean_dyx) {
+    const float* __restrict__ w1, const float* __restrict__ w2, int Co, int Cm, int P,
+    float* __restrict__ dw1_part, float* __restrict__ dw2_part, float* __restrict__ dbn_part,
+    float* __restrict__ coef_a1, float* __restrict__ coef_a2) {
     extern __shared__ float sm[];
     float* m = sm;            // [Co] pooled
     float* a = m + Co;        // [Co] gate
     float* ds = a + Co;       // [Co]
     float* u = ds + Co;       // [Cm]
     float* du = u + Cm;       // [Cm]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < Co * Cm; i += 256) dw1[i] = 0.f, dw2[i] = 0.f;
-    for (int c = tid; c < Co; c += 256) dbn_w[c] = 0.f, dbn_b[c] = 0.f;
-    const float inv_p = 1.f / (float)P;
-    for (int b = 0; b < B; ++b) {
-        for (int c = tid; c < Co; c += 256) {
-            const float av = gate[(size_t)b * Co + c];
-            m[c] = pooled[(size_t)b * Co + c];
-            a[c] = av;
-            ds[c] = sums[((size_t)b * Co + c) * 5 + 0] * av * (1.f - av);
-        }
-        __syncthreads();
-        for (int j = wave; j < Cm; j += 4) {  // u = W1 m ;  dr = W2^T ds
-            float acc = 0.f, dr = 0.f;
-            for (int c = lane; c < Co; c += 64) {
-                acc += w1[(size_t)j * Co + c] * m[c];
-                dr += w2[(size_t)c * Cm + j] * ds[c];
-            }
-            acc = wave_sum(acc);
-            dr = wave_sum(dr);
-            if (lane == 0) {
-                u[j] = acc;
-                du[j] = acc > 0.f ? dr : 0.f;
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < Co * Cm; i += 256) {
-            {   // dw2[c][j] += ds[c] * relu(u[j])
-                const int c = i / Cm, j = i % Cm;
-                dw2[i] += ds[c] * fmaxf(u[j], 0.f);
-            }
-            {   // dw1[j][c] += du[j] * m[c]
-                const int j = i / Co, c = i % Co;
-                dw1[i] += du[j] * m[c];
-            }
-        }
-        for (int c = tid; c < Co; c += 256) {
-            float dm = 0.f;
-            for (int j = 0; j < Cm; ++j) dm += w1[(size_t)j * Co + c] * du[j];
-            const float a1 = 1.f + a[c], a2 = dm * inv_p;
-            const float* s = sums + ((size_t)b * Co + c) * 5;
-            coef_a1[(size_t)b * Co + c] = a1;
-            coef_a2[(size_t)b * Co + c] = a2;
-            dbn_b[c] += a1 * s[1] + a2 * s[3];
-            dbn_w[c] += a1 * s[2] + a2 * s[4];
-        }
-        __syncthreads();
-    }
-    const float inv_count = 1.f / ((float)B * (float)P);
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int c = tid; c < Co; c += 256) {
-        mean_dy[c] = training ? dbn_b[c] * inv_count : 0.f;
-        mean_dyx[c] = training ? dbn_w[c] * inv_count : 0.f;
+        const float av = gate[(size_t)b * Co + c];
+        m[c] = pooled[(size_t)b * Co + c];
+        a[c] = av;
+        ds[c] = sums[((size_t)b * Co + c) * 5 + 0] * av * (1.f - av);
+    }
+    __syncthreads();
+    for (int j = wave; j < Cm; j += 4) {  // u = W1 m ;  dr = W2^T ds
+        float acc = 0.f, dr = 0.f;
+        for (int c = lane; c < Co; c += 64) {
+            acc += w1[(size_t)j * Co + c] * m[c];
+            dr += w2[(size_t)c * Cm + j] * ds[c];
+        }
+        acc = wave_sum(acc);
+        dr = wave_sum(dr);
+        if (lane == 0) {
+            u[j] = acc;
+            du[j] = acc > 0.f ? dr : 0.f;
+        }
+    }
+    __syncthreads();
+    float* d1 = dw1_part + (size_t)b * Co * Cm;
+    float* d2 = dw2_part + (size_t)b * Co * Cm;
+    for (int i = tid; i < Co * Cm; i += 256) {
+        d2[i] = ds[i / Cm] * fmaxf(u[i % Cm], 0.f);  // dw2[c][j] = ds[c] relu(u[j])
+        d1[i] = du[i / Co] * m[i % Co];              // dw1[j][c] = du[j] m[c]
+    }
+    const float inv_p = 1.f / (float)P;
+    for (int c = tid; c < Co; c += 256) {
+        float dm = 0.f;
+        for (int j = 0; j < Cm; ++j) dm += w1[(size_t)j * Co + c] * du[j];
+        const float a1 = 1.f + a[c], a2 = dm * inv_p;
+        const float* s = sums + ((size_t)b * Co + c) * 5;
+        coef_a1[(size_t)b * Co + c] = a1;
+        coef_a2[(size_t)b * Co + c] = a2;
+        dbn_part[((size_t)b * 2 + 0) * Co + c] = a1 * s[1] + a2 * s[3];  // sum_p dy
+        dbn_part[((size_t)b * 2 + 1) * Co + c] = a1 * s[2] + a2 * s[4];  // sum_p dy * xhat
+    }
+}
+
+// stage 2: ordered sums over images (deterministic)
+__global__ void ffm_bwd_combine_kernel(const float* __restrict__ dw1_part, const float* __restrict__ dw2_part,
+                                       const float* __restrict__ dbn_part, int B, int Co, int Cm, int P, int training,
+                                       float* __restrict__ dw1, float* __restrict__ dw2, float* __restrict__ dbn_w,
+                                       float* __restrict__ dbn_b, float* __restrict__ mean_dy,
+                                       float* __restrict__ mean_dyx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = Co * Cm;
+    if (i < n) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            s1 += dw1_part[(size_t)b * n + i];
+            s2 += dw2_part[(size_t)b * n + i];
+        }
+        dw1[i] = s1;
+        dw2[i] = s2;
+    }
+    if (i < Co) {
+        float sb = 0.f, sw = 0.f;
+        for (int b = 0; b < B; ++b) {
+            sb += dbn_part[((size_t)b * 2 + 0) * Co + i];
+            sw += dbn_part[((size_t)b * 2 + 1) * Co + i];
+        }
+        dbn_b[i] = sb;
+        dbn_w[i] = sw;
+        const float inv_count = 1.f / ((float)B * (float)P);
+        mean_dy[i] = training ? sb * inv_count : 0.f;
+        mean_dyx[i] = training ? sw * inv_count : 0.f;
     }
 }
 
@@ -606,7 +642,7 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
     a.P = P;
     a.stat_part = training ? stat_part : nullptr;
     gemm_kmajor(a, s.B, stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(s.Co, 256)), dim3(256), 0, stream, stat_part, fwd_tiles(s),
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(s.Co), dim3(256), 0, stream, stat_part, fwd_tiles(s),
                        s.Co, (long long)s.B * P, training, momentum, eps, run_mean, run_var, save_mean, save_invstd);
     hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w, bn_b,
                        pooled, s.Co, P);
@@ -619,7 +655,7 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
 }
 
 struct BwdWs {
-    size_t sums, a1, a2, mdy, mdyx, dz, part, total;
+    size_t sums, a1, a2, mdy, mdyx, dw1p, dw2p, dbnp, dz, part, total;
 };
 static BwdWs bwd_layout(const FfmShape& s) {
     const int P = s.H * s.W, Cin = s.Cs + s.Cc;
@@ -636,6 +672,9 @@ static BwdWs bwd_layout(const FfmShape& s) {
     w.a2 = take((size_t)s.B * s.Co * sizeof(float));
     w.mdy = take((size_t)s.Co * sizeof(float));
     w.mdyx = take((size_t)s.Co * sizeof(float));
+    w.dw1p = take((size_t)s.B * s.Co * s.Cm * sizeof(float));
+    w.dw2p = take((size_t)s.B * s.Co * s.Cm * sizeof(float));
+    w.dbnp = take((size_t)s.B * 2 * s.Co * sizeof(float));
     w.dz = take((size_t)s.B * s.Co * P * sizeof(float));
     w.part = take((size_t)dw_nsplit(total_chunks) * s.Co * Cin * sizeof(float));
     w.total = off;
@@ -663,9 +702,13 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
 
     hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
                        bn_w, bn_b, sums, s.Co, P);
-    hipLaunchKernelGGL(ffm_bwd_small_kernel, dim3(1), dim3(256), (size_t)(3 * s.Co + 2 * s.Cm) * sizeof(float), stream,
-                       sums, pooled, gate, w1, w2, s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, a1, a2, mdy,
-                       mdyx);
+    float* dw1p = reinterpret_cast<float*>(base + L.dw1p);
+    float* dw2p = reinterpret_cast<float*>(base + L.dw2p);
+    float* dbnp = reinterpret_cast<float*>(base + L.dbnp);
+    hipLaunchKernelGGL(ffm_bwd_image_kernel, dim3(s.B), dim3(256), (size_t)(3 * s.Co + 2 * s.Cm) * sizeof(float), stream,
+                       sums, pooled, gate, w1, w2, s.Co, s.Cm, P, dw1p, dw2p, dbnp, a1, a2);
+    hipLaunchKernelGGL(ffm_bwd_combine_kernel, dim3(ceil_div(s.Co * s.Cm, 256)), dim3(256), 0, stream, dw1p, dw2p, dbnp,
+                       s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, mdy, mdyx);
     const int cpr = ceil_div(P, 4096);
     hipLaunchKernelGGL(ffm_dz_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
                        bn_w, bn_b, a1, a2, mdy, mdyx, dz, s.Co, P, cpr);

@@ -249,11 +249,27 @@ def train_step(w, x, labels, mode, thresh=0.7, ohem_divisor=16, ignore_lb=255):
     return out.detach(), out16.detach(), loss.detach()
 
 
-def time_cpu_baseline(state_dict, mode, batch, size, n_classes, steps=2, warmup=1, threads=None):
-    """Images/s of the CPU restatement on synthetic data (bench.py cpu_baseline leg)."""
+def usable_cpu_threads(cap=64):
+    """Host threads this process may really use: affinity mask and cgroup CPU quota, capped.
+
+    (os.cpu_count() on the GPU box reports every hardware thread of the node although the job's
+    cgroup grants a fraction of them; oversubscribing intra-op threads made the baseline ~40x slower.)
+    """
     import os
 
-    threads = threads or os.cpu_count()
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def time_cpu_baseline(state_dict, mode, batch, size, n_classes, steps=2, warmup=1, threads=None):
+    """Images/s of the CPU restatement on synthetic data (bench.py cpu_baseline leg)."""
+    threads = threads or usable_cpu_threads()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(batch, 3, size, size, generator=g)

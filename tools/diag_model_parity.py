@@ -1,0 +1,69 @@
+"""Diagnostic (not a test): per-tensor gradient deviation of the HIP-backed model vs fp32/fp64 CPU oracle,
+next to the same model run with stock ATen ops on the GPU."""
+import copy
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from cabinet_amd import functional  # noqa: E402
+from cabinet_amd.train import build_model, make_criteria, synthetic_batch  # noqa: E402
+from oracle import model_ref  # noqa: E402
+
+mode, batch, size, ncls = "small", 4, 512, 8
+net = build_model(mode, n_classes=ncls, seed=0, gamma=0.5, freeze_unused=False)
+sd = copy.deepcopy(net.state_dict())
+im, lb = synthetic_batch(batch, size, size, ncls, "cpu", seed=1)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+w32 = model_ref.Weights(sd)
+o32 = model_ref.train_step(w32, im, lb, mode)
+w64 = model_ref.Weights(sd, dtype=torch.float64)
+o64 = model_ref.train_step(w64, im.double(), lb, mode)
+g32, g64 = w32.grads(), w64.grads()
+
+
+def run_gpu(hip):
+    n = build_model(mode, n_classes=ncls, seed=0, gamma=0.5, freeze_unused=False)
+    n.load_state_dict(sd)
+    n = n.cuda().train()
+    if not hip:
+        # stock ATen on the GPU: composite ops instead of the HIP kernels (diagnostic only)
+        import torch.nn.functional as F
+
+        def attn(q, k, v, scale):
+            return torch.bmm(v, F.softmax(torch.bmm(q.transpose(1, 2), k) * scale, dim=-1).transpose(1, 2))
+        import cabinet_amd.models.cab as cabmod
+        import cabinet_amd.models.cabinet as cm
+        cabmod.cab_attention = attn
+
+        def ffm_fwd(self, fsp, fcp):
+            feat = self.convblk(torch.cat([fsp, fcp], dim=1))
+            atten = self.sigmoid(self.conv2(self.relu(self.conv1(self.avg_pool(feat)))))
+            return feat * atten + feat
+        cm.FeatureFusionModule.forward = ffm_fwd
+    crit = make_criteria(batch, size, size, "cuda")
+    out, out16 = n(im.cuda())
+    loss = crit[0](out, lb.cuda()) + crit[1](out16, lb.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    return out, out16, loss, {k: p.grad for k, p in n.named_parameters() if p.grad is not None}
+
+
+res = {"hip": run_gpu(True), "aten": run_gpu(False)}
+for tag, (out, out16, loss, g) in res.items():
+    print(f"== {tag}: loss {float(loss):.6f} (cpu32 {float(o32[2]):.6f}, cpu64 {float(o64[2]):.6f})")
+    print(f"   logits rel vs cpu32 {rel(out, o32[0]):.2e} / vs fp64 {rel(out, o64[0]):.2e};  cpu32 vs fp64 {rel(o32[0], o64[0]):.2e}")
+    rows = sorted(((rel(g[k], g32[k]), rel(g[k], g64[k]), rel(g32[k], g64[k]), k) for k in g), reverse=True)
+    print("   worst 12 grads: rel(gpu,cpu32) rel(gpu,fp64) rel(cpu32,fp64) name")
+    for r in rows[:12]:
+        print("   %.2e %.2e %.2e %s" % r)
+    hot = [r for r in rows if r[3].startswith(("ffm.", "ab.a2block."))]
+    print("   worst hot-path grads:")
+    for r in hot[:6]:
+        print("   %.2e %.2e %.2e %s" % r)
