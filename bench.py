@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--kernel-iters", type=int, default=30)
     return ap.parse_args()
 
@@ -222,12 +222,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model_ref
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-        cb = model_ref.time_cpu_baseline(sd, args.mode, args.cpu_batch, args.size, args.classes, steps=2, warmup=1)
+        cb = model_ref.time_cpu_baseline(sd, args.mode, args.cpu_batch, args.size, args.classes)
         result["cpu_baseline"] = {
             "value": round(cb["value"], 4), "unit": "images/s", "cores": cb["cores"], "kind": "port",
             "sample": (f"oracle/model_ref.py (PyTorch-CPU fp32 restatement of the reference, pinned to reference "
-                       f"vectors): B={args.cpu_batch} {args.size}x{args.size}, 1 warm-up + 2 timed steps of "
-                       "fwd + 2x OhemCE + bwd"),
+                       f"vectors): B={args.cpu_batch} {args.size}x{args.size}, 1 warm-up + {cb['timed_steps']} timed steps "
+                       f"({cb['seconds']:.1f} s) of fwd + 2x OhemCE + bwd"),
             "seconds_per_step": round(cb["seconds_per_step"], 3),
         }
     if rank == 0:

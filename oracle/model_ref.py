@@ -267,19 +267,27 @@ def usable_cpu_threads(cap=64):
     return max(1, min(n, cap))
 
 
-def time_cpu_baseline(state_dict, mode, batch, size, n_classes, steps=2, warmup=1, threads=None):
+def time_cpu_baseline(state_dict, mode, batch, size, n_classes, steps=8, warmup=1, threads=None,
+                      min_seconds=10.0, max_seconds=40.0):
     """Images/s of the CPU restatement on synthetic data (bench.py cpu_baseline leg)."""
     threads = threads or usable_cpu_threads()
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(batch, 3, size, size, generator=g)
     lb = torch.randint(0, n_classes, (batch, size, size), generator=g)
-    times = []
-    for it in range(warmup + steps):
+    times, it = [], 0
+    # bounded sample: `warmup` untimed steps, then timed steps until ~min_seconds of CPU work or `steps`
+    while True:
         w = Weights(state_dict)
         t0 = time.perf_counter()
         train_step(w, x, lb, mode)
+        dt = time.perf_counter() - t0
         if it >= warmup:
-            times.append(time.perf_counter() - t0)
+            times.append(dt)
+        it += 1
+        if len(times) >= steps or (len(times) >= 2 and sum(times) >= min_seconds) or \
+                (times and sum(times) >= max_seconds):
+            break
     dt = sum(times) / len(times)
-    return dict(value=batch / dt, seconds_per_step=dt, cores=threads, batch=batch)
+    return dict(value=batch / dt, seconds_per_step=dt, cores=threads, batch=batch, timed_steps=len(times),
+                seconds=sum(times))
