@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--kernel-iters", type=int, default=30)
+    ap.add_argument("--kernels-only", action="store_true", help="only time the hand-written kernels (dev aid)")
     return ap.parse_args()
 
 
@@ -138,6 +139,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.kernels_only:
+        for r in kernel_rooflines(args.batch, args.size, args.kernel_iters):
+            print(f"{r['kernel'][:52]:52s} {r['ms_per_launch'] * 1e3:9.1f} us  {r['tflops']:7.2f} TF/s  "
+                  f"frac {r['frac']:.3f}  {r['gbytes_per_s']:8.1f} GB/s")
+        return
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")

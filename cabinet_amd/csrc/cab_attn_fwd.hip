@@ -31,7 +31,7 @@ constexpr float kRescaleThreshold = 12.0f;  // log2 units
 template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit) {
+    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit, int B) {
     constexpr int VB = VC / 32;
     constexpr int VSTR = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -41,15 +41,24 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
     float* s_l = s_m + 128;             // [4][32] running sum
     float* s_f = s_l + 128;             // [4][32] merge factors
 
-    const int b = blockIdx.z, split = blockIdx.y, i0 = blockIdx.x * 32;
-    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+    // tile list is image-major: (b, split, query tile); each XCD takes a contiguous chunk of it so the
+    // (Kc+Vc) x n key/value panel of an image is fetched into ONE L2 instead of all eight
+    const int nqt = (n + 31) >> 5, per_img = nqt * kvsplit;
+    const int tile = xcd_chunked_tile(blockIdx.x, per_img * B);
+    const int b = tile / per_img, rem = tile - b * per_img, split = rem / nqt, i0 = (rem - split * nqt) * 32;
 
-    // Q operand: lane (li,h) holds q[2s+h][i0+li] * scale*log2(e) for s = 0..KC/2-1
+    const int row_bytes = n * 4;  // one NCHW row (channel) of this image
+    const buf_rsrc q_rs = make_rsrc(q + (size_t)b * KC * n, (unsigned)KC * row_bytes);
+    const buf_rsrc k_rs = make_rsrc(k + (size_t)b * KC * n, (unsigned)KC * row_bytes);
+    const buf_rsrc v_rs = make_rsrc(v + (size_t)b * VC * n, (unsigned)VC * row_bytes);
+
+    // Q operand: lane (li,h) holds the RAW q[2s+h][i0+li] for s = 0..KC/2-1 (no arithmetic on the loaded
+    // values, so the 64 loads stay in flight together); scale*log2(e) is applied inside the softmax.
     float qreg[KC / 2];
     {
-        const float* qp = q + qk_base + (size_t)h * n + min(i0 + li, n - 1);
+        const int voff = (h * n + min(i0 + li, n - 1)) * 4;
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) qreg[s] = qp[(size_t)(2 * s) * n] * qscale;
+        for (int s = 0; s < KC / 2; ++s) qreg[s] = bload(q_rs, voff, s * 2 * row_bytes);
     }
 
     f32x16 o[VB];
@@ -59,60 +68,107 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    const int NT = (n + 31) >> 5;
-    for (int t = split * 4 + wave; t < NT; t += 4 * kvsplit) {
-        const int j0 = t * 32;
-        const int jk = min(j0 + li, n - 1);
+    const int NT = (n + 31) >> 5, tstep = 4 * kvsplit;
+    int t = split * 4 + wave;
 
-        // ---- S^T = K^T Q  (keys in accumulator rows, query on the lane) ----
-        f32x16 s;
+    // ---- software-pipelined main loop -------------------------------------------------------------
+    // Iteration i overlaps three tiles so the matrix pipe always has a ready MFMA:
+    //   phase A:  S^T(i+1) chain (MFMA)      ||  V(i) registers -> LDS image          (LDS idle otherwise)
+    //   phase B:  O^T += V(i) P(i)^T (MFMA)  ||  softmax of S^T(i+1) on the VALU, loads K(i+2), V(i+1)
+    // K and V tiles are fetched one full phase before use; K loads are issued before V loads so the
+    // 6-bit in-order vmcnt can express "K landed" (<= 63 outstanding) without draining V.
+    float kA[KC / 2], vA[VC / 2];
+    auto load_k = [&](int tile_idx) {
+        const int voff = (h * n + min(min(tile_idx, NT - 1) * 32 + li, n - 1)) * 4;
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) kA[c2] = bload(k_rs, voff, c2 * 2 * row_bytes);
+    };
+    auto load_v = [&](int tile_idx) {
+        const int voff = (h * n + min(min(tile_idx, NT - 1) * 32 + li, n - 1)) * 4;
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) vA[c2] = bload(v_rs, voff, c2 * 2 * row_bytes);
+    };
+    auto s_chain = [&](f32x16& s) {  // S^T = K^T Q: keys in accumulator rows, query on the lane
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        {
-            const float* kp = k + qk_base + (size_t)h * n + jk;
 #pragma unroll
-            for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kp[(size_t)(2 * c2) * n], qreg[c2], s);
-        }
-        // ---- V tile -> wave-private LDS image vs[c][key] ----
-        {
-            const float* vp = v + v_base + (size_t)h * n + jk;
+        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kA[c2], qreg[c2], s);
+    };
+    auto v_to_lds = [&]() {  // channel-on-lane reads of V need the transpose: padded wave-private image
 #pragma unroll
-            for (int c2 = 0; c2 < VC / 2; ++c2) vs[(2 * c2 + h) * VSTR + li] = vp[(size_t)(2 * c2) * n];
-        }
-        if (j0 + 32 > n) {
+        for (int c2 = 0; c2 < VC / 2; ++c2) vs[(2 * c2 + h) * VSTR + li] = vA[c2];
+    };
+    // online softmax of one S^T tile, branch-free; statistics are per lane (= per query).
+    // Rescaling is deferred: the running max moves only when it grows by > 2^kRescaleThreshold.
+    auto softmax = [&](f32x16& s, int j0, float& alpha) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (j0 + acc_row(r) + 4 * h >= n) s[r] = -INFINITY;
-        }
-        // ---- online softmax, statistics per lane (= per query) ----
+        for (int r = 0; r < 16; ++r) s[r] = (j0 + acc_row(r) + 4 * h >= n) ? -INFINITY : s[r];
         float mt = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
-        mt = fmaxf(mt, swap_half(mt));
-        if (__any(mt > m + kRescaleThreshold)) {
-            const float mn = (mt > m + kRescaleThreshold) ? mt : m;
-            const float alpha = fast_exp2(m - mn);  // m == -inf -> 0
-            m = mn;
-            l *= alpha;
-#pragma unroll
-            for (int cb = 0; cb < VB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
-        }
+        mt = fmaxf(mt, swap_half(mt)) * qscale;  // qscale > 0: max commutes with the scaling
+        const float mn = (mt > m + kRescaleThreshold) ? mt : m;
+        alpha = fast_exp2(m - mn);  // 1 when the max stays; 0 on the first tile (m == -inf)
+        m = mn;
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = fast_exp2(s[r] - m);
+            s[r] = fast_exp2(fmaf(s[r], qscale, -mn));
             rs += s[r];
         }
-        l += rs;
-        // ---- O^T += V P^T : A = V[c][key] (channel on lane), B = P^T regs ----
+        l = l * alpha + rs;
+    };
+    auto pv = [&](const f32x16& p) {  // O^T += V P^T : A = V[c][key] from LDS, B = P^T registers
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = acc_row(r) + 4 * h;
 #pragma unroll
-            for (int cb = 0; cb < VB; ++cb) o[cb] = mfma32(vs[(cb * 32 + li) * VSTR + key], s[r], o[cb]);
+            for (int cb = 0; cb < VB; ++cb) o[cb] = mfma32(vs[(cb * 32 + li) * VSTR + key], p[r], o[cb]);
         }
+    };
+
+    if (t < NT) {
+        f32x16 p, sn;
+        float alpha;
+        load_k(t);
+        load_v(t);
+        s_chain(p);
+        load_k(t + tstep);
+        softmax(p, t * 32, alpha);  // O is still zero: nothing to rescale
+        for (; t + tstep < NT; t += tstep) {
+            // ---- phase A ----
+            s_chain(sn);
+            v_to_lds();
+#pragma unroll
+            for (int i = 0; i < KC / 2; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, (VC + KC - 1) / KC, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase B ----
+            load_k(t + 2 * tstep);
+            load_v(t + tstep);
+            pv(p);
+            softmax(sn, (t + tstep) * 32, alpha);
+#pragma unroll
+            for (int i = 0; i < 16 * VB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x20, (KC / 2 + VC / 2 + 16 * VB - 1) / (16 * VB), 1);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+            }
+            p = sn;
+        }
+        // ---- last tile of this wave: nothing left to overlap ----
+        v_to_lds();
+        pv(p);
     }
 
     // ---- merge the 4 waves (disjoint key subsets) ----
@@ -138,7 +194,7 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
         s_f[w * 32 + i] = (lt > 0.f) ? fast_exp2(s_m[w * 32 + i] - ms) / lt : 0.f;
     }
     __syncthreads();
-    const size_t out_base = ((size_t)split * gridDim.z + b) * VC * n;
+    const size_t out_base = ((size_t)split * B + b) * VC * n;
     for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
         const int c = idx >> 5, i = idx & 31;
         float acc = 0.f;
@@ -147,7 +203,7 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
         if (i0 + i < n) ctx[out_base + (size_t)c * n + i0 + i] = acc;
     }
     if (threadIdx.x < 32 && i0 + threadIdx.x < n)
-        lse[((size_t)split * gridDim.z + b) * n + i0 + threadIdx.x] =
+        lse[((size_t)split * B + b) * n + i0 + threadIdx.x] =
             (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
 }
 
@@ -186,12 +242,12 @@ static hipError_t launch_fwd(const float* q, const float* k, const float* v, flo
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid((n + 31) / 32, kvsplit, B);
+    dim3 grid(((n + 31) / 32) * kvsplit * B);
     if (kvsplit == 1) {
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q, k, v, ctx, lse, n, scale * LOG2E_F, 1);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q, k, v, ctx, lse, n, scale * LOG2E_F, 1, B);
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q, k, v, part_ctx, part_lse, n,
-                           scale * LOG2E_F, kvsplit);
+                           scale * LOG2E_F, kvsplit, B);
         dim3 mgrid((n + 255) / 256, VC < 32 ? VC : 32, B);
         hipLaunchKernelGGL(cab_attn_fwd_merge_kernel, mgrid, dim3(256), 0, stream, part_ctx, part_lse, ctx,
                            lse, B, VC, n, kvsplit);

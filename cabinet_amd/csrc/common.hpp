@@ -33,6 +33,24 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// ---- buffer loads: wave-uniform descriptor + per-lane byte offset + SCALAR byte offset, so a strided
+// walk over NCHW rows costs one SALU multiply per load and no vector address arithmetic ----
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(buf_rsrc r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Map the linear
+// block id to a tile index so that each XCD walks a CONTIGUOUS chunk of the tile list (bijective for
+// any total): tiles that share an operand panel then share one L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_chunked_tile(int block, int total) {
+    const int xcd = block & 7, slot = block >> 3, q = total >> 3, r = total & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 #define LOG2E_F 1.4426950408889634f
 #define LN2_F 0.6931471805599453f
 
