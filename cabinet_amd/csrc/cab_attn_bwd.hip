@@ -242,6 +242,276 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_kernel(
     }
 }
 
+// =====================================================================================================
+// Fast path (Kc <= 128 and Kc + Vc <= 256, i.e. what CABiNet itself uses): whole-tile transposed images
+// in LDS (XOR-swizzled, unpadded: element (c,pos) at c*32 + (pos ^ (c&31)), conflict-free for the
+// position-on-lane write and the channel-on-lane read), operands prefetched one tile ahead into
+// registers with scalar-offset buffer loads, XCD-chunked tile order.  No global value is read twice by a
+// wave and no load latency sits between MFMA chains.
+// =====================================================================================================
+__device__ __forceinline__ constexpr int simg(int c, int pos) { return c * 32 + (pos ^ (c & 31)); }
+
+template <int KC, int VC>
+__global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
+    const float* __restrict__ v, const float* __restrict__ ctx, const float* __restrict__ lse,
+    float* __restrict__ dq, float* __restrict__ delta, int n, float scale, int B) {
+    constexpr int KB = KC / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* qt = smem;                   // [KC][32]  q * scale*log2e   (B operand of S^T)
+    float* gt = qt + KC * 32;           // [VC][32]  g                 (B operand of dP^T)
+    float* kimg = gt + VC * 32;         // [4 waves][KC*32] swizzled transposed K tile
+    float* red = kimg + 4 * KC * 32;    // [KC][32]
+    float* s_part = red + KC * 32;      // [8][32]
+    float* s_delta = s_part + 256;      // [32]
+    float* s_lse = s_delta + 32;        // [32]
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int nqt = (n + 31) >> 5;
+    const int tile = xcd_chunked_tile(blockIdx.x, nqt * B);
+    const int b = tile / nqt, i0 = (tile - b * nqt) * 32;
+    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+    const float qscale = scale * LOG2E_F;
+    const int row_bytes = n * 4;
+    const buf_rsrc k_rs = make_rsrc(k + qk_base, (unsigned)KC * row_bytes);
+    const buf_rsrc v_rs = make_rsrc(v + v_base, (unsigned)VC * row_bytes);
+
+    const int NT = (n + 31) >> 5;
+    float kv[KC / 2], vv[VC / 2];
+    auto load_kv = [&](int t) {
+        const int voff = (h * n + min(min(t, NT - 1) * 32 + li, n - 1)) * 4;
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) kv[c2] = bload(k_rs, voff, c2 * 2 * row_bytes);
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) vv[c2] = bload(v_rs, voff, c2 * 2 * row_bytes);
+    };
+    load_kv(wave);  // in flight during the prologue
+
+    {
+        const int i = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int ig = min(i0 + i, n - 1);
+        for (int c = part; c < KC; c += 8) qt[c * 32 + i] = q[qk_base + (size_t)c * n + ig] * qscale;
+        float acc = 0.f;
+        for (int c = part; c < VC; c += 8) {
+            const float gv = g[v_base + (size_t)c * n + ig];
+            gt[c * 32 + i] = gv;
+            acc += gv * ctx[v_base + (size_t)c * n + ig];
+        }
+        s_part[part * 32 + i] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float d = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) d += s_part[p * 32 + threadIdx.x];
+        s_delta[threadIdx.x] = d;
+        const int ig = i0 + threadIdx.x;
+        if (ig < n) delta[(size_t)b * n + ig] = d;
+        s_lse[threadIdx.x] = lse[(size_t)b * n + min(ig, n - 1)] * LOG2E_F;
+    }
+    __syncthreads();
+    const float my_delta = s_delta[li], my_lse2 = s_lse[li];
+
+    f32x16 acc[KB];
+#pragma unroll
+    for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    float* kim = kimg + wave * (KC * 32);
+
+    for (int t = wave; t < NT; t += 4) {
+        const int j0 = t * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+        // S^T chain; the K registers are also laid down as the transposed image the dq product reads
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kv[c2], qt[(2 * c2 + h) * 32 + li], s);
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) kim[simg(2 * c2 + h, li)] = kv[c2];
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(vv[c2], gt[(2 * c2 + h) * 32 + li], dp);
+        __builtin_amdgcn_sched_barrier(0);
+        load_kv(t + 4);  // next tile: lands while the dq product below runs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = j0 + acc_row(r) + 4 * h < n;
+            const float p = valid ? fast_exp2(s[r] - my_lse2) : 0.f;
+            s[r] = p * (dp[r] - my_delta);  // dS^T[key][query]
+        }
+#pragma unroll
+        for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[cb] = mfma32(kim[simg(cb * 32 + li, acc_row(r) + 4 * h)], s[r], acc[cb]);
+    }
+
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    red[idx] = (w == 0) ? acc[cb][r] : red[idx] + acc[cb][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
+        const int c = idx >> 5, i = idx & 31;
+        if (i0 + i < n) dq[qk_base + (size_t)c * n + i0 + i] = red[idx] * scale;
+    }
+}
+
+template <int KC, int VC>
+__global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
+    const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dk, float* __restrict__ dv, int n, float scale, int B) {
+    constexpr int KB = KC / 32, VB = VC / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* kt = smem;                    // [KC][32] raw k tile   (B operand of S)
+    float* vt = kt + KC * 32;            // [VC][32] raw v tile   (B operand of dP)
+    float* img = vt + VC * 32;           // [4 waves][(KC+VC)*32] swizzled transposed q | g tiles
+    float* red = img;                    // reduction scratch aliases the images after the main loop
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int nkt = (n + 31) >> 5;
+    const int tile = xcd_chunked_tile(blockIdx.x, nkt * B);
+    const int b = tile / nkt, j0 = (tile - b * nkt) * 32;
+    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+    const float qscale = scale * LOG2E_F;
+    const int row_bytes = n * 4;
+    const buf_rsrc q_rs = make_rsrc(q + qk_base, (unsigned)KC * row_bytes);
+    const buf_rsrc g_rs = make_rsrc(g + v_base, (unsigned)VC * row_bytes);
+
+    const int NT = (n + 31) >> 5;
+    float qv[KC / 2], gv[VC / 2];
+    auto load_qg = [&](int t) {
+        const int voff = (h * n + min(min(t, NT - 1) * 32 + li, n - 1)) * 4;
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) qv[c2] = bload(q_rs, voff, c2 * 2 * row_bytes);
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) gv[c2] = bload(g_rs, voff, c2 * 2 * row_bytes);
+    };
+    load_qg(wave);
+    {
+        const int j = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int jg = min(j0 + j, n - 1);
+        for (int c = part; c < KC; c += 8) kt[c * 32 + j] = k[qk_base + (size_t)c * n + jg];
+        for (int c = part; c < VC; c += 8) vt[c * 32 + j] = v[v_base + (size_t)c * n + jg];
+    }
+    __syncthreads();
+
+    f32x16 dka[KB], dva[VB];
+#pragma unroll
+    for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dka[cb][r] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dva[cb][r] = 0.f;
+    float* qim = img + wave * ((KC + VC) * 32);
+    float* gim = qim + KC * 32;
+
+    for (int t = wave; t < NT; t += 4) {
+        const int i0 = t * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+        // row constants of this query tile (16 rows per lane half), issued early
+        float l2[16], dl[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t si = (size_t)b * n + min(i0 + acc_row(r) + 4 * h, n - 1);
+            l2[r] = lse[si];
+            dl[r] = delta[si];
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(qv[c2], kt[(2 * c2 + h) * 32 + li], s);
+#pragma unroll
+        for (int c2 = 0; c2 < KC / 2; ++c2) qim[simg(2 * c2 + h, li)] = qv[c2];
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(gv[c2], vt[(2 * c2 + h) * 32 + li], dp);
+#pragma unroll
+        for (int c2 = 0; c2 < VC / 2; ++c2) gim[simg(2 * c2 + h, li)] = gv[c2];
+        __builtin_amdgcn_sched_barrier(0);
+        load_qg(t + 4);  // next query tile: lands while the dv / dk products run
+        f32x16 p;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool valid = i0 + acc_row(r) + 4 * h < n;
+            p[r] = valid ? fast_exp2(fmaf(s[r], qscale, -l2[r] * LOG2E_F)) : 0.f;  // P[query][key]
+            s[r] = p[r] * (dp[r] - dl[r]);                                          // dS[query][key]
+        }
+#pragma unroll
+        for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dva[cb] = mfma32(gim[simg(cb * 32 + li, acc_row(r) + 4 * h)], p[r], dva[cb]);
+#pragma unroll
+        for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dka[cb] = mfma32(qim[simg(cb * 32 + li, acc_row(r) + 4 * h)], s[r], dka[cb]);
+    }
+
+    __syncthreads();  // every wave is done with its images: reuse them as reduction scratch
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    red[idx] = (w == 0) ? dka[cb][r] : red[idx] + dka[cb][r];
+                }
+#pragma unroll
+            for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idx = (KC + cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    red[idx] = (w == 0) ? dva[cb][r] : red[idx] + dva[cb][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
+        const int c = idx >> 5, j = idx & 31;
+        if (j0 + j < n) dk[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
+    }
+    for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
+        const int c = idx >> 5, j = idx & 31;
+        if (j0 + j < n) dv[v_base + (size_t)c * n + j0 + j] = red[KC * 32 + idx];
+    }
+}
+
+template <int KC, int VC>
+static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k, const float* v,
+                                  const float* ctx, const float* lse, float scale, int B, int n, float* dq,
+                                  float* dk, float* dv, float* delta, hipStream_t stream) {
+    const size_t lds_dq = (size_t)((KC + VC) * 32 + 4 * KC * 32 + KC * 32 + 256 + 64) * sizeof(float);
+    const size_t lds_kv = (size_t)((KC + VC) * 32 + 4 * (KC + VC) * 32) * sizeof(float);
+    auto k_dq = cab_attn_bwd_dq_fast_kernel<KC, VC>;
+    auto k_kv = cab_attn_bwd_dkdv_fast_kernel<KC, VC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dq),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_kv);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid(((n + 31) / 32) * B);
+    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, dq, delta, n, scale, B);
+    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale, B);
+    return hipGetLastError();
+}
+
 template <int KC, int VC>
 static hipError_t launch_bwd(const float* g, const float* q, const float* k, const float* v, const float* ctx,
                              const float* lse, float scale, int B, int n, float* dq, float* dk, float* dv,
@@ -277,11 +547,11 @@ hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, 
                              float* dq, float* dk, float* dv, void* ws, hipStream_t stream) {
     float* delta = static_cast<float*>(ws);
     if (Kc == 128 && Vc == 128)
-        return launch_bwd<128, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
+        return launch_bwd_fast<128, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
     if (Kc == 256 && Vc == 128)
         return launch_bwd<256, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
     if (Kc == 64 && Vc == 64)
-        return launch_bwd<64, 64>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
+        return launch_bwd_fast<64, 64>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
     return hipErrorInvalidValue;
 }
 
