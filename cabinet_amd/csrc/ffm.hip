@@ -45,7 +45,10 @@ struct GemmKArgs {
 constexpr int GK_BK = 16;   // k-chunk
 constexpr int GK_NT = 128;  // pixels per tile (2 waves x 2 blocks x 32)
 
-template <int WM>  // 32-row blocks per wave along m; tile = 4 waves x WM x 32 rows
+// INTERIOR: every tile is full (P % 128 == 0, M % tile == 0, 16-byte aligned rows): the staging loads
+// carry no guards, so nothing forces the compiler to wait for them before the MFMA block of the
+// current chunk (the guarded form branches per load and drains vmcnt at every join).
+template <int WM, bool INTERIOR>  // 32-row blocks per wave along m; tile = 4 waves x WM x 32 rows
 __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
     constexpr int MT = 128 * WM;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
         for (int i = 0; i < WM; ++i) {
             const int idx = tid + i * 512, kk = idx / (MT / 4), c4 = idx % (MT / 4);
             const int m = m0 + c4 * 4;
-            if (m < M)
+            if (INTERIOR || m < M)
                 ra[i] = *reinterpret_cast<const f32x4*>(a.at + (size_t)(k0 + kk) * M + m);
             else
                 ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
             const int kk = tid >> 5, c4 = tid & 31, k = k0 + kk, p = p0 + c4 * 4;
             const float* row = (k < a.K0) ? a.src0 + ((size_t)b * a.K0 + k) * P
                                           : a.src1 + ((size_t)b * (K - a.K0) + (k - a.K0)) * P;
-            if (vec_ok && p + 3 < P) {
+            if (INTERIOR || (vec_ok && p + 3 < P)) {
                 rb = *reinterpret_cast<const f32x4*>(row + p);
             } else {
 #pragma unroll
@@ -169,25 +172,27 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
     }
 }
 
-template <int WM>
+template <int WM, bool INTERIOR>
 static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
     constexpr int MT = 128 * WM;
     const size_t lds = (size_t)(2 * GK_BK * MT + 2 * GK_BK * GK_NT) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(ceil_div(a.P, GK_NT), ceil_div(a.M, MT), B);
-    hipLaunchKernelGGL(gemm_kmajor_kernel<WM>, grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm_kmajor_kernel<WM, INTERIOR>), grid, dim3(512), lds, stream, a);
 }
 
 static void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
-    if (a.M > 256 && a.M <= 384)
-        launch_gemm_k<3>(a, B, stream);
+    const bool wide = a.M > 256 && a.M <= 384;
+    const bool interior = (a.P % GK_NT) == 0 && (a.M % (wide ? 384 : 256)) == 0;
+    if (wide)
+        interior ? launch_gemm_k<3, true>(a, B, stream) : launch_gemm_k<3, false>(a, B, stream);
     else
-        launch_gemm_k<2>(a, B, stream);
+        interior ? launch_gemm_k<2, true>(a, B, stream) : launch_gemm_k<2, false>(a, B, stream);
 }
 
 // =====================================================================================
@@ -197,6 +202,7 @@ constexpr int G3_T = 128;    // output tile (o and c)
 constexpr int G3_BK = 32;    // pixels per chunk
 constexpr int G3_STR = 33;
 
+template <bool INTERIOR>  // INTERIOR: P % 32 == 0, Co % 128 == 0, Cs % 128 == 0, Cc % 128 == 0 (see G1/G2)
 __global__ __launch_bounds__(256) void gemm_dw_kernel(const float* __restrict__ dz, const float* __restrict__ fsp,
                                                        const float* __restrict__ fcp, float* __restrict__ part,
                                                        int B, int Co, int Cs, int Cc, int P, int chunks_per_img,
@@ -232,7 +238,11 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(const float* __restrict__ 
             const float* xr = (c < Cs)    ? fsp + ((size_t)b * Cs + c) * P
                               : (c < Cin) ? fcp + ((size_t)b * Cc + (c - Cs)) * P
                                           : nullptr;
-            if (vec_ok && p + 3 < P) {
+            if (INTERIOR) {
+                rz[i] = *reinterpret_cast<const f32x4*>(dz + ((size_t)b * Co + o) * P + p);
+                rx[i] = *reinterpret_cast<const f32x4*>(
+                    (c0 < Cs ? fsp + ((size_t)b * Cs + c) * P : fcp + ((size_t)b * Cc + (c - Cs)) * P) + p);
+            } else if (vec_ok && p + 3 < P) {
                 rz[i] = zr ? *reinterpret_cast<const f32x4*>(zr + p) : f32x4{0.f, 0.f, 0.f, 0.f};
                 rx[i] = xr ? *reinterpret_cast<const f32x4*>(xr + p) : f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
@@ -726,13 +736,22 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
     const size_t lds = (size_t)(4 * G3_T * G3_STR) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_dw_kernel, dim3(ceil_div(s.Co, G3_T), ceil_div(Cin, G3_T), nsplit), dim3(256), lds, stream,
-                       dz, fsp, fcp, part, s.B, s.Co, s.Cs, s.Cc, P, chunks_per_img, cps);
+    const bool interior = (P % G3_BK) == 0 && (s.Co % G3_T) == 0 && (s.Cs % G3_T) == 0 && (s.Cc % G3_T) == 0;
+    const dim3 g3grid(ceil_div(s.Co, G3_T), ceil_div(Cin, G3_T), nsplit);
+    if (interior)
+        hipLaunchKernelGGL(gemm_dw_kernel<true>, g3grid, dim3(256), lds, stream, dz, fsp, fcp, part, s.B, s.Co, s.Cs,
+                           s.Cc, P, chunks_per_img, cps);
+    else
+        hipLaunchKernelGGL(gemm_dw_kernel<false>, g3grid, dim3(256), lds, stream, dz, fsp, fcp, part, s.B, s.Co, s.Cs,
+                           s.Cc, P, chunks_per_img, cps);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(s.Co * Cin, 256)), dim3(256), 0, stream, part, dw_blk,
                        s.Co * Cin, nsplit);
     return hipGetLastError();
