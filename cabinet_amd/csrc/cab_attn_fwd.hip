@@ -207,171 +207,6 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
             (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
 }
 
-// =====================================================================================================
-// K1, 8-wave form (Kc <= 128): TWO waves per SIMD, so one wave's softmax (VALU) runs under the other
-// wave's MFMA chain without relying on instruction scheduling.  To fit the 256-register budget per wave:
-//   * the Q tile lives in LDS (shared by the 8 waves; B operand = one conflict-free ds_read per MFMA),
-//   * V goes global -> LDS by LDS-DMA (`buffer_load ... lds`), no staging registers and no ds_write:
-//     the image is unpadded [c][32] with slot = key ^ (c & 31); the swizzle is applied on the per-lane
-//     SOURCE address (the DMA destination is lane-linear), and makes the channel-on-lane read
-//     conflict-free,
-//   * only the streamed K tile (prefetched one phase ahead), O, S and P are registers.
-// hipcc does not order a ds_read behind an LDS-DMA, so the two hand-offs carry explicit waits:
-// vmcnt(0) before the first read of a freshly DMA'd V image (issued a full MFMA phase earlier), and
-// lgkmcnt(0) after the last read of an image before the next DMA overwrites it.
-// =====================================================================================================
-template <int KC, int VC>
-__global__ __launch_bounds__(512) void cab_attn_fwd8_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit, int B) {
-    constexpr int VB = VC / 32, NW = 8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* qs = smem;                      // [KC][32] raw q tile
-    float* vimg = qs + KC * 32;            // [8 waves][VC*32] swizzled V images; later the O merge scratch
-    float* s_m = vimg + NW * VC * 32;      // [8][32]
-    float* s_l = s_m + NW * 32;            // [8][32]
-    float* s_f = s_l + NW * 32;            // [8][32]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    float* vim = vimg + wave * (VC * 32);
-
-    const int nqt = (n + 31) >> 5, per_img = nqt * kvsplit;
-    const int tile = xcd_chunked_tile(blockIdx.x, per_img * B);
-    const int b = tile / per_img, rem = tile - b * per_img, split = rem / nqt, i0 = (rem - split * nqt) * 32;
-    const int row_bytes = n * 4;
-    const buf_rsrc k_rs = make_rsrc(k + (size_t)b * KC * n, (unsigned)KC * row_bytes);
-    const buf_rsrc v_rs = make_rsrc(v + (size_t)b * VC * n, (unsigned)VC * row_bytes);
-    const int NT = (n + 31) >> 5, tstep = NW * kvsplit;
-    int t = split * NW + wave;
-
-    float kA[KC / 2];
-    auto load_k = [&](int tile_idx) {
-        const int voff = (h * n + min(min(tile_idx, NT - 1) * 32 + li, n - 1)) * 4;
-#pragma unroll
-        for (int c2 = 0; c2 < KC / 2; ++c2) kA[c2] = bload(k_rs, voff, c2 * 2 * row_bytes);
-    };
-    const int lih = li ^ h;
-    auto dma_v = [&](int tile_idx) {  // row c = 2*c2+h, LDS slot li  <-  V[c][key = li ^ (c & 31)]
-        const int jb = min(tile_idx, NT - 1) * 32;
-#pragma unroll
-        for (int c2 = 0; c2 < VC / 2; ++c2) {
-            const int key = lih ^ ((2 * c2) & 31);
-            const int voff = (h * n + min(jb + key, n - 1)) * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (__attribute__((address_space(3))) void*)(vim + c2 * 64), 4,
-                                                     voff, c2 * 2 * row_bytes, 0, 0);
-        }
-    };
-    if (t < NT) {
-        load_k(t);
-        dma_v(t);
-    }
-    {   // Q tile -> LDS, all 512 threads
-        const int i = threadIdx.x & 31, part = threadIdx.x >> 5;
-        const float* qp = q + (size_t)b * KC * n + min(i0 + i, n - 1);
-        for (int c = part; c < KC; c += 16) qs[c * 32 + i] = qp[(size_t)c * n];
-    }
-    __syncthreads();
-
-    f32x16 o[VB];
-#pragma unroll
-    for (int cb = 0; cb < VB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
-
-    auto s_chain = [&](f32x16& s) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kA[c2], qs[(2 * c2 + h) * 32 + li], s);
-    };
-    auto softmax = [&](f32x16& s, int j0, float& alpha) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = (j0 + acc_row(r) + 4 * h >= n) ? -INFINITY : s[r];
-        float mt = s[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[r]);
-        mt = fmaxf(mt, swap_half(mt)) * qscale;
-        const float mn = (mt > m + kRescaleThreshold) ? mt : m;
-        alpha = fast_exp2(m - mn);
-        m = mn;
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = fast_exp2(fmaf(s[r], qscale, -mn));
-            rs += s[r];
-        }
-        l = l * alpha + rs;
-    };
-    auto pv = [&](const f32x16& p) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = acc_row(r) + 4 * h;
-#pragma unroll
-            for (int cb = 0; cb < VB; ++cb) o[cb] = mfma32(vim[(cb * 32 + li) * 32 + (key ^ li)], p[r], o[cb]);
-        }
-    };
-
-    if (t < NT) {
-        f32x16 p, sn;
-        float alpha;
-        s_chain(p);
-        load_k(t + tstep);
-        softmax(p, t * 32, alpha);
-        for (; t + tstep < NT; t += tstep) {
-            s_chain(sn);                                          // phase A: S^T of the next tile
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // V(t) image landed (DMA issued a phase ago)
-            load_k(t + 2 * tstep);                                // phase B
-            pv(p);
-            softmax(sn, (t + tstep) * 32, alpha);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // all reads of the image returned
-            dma_v(t + tstep);                                     // refill it for the next iteration
-            if (__any(alpha != 1.0f)) {
-#pragma unroll
-                for (int cb = 0; cb < VB; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
-            }
-            p = sn;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pv(p);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-
-    // ---- merge the 8 waves (disjoint key subsets) ----
-    l += swap_half(l);
-    if (h == 0) {
-        s_m[wave * 32 + li] = m;
-        s_l[wave * 32 + li] = l;
-    }
-#pragma unroll
-    for (int cb = 0; cb < VB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vim[(cb * 32 + acc_row(r) + 4 * h) * 32 + li] = o[cb][r];
-    __syncthreads();
-    float ms = -INFINITY, lt = 0.f;
-    if (threadIdx.x < NW * 32) {
-        const int i = threadIdx.x & 31, w = threadIdx.x >> 5;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) ms = fmaxf(ms, s_m[ww * 32 + i]);
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) lt += s_l[ww * 32 + i] * fast_exp2(s_m[ww * 32 + i] - ms);
-        s_f[w * 32 + i] = (lt > 0.f) ? fast_exp2(s_m[w * 32 + i] - ms) / lt : 0.f;
-    }
-    __syncthreads();
-    const size_t out_base = ((size_t)split * B + b) * VC * n;
-    for (int idx = threadIdx.x; idx < VC * 32; idx += 512) {
-        const int c = idx >> 5, i = idx & 31;
-        float acc = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) acc += vimg[w * (VC * 32) + c * 32 + i] * s_f[w * 32 + i];
-        if (i0 + i < n) ctx[out_base + (size_t)c * n + i0 + i] = acc;
-    }
-    if (threadIdx.x < 32 && i0 + threadIdx.x < n)
-        lse[((size_t)split * B + b) * n + i0 + threadIdx.x] =
-            (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
-}
-
 // merge kvsplit partial results: lse = logsumexp_s(lse_s), ctx = sum_s exp(lse_s - lse) ctx_s
 __global__ void cab_attn_fwd_merge_kernel(const float* __restrict__ part_ctx,
                                           const float* __restrict__ part_lse,
@@ -398,11 +233,9 @@ template <int KC, int VC>
 static hipError_t launch_fwd(const float* q, const float* k, const float* v, float scale, int B, int n,
                              float* ctx, float* lse, float* part_ctx, float* part_lse, int kvsplit,
                              hipStream_t stream) {
-    constexpr bool kEight = KC <= 128;  // 8-wave / LDS-DMA form; Kc = 256 keeps the 4-wave register form
-    const size_t lds = kEight ? (size_t)(KC * 32 + 8 * VC * 32 + 3 * 256) * sizeof(float)
-                              : (size_t)(4 * VC * 33 + 3 * 128) * sizeof(float);
-    auto kern = kEight ? cab_attn_fwd8_kernel<KC, VC> : cab_attn_fwd_kernel<KC, VC>;
-    const dim3 block(kEight ? 512 : 256);
+    const size_t lds = (size_t)(4 * VC * 33 + 3 * 128) * sizeof(float);
+    auto kern = cab_attn_fwd_kernel<KC, VC>;
+    const dim3 block(256);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
