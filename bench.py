@@ -70,6 +70,34 @@ def time_kernel(fn, iters, warm=3):
     return start.elapsed_time(stop) / iters
 
 
+_PMC_KEYS = {  # bench kernel group -> rocprofv3 kernel names whose HBM traffic it sums
+    "cab_attn_fwd": ["cabinet::cab_attn_fwd_kernel<128, 128>"],
+    "cab_attn_bwd": ["cabinet::cab_attn_bwd_dq_fast_kernel<128, 128>", "cabinet::cab_attn_bwd_dkdv_fast_kernel<128, 128>"],
+    "ffm_fwd": ["cabinet::transpose_kernel", "cabinet::gemm_kmajor_kernel<2, true>", "cabinet::bn_finalize_kernel",
+                "cabinet::ffm_pool_kernel", "cabinet::ffm_se_kernel", "cabinet::ffm_gate_kernel"],
+    "ffm_bwd": ["cabinet::ffm_bwd_reduce_kernel", "cabinet::ffm_bwd_image_kernel", "cabinet::ffm_bwd_combine_kernel",
+                "cabinet::ffm_dz_kernel", "cabinet::gemm_kmajor_kernel<3, true>", "cabinet::gemm_dw_kernel<true>",
+                "cabinet::reduce_slabs_kernel"],
+}
+
+
+def measured_traffic(group, batch, size):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_counters.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 calibration in that file).
+    Only valid for the shape the counters were collected at (config 3); otherwise None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    if (batch, size) != (8, 1024) or not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    total = 0.0
+    for name in _PMC_KEYS[group]:
+        c = pmc.get(name)
+        if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            return None
+        total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return round(total)
+
+
 def kernel_rooflines(batch, size, iters):
     """Per hand-written kernel group at this workload's shapes: duration from HIP events, algorithmic
     work per launch from SURVEY.md section 8(d) / BASELINE.md section 3."""
@@ -98,6 +126,7 @@ def kernel_rooflines(batch, size, iters):
         else:
             r = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                      frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None)
+        r["traffic"] = measured_traffic(name.split(" ")[0], batch, size)
         r.update(kernel=name, ms_per_launch=round(ms, 4), algorithmic_gflop=round(flops / 1e9, 3),
                  algorithmic_mbytes=round(bytes_ / 1e6, 1), tflops=round(tf, 2), gbytes_per_s=round(gbs, 1))
         out.append(r)
@@ -221,6 +250,8 @@ def main():
         k1 = ks[0]
         result["roofline"] = {k: k1[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
         result["roofline"].update(kernel=k1["kernel"], ms_per_launch=k1["ms_per_launch"],
+                                  algorithmic_bytes=round(k1["algorithmic_mbytes"] * 1e6),
+                                  traffic_source="profiles/r01_pmc_counters.json (rocprofv3 --pmc, FETCH x2 calibrated)",
                                   peak_is="dense fp32 MFMA (v_mfma_f32_32x32x2_f32), not bf16",
                                   longest_kernel_group=dom["kernel"], longest_kernel_frac=dom["frac"])
     if world > 1:

@@ -212,8 +212,13 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(const float* __restrict__ 
     float* Bx = smem + 2 * G3_T * G3_STR;     // [2][128][33]   X rows (c) x pixels
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wo = wave >> 1, wc = wave & 1;
-    const int o0 = blockIdx.x * G3_T, c0 = blockIdx.y * G3_T, split = blockIdx.z;
+    // 1-D grid, XCD-chunked: the (o-tile, c-tile) blocks of ONE pixel range run on the same XCD, so the
+    // dz rows re-read by the c-tiles and the X rows re-read by the o-tiles come out of that XCD's L2
     const int Cin = Cs + Cc;
+    const int ntx = (Co + G3_T - 1) / G3_T, nty = (Cin + G3_T - 1) / G3_T;
+    const int vt = xcd_chunked_tile(blockIdx.x, gridDim.x);
+    const int split = vt / (ntx * nty), xy = vt - split * (ntx * nty);
+    const int o0 = (xy % ntx) * G3_T, c0 = (xy / ntx) * G3_T;
     const int chunk_lo = split * chunks_per_split;
     const int chunk_hi = min(chunk_lo + chunks_per_split, B * chunks_per_img);
     const bool vec_ok = (P & 3) == 0;
@@ -745,7 +750,7 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
         attr_done = true;
     }
     const bool interior = (P % G3_BK) == 0 && (s.Co % G3_T) == 0 && (s.Cs % G3_T) == 0 && (s.Cc % G3_T) == 0;
-    const dim3 g3grid(ceil_div(s.Co, G3_T), ceil_div(Cin, G3_T), nsplit);
+    const dim3 g3grid(ceil_div(s.Co, G3_T) * ceil_div(Cin, G3_T) * nsplit);
     if (interior)
         hipLaunchKernelGGL(gemm_dw_kernel<true>, g3grid, dim3(256), lds, stream, dz, fsp, fcp, part, s.B, s.Co, s.Cs,
                            s.Cc, P, chunks_per_img, cps);
