@@ -75,9 +75,9 @@ _PMC_KEYS = {  # bench kernel group -> rocprofv3 kernel names whose HBM traffic 
     "cab_attn_bwd": ["cabinet::cab_attn_bwd_dq_fast_kernel<128, 128>", "cabinet::cab_attn_bwd_dkdv_fast_kernel<128, 128>"],
     "ffm_fwd": ["cabinet::transpose_kernel", "cabinet::gemm_kmajor_kernel<2, true>", "cabinet::bn_finalize_kernel",
                 "cabinet::ffm_pool_kernel", "cabinet::ffm_se_kernel", "cabinet::ffm_gate_kernel"],
-    "ffm_bwd": ["cabinet::ffm_bwd_reduce_kernel", "cabinet::ffm_bwd_image_kernel", "cabinet::ffm_bwd_combine_kernel",
-                "cabinet::ffm_dz_kernel", "cabinet::gemm_kmajor_kernel<3, true>", "cabinet::gemm_dw_kernel<true>",
-                "cabinet::reduce_slabs_kernel"],
+    "ffm_bwd": None,      # (plain form: not re-profiled after the dW split; see profiles/r01_pmc_counters.json)
+    "ffm_up_fwd": None,   # several launches of the same kernel symbols with different shapes: per-launch PMC
+    "ffm_up_bwd": None,   # rows cannot be attributed by name alone
 }
 
 
@@ -90,6 +90,8 @@ def measured_traffic(group, batch, size):
         return None
     pmc = json.load(open(path))
     total = 0.0
+    if not _PMC_KEYS.get(group):
+        return None
     for name in _PMC_KEYS[group]:
         c = pmc.get(name)
         if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
@@ -157,6 +159,23 @@ def kernel_rooflines(batch, size, iters):
     ms = time_kernel(bwd, iters)
     entry("ffm_bwd (K4: reduce, dz, dX GEMM, dW split-K GEMM)", ms, 4.0 * B * P * (Cs + Cc) * Co,
           4.0 * B * P * (2 * Co + 2 * Co + Co + Co + (Cs + Cc) + Co + (Cs + Cc)), "mfma")
+    # ---- the form CABiNet.forward uses: bilinear upsample of `low` fused into the FFM.
+    # conv and resize commute, so the Cc part runs at low resolution: executed GEMM work drops 2.7x and the
+    # op becomes HBM-bound; algorithmic bytes = this build's pass structure.
+    hl = wl = size // 32
+    Pl = hl * wl
+    low = torch.randn(B, Cc, hl, wl, generator=g).to(dev)
+    upf = lambda: Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
+    o, z, mean, invstd, pooled, gate = upf()
+    ms = time_kernel(upf, iters)
+    fl_f = 2.0 * B * Co * (P * Cs + Pl * Cc)
+    by_f = 4.0 * B * (P * (Cs + 4 * Co) + Pl * (Cc + 2 * Co))
+    entry("ffm_up_fwd (K3': resize fused, conv commuted to low res)", ms, fl_f, by_f, "hbm")
+    upb = lambda: Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
+    ms = time_kernel(upb, iters)
+    fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
+    by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))
+    entry("ffm_up_bwd (K4': reduce, dz, dfsp GEMM, U^T dz, low-res GEMMs, dW)", ms, fl_b, by_b, "hbm")
     return out
 
 

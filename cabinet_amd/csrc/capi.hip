@@ -30,6 +30,19 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
                        const float* w1, const float* w2, int training, float momentum, float eps, float* out,
                        float* z, float* save_mean, float* save_invstd, float* pooled, float* gate, void* ws,
                        hipStream_t stream);
+size_t ffm_up_fwd_workspace(const FfmShape& s, int Hl, int Wl);
+size_t ffm_up_bwd_workspace(const FfmShape& s, int Hl, int Wl);
+hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, const float* low,
+                          const float* w_blk, const float* bn_w, const float* bn_b, float* run_mean,
+                          float* run_var, const float* w1, const float* w2, int training, float momentum,
+                          float eps, float* out, float* z, float* save_mean, float* save_invstd, float* pooled,
+                          float* gate, void* ws, hipStream_t stream);
+hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, const float* fsp,
+                          const float* low, const float* w_blk, const float* bn_w, const float* bn_b,
+                          const float* w1, const float* w2, const float* z, const float* save_mean,
+                          const float* save_invstd, const float* pooled, const float* gate, int training,
+                          float* dfsp, float* dlow, float* dw_blk, float* dbn_w, float* dbn_b, float* dw1,
+                          float* dw2, void* ws, hipStream_t stream);
 hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, const float* fcp,
                        const float* w_blk, const float* bn_w, const float* bn_b, const float* w1,
                        const float* w2, const float* z, const float* save_mean, const float* save_invstd,
@@ -177,6 +190,64 @@ int cabinet_ffm_bwd(const float* dout, const float* fsp, const float* fcp, const
                                            dfcp, dw_blk, dbn_weight, dbn_bias, dw1, dw2, workspace,
                                            static_cast<hipStream_t>(stream)),
                       "ffm_bwd launch");
+}
+
+// ------------------------------------------------------------- FFM + fused upsample
+static int check_low(int Hl, int Wl) {
+    if (Hl <= 0 || Wl <= 0) return fail(CABINET_ERR_INVALID_ARG, "ffm_up: non-positive low-resolution size");
+    return CABINET_OK;
+}
+
+size_t cabinet_ffm_up_fwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl) {
+    if (B <= 0 || Cs <= 0 || Cc <= 0 || Co <= 0 || Cm <= 0 || H <= 0 || W <= 0 || Hl <= 0 || Wl <= 0) return 0;
+    return cabinet::ffm_up_fwd_workspace({B, Cs, Cc, Co, Cm, H, W}, Hl, Wl);
+}
+
+int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk, const float* bn_weight,
+                       const float* bn_bias, float* running_mean, float* running_var, const float* w1,
+                       const float* w2, int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl,
+                       int training, float momentum, float eps, float* out, float* z, float* save_mean,
+                       float* save_invstd, float* pooled, float* gate, void* workspace, size_t workspace_bytes,
+                       cabinet_stream_t stream) {
+    if (int rc = check_ffm_shape(B, Cs, Cc, Co, Cm, H, W)) return rc;
+    if (int rc = check_low(Hl, Wl)) return rc;
+    if (!fsp || !low || !w_blk || !bn_weight || !bn_bias || !running_mean || !running_var || !w1 || !w2 || !out ||
+        !z || !save_mean || !save_invstd || !pooled || !gate)
+        return fail(CABINET_ERR_INVALID_ARG, "ffm_up_fwd: null tensor pointer");
+    const size_t need = cabinet_ffm_up_fwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W, Hl, Wl);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "ffm_up_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::ffm_up_fwd_run({B, Cs, Cc, Co, Cm, H, W}, Hl, Wl, fsp, low, w_blk, bn_weight, bn_bias,
+                                              running_mean, running_var, w1, w2, training, momentum, eps, out, z,
+                                              save_mean, save_invstd, pooled, gate, workspace,
+                                              static_cast<hipStream_t>(stream)),
+                      "ffm_up_fwd launch");
+}
+
+size_t cabinet_ffm_up_bwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl) {
+    if (B <= 0 || Cs <= 0 || Cc <= 0 || Co <= 0 || Cm <= 0 || H <= 0 || W <= 0 || Hl <= 0 || Wl <= 0) return 0;
+    return cabinet::ffm_up_bwd_workspace({B, Cs, Cc, Co, Cm, H, W}, Hl, Wl);
+}
+
+int cabinet_ffm_up_bwd(const float* dout, const float* fsp, const float* low, const float* w_blk,
+                       const float* bn_weight, const float* bn_bias, const float* w1, const float* w2,
+                       const float* z, const float* save_mean, const float* save_invstd, const float* pooled,
+                       const float* gate, int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl,
+                       int training, float* dfsp, float* dlow, float* dw_blk, float* dbn_weight, float* dbn_bias,
+                       float* dw1, float* dw2, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_ffm_shape(B, Cs, Cc, Co, Cm, H, W)) return rc;
+    if (int rc = check_low(Hl, Wl)) return rc;
+    if (!dout || !fsp || !low || !w_blk || !bn_weight || !bn_bias || !w1 || !w2 || !z || !save_mean ||
+        !save_invstd || !pooled || !gate || !dfsp || !dlow || !dw_blk || !dbn_weight || !dbn_bias || !dw1 || !dw2)
+        return fail(CABINET_ERR_INVALID_ARG, "ffm_up_bwd: null tensor pointer");
+    const size_t need = cabinet_ffm_up_bwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W, Hl, Wl);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "ffm_up_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::ffm_up_bwd_run({B, Cs, Cc, Co, Cm, H, W}, Hl, Wl, dout, fsp, low, w_blk, bn_weight,
+                                              bn_bias, w1, w2, z, save_mean, save_invstd, pooled, gate, training,
+                                              dfsp, dlow, dw_blk, dbn_weight, dbn_bias, dw1, dw2, workspace,
+                                              static_cast<hipStream_t>(stream)),
+                      "ffm_up_bwd launch");
 }
 
 }  // extern "C"

@@ -30,7 +30,8 @@ struct FfmShape {
 // G1 / G2:  D[m][p] = sum_k At[k][m] * Bm[k][p]   per image
 // =====================================================================================
 struct GemmKArgs {
-    const float* at;   // [K][M], M contiguous (shared by all images)
+    const float* at;   // [K][lda], M (<= lda) contiguous entries per row (shared by all images)
+    int lda;
     int M, K;
     const float* src0; // B-operand rows k <  K0 : (B, K0, P)
     const float* src1; // B-operand rows k >= K0 : (B, K-K0, P)
@@ -39,8 +40,20 @@ struct GemmKArgs {
     float* dst1;       // output rows m >= M0 : (B, M-M0, P)
     int M0;
     int P;
-    float* stat_part;  // nullptr or [2][M][B*gridDim.x] per-tile (sum, sum of squares) over pixels
+    // optional epilogue term: D[m][p] += bilinear_upsample(up_src[b][m])(p), align_corners=False semantics
+    // of F.interpolate (reference cabinet.py:228-230); up_src: (B, M, Hl, Wl), output pixels p = oy*W + ox
+    const float* up_src;
+    int Hl, Wl, W;
+    float rh, rw;      // Hl / H, Wl / W
 };
+
+// one axis of F.interpolate(mode="bilinear", align_corners=False): source taps and weight of the upper tap
+__device__ __forceinline__ void bilinear_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
+    const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
+    i0 = min((int)src, in_size - 1);
+    i1 = min(i0 + 1, in_size - 1);
+    lam = src - (float)i0;
+}
 
 constexpr int GK_BK = 16;   // k-chunk
 constexpr int GK_NT = 128;  // pixels per tile (2 waves x 2 blocks x 32)
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
             const int idx = tid + i * 512, kk = idx / (MT / 4), c4 = idx % (MT / 4);
             const int m = m0 + c4 * 4;
             if (INTERIOR || m < M)
-                ra[i] = *reinterpret_cast<const f32x4*>(a.at + (size_t)(k0 + kk) * M + m);
+                ra[i] = *reinterpret_cast<const f32x4*>(a.at + (size_t)(k0 + kk) * a.lda + m);
             else
                 ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -126,47 +139,77 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: store D; optional per-row (sum, sumsq) over this tile's valid pixels ----
-    float* s_stat = smem;  // [2 (wn)][2][MT], aliases As after the final barrier
+    // ---- optional epilogue term: + bilinear upsample of a low-resolution (B, M, Hl, Wl) map ----
+    if (a.up_src) {
+        const size_t plane = (size_t)a.Hl * a.Wl;
+        if (INTERIOR && (a.W % GK_NT) == 0 && a.Wl <= 32) {  // vrow (MT x Wl floats) must fit the staging LDS
+            // the tile is a 128-pixel segment of ONE output row: interpolate the two source rows vertically
+            // into LDS once (coalesced), then every output needs two LDS reads instead of four L2 gathers
+            float* vrow = smem;  // [MT][Wl], aliases the staging buffers (all waves are past the last barrier)
+            const int oy = p0 / a.W, ox0 = p0 - oy * a.W;
+            int y0, y1;
+            float ly;
+            bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
+            for (int idx = tid; idx < MT * a.Wl; idx += 512) {
+                const int ml = idx / a.Wl, xs = idx - ml * a.Wl;
+                const float* src = a.up_src + ((size_t)b * M + m0 + ml) * plane;
+                vrow[idx] = (1.f - ly) * src[y0 * a.Wl + xs] + ly * src[y1 * a.Wl + xs];
+            }
+            __syncthreads();
+            int x0[2], x1[2];
+            float lx[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bilinear_taps(ox0 + wn * 64 + j * 32 + li, a.rw, a.Wl, x0[j], x1[j], lx[j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float* vr = vrow + (wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h) * a.Wl;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j][r] += (1.f - lx[j]) * vr[x0[j]] + lx[j] * vr[x1[j]];
+                }
+            __syncthreads();  // vrow is dead before s_stat (same LDS) is written below
+        } else {
+            int o00[2], o01[2], o10[2], o11[2];
+            float w00[2], w01[2], w10[2], w11[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = min(p0 + wn * 64 + j * 32 + li, P - 1);
+                const int oy = p / a.W, ox = p - oy * a.W;
+                int y0, y1, x0, x1;
+                float ly, lx;
+                bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
+                bilinear_taps(ox, a.rw, a.Wl, x0, x1, lx);
+                o00[j] = y0 * a.Wl + x0, o01[j] = y0 * a.Wl + x1, o10[j] = y1 * a.Wl + x0, o11[j] = y1 * a.Wl + x1;
+                w00[j] = (1.f - ly) * (1.f - lx), w01[j] = (1.f - ly) * lx, w10[j] = ly * (1.f - lx), w11[j] = ly * lx;
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = min(m0 + wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h, M - 1);
+                    const float* src = a.up_src + ((size_t)b * M + m) * plane;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j][r] += w00[j] * src[o00[j]] + w01[j] * src[o01[j]] + w10[j] * src[o10[j]] +
+                                        w11[j] * src[o11[j]];
+                }
+        }
+    }
+
+    // ---- epilogue: store D (rows are 128-byte contiguous segments per lane half) ----
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ml = wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h;  // row inside the tile
-            const int m = m0 + ml;
-            float s1 = 0.f, s2 = 0.f;
-            float* drow = nullptr;
-            if (m < M)
-                drow = (m < a.M0) ? a.dst0 + ((size_t)b * a.M0 + m) * P
-                                  : a.dst1 + ((size_t)b * (M - a.M0) + (m - a.M0)) * P;
+            const int m = m0 + wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h;
+            if (m >= M) continue;
+            float* drow = (m < a.M0) ? a.dst0 + ((size_t)b * a.M0 + m) * P
+                                     : a.dst1 + ((size_t)b * (M - a.M0) + (m - a.M0)) * P;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p = p0 + wn * 64 + j * 32 + li;
-                const float val = acc[i][j][r];
-                if (p < P) {
-                    if (drow) drow[p] = val;
-                    s1 += val;
-                    s2 += val * val;
-                }
-            }
-            if (a.stat_part) {
-                s1 = half_sum(s1);
-                s2 = half_sum(s2);
-                if (li == 0) {
-                    s_stat[(wn * 2 + 0) * MT + ml] = s1;
-                    s_stat[(wn * 2 + 1) * MT + ml] = s2;
-                }
-            }
-        }
-    }
-    if (a.stat_part) {
-        __syncthreads();
-        const size_t ntiles = (size_t)gridDim.x * gridDim.z, tile = (size_t)b * gridDim.x + blockIdx.x;
-        for (int ml = tid; ml < MT; ml += 512) {
-            const int m = m0 + ml;
-            if (m < M) {
-                a.stat_part[(size_t)m * ntiles + tile] = s_stat[0 * MT + ml] + s_stat[2 * MT + ml];
-                a.stat_part[((size_t)M + m) * ntiles + tile] = s_stat[1 * MT + ml] + s_stat[3 * MT + ml];
+                if (p < P) drow[p] = acc[i][j][r];
             }
         }
     }
@@ -187,9 +230,12 @@ static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
 }
 
 static void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
-    const bool wide = a.M > 256 && a.M <= 384;
-    const bool interior = (a.P % GK_NT) == 0 && (a.M % (wide ? 384 : 256)) == 0;
-    if (wide)
+    int wm = a.M <= 128 ? 1 : (a.M > 256 && a.M <= 384) ? 3 : 2;
+    if (wm > 1 && (a.M % 128) == 0 && ceil_div(a.P, GK_NT) * B * ceil_div(a.M, 128 * wm) < 200) wm = 1;  // small grid
+    const bool interior = (a.P % GK_NT) == 0 && (a.M % (128 * wm)) == 0 && (a.lda % 4) == 0;
+    if (wm == 1)
+        interior ? launch_gemm_k<1, true>(a, B, stream) : launch_gemm_k<1, false>(a, B, stream);
+    else if (wm == 3)
         interior ? launch_gemm_k<3, true>(a, B, stream) : launch_gemm_k<3, false>(a, B, stream);
     else
         interior ? launch_gemm_k<2, true>(a, B, stream) : launch_gemm_k<2, false>(a, B, stream);
@@ -312,15 +358,72 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(const float* __restrict__ 
             }
 }
 
-__global__ void reduce_slabs_kernel(const float* __restrict__ part, float* __restrict__ out, int count, int nsplit) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// out[o * ldo + col_off + c] = sum_k part[k][o][c]   (slab sum into a column block of dW_blk)
+__global__ void reduce_slabs_strided_kernel(const float* __restrict__ part, float* __restrict__ out, int Co, int Cx,
+                                            int ldo, int col_off, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, count = Co * Cx;
     if (i >= count) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * count + i];
-    out[i] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {
+        s0 += part[(size_t)k * count + i];
+        s1 += part[(size_t)(k + 1) * count + i];
+        s2 += part[(size_t)(k + 2) * count + i];
+        s3 += part[(size_t)(k + 3) * count + i];
+    }
+    for (; k < nsplit; ++k) s0 += part[(size_t)k * count + i];
+    out[(size_t)(i / Cx) * ldo + col_off + (i % Cx)] = (s0 + s1) + (s2 + s3);
 }
 
-static int dw_nsplit(int total_chunks) { return total_chunks < 64 ? total_chunks : 64; }
+// adjoint of the bilinear upsample (gather form, deterministic): lo[pl][ys][xs] = sum over the output
+// pixels whose taps touch (ys,xs) of weight * hi[pl][oy][ox].  One workgroup per (plane, band of 8 source
+// rows): the <= 8*ratio+6 output rows the band touches are staged in LDS with coalesced, independent loads,
+// then each thread produces source pixels from LDS in a fixed summation order.
+constexpr int ADJ_BAND = 8;
+__global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __restrict__ hi, float* __restrict__ lo,
+                                                                int H, int W, int Hl, int Wl, float rh, float rw,
+                                                                int max_rows) {
+    extern __shared__ float rows[];  // [max_rows][W]
+    const int bands = (Hl + ADJ_BAND - 1) / ADJ_BAND, pl = blockIdx.x / bands;
+    const int ys_lo = (blockIdx.x % bands) * ADJ_BAND, ys_hi = min(ys_lo + ADJ_BAND, Hl) - 1;
+    const int oy_lo = max(0, (int)floorf(((float)ys_lo - 0.5f) / rh - 0.5f) - 1);
+    const int oy_hi = min(min(H - 1, (int)ceilf(((float)ys_hi + 1.5f) / rh - 0.5f) + 1), oy_lo + max_rows - 1);
+    const float* src = hi + ((size_t)pl * H + oy_lo) * W;
+    const int n_in = (oy_hi - oy_lo + 1) * W;
+    for (int i = threadIdx.x; i < n_in; i += 256) rows[i] = src[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < (ys_hi - ys_lo + 1) * Wl; o += 256) {
+        const int ys = ys_lo + o / Wl, xs = o % Wl;
+        const int a_lo = max(oy_lo, (int)floorf(((float)ys - 0.5f) / rh - 0.5f) - 1);
+        const int a_hi = min(oy_hi, (int)ceilf(((float)ys + 1.5f) / rh - 0.5f) + 1);
+        const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1);
+        const int b_hi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1);
+        float acc = 0.f;
+        for (int oy = a_lo; oy <= a_hi; ++oy) {
+            int y0, y1;
+            float ly;
+            bilinear_taps(oy, rh, Hl, y0, y1, ly);
+            const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+            if (wy == 0.f) continue;
+            const float* rr = rows + (oy - oy_lo) * W;
+            float row = 0.f;
+            for (int ox = b_lo; ox <= b_hi; ++ox) {
+                int x0, x1;
+                float lx;
+                bilinear_taps(ox, rw, Wl, x0, x1, lx);
+                row += ((x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f)) * rr[ox];
+            }
+            acc += wy * row;
+        }
+        lo[((size_t)pl * Hl + ys) * Wl + xs] = acc;
+    }
+}
+
+// enough pixel-range splits that (output tiles x splits) covers the chip ~3x
+static int dw_nsplit(int total_chunks, int tiles) {
+    const int want = ceil_div(768, tiles);
+    return total_chunks < want ? total_chunks : (want < 128 ? want : 128);
+}
 
 // =====================================================================================
 // small kernels
@@ -334,6 +437,41 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     const int ox = blockIdx.y * 32 + threadIdx.x, oy0 = blockIdx.x * 32;
     for (int j = threadIdx.y; j < 32; j += 8)
         if (ox < rows && oy0 + j < cols) out[(size_t)(oy0 + j) * rows + ox] = tile[threadIdx.x][j];
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return t;
+}
+
+// per (b,c) row of z: sum and sum of squares over the P pixels -> stat_part[2][C][B]
+// (a streaming pass over z, which is still Infinity-Cache resident right after the GEMM wrote it; this
+// replaced an in-epilogue cross-lane reduction that cost ~60 us per launch in wave shuffles)
+__global__ __launch_bounds__(256) void bn_rowstats_kernel(const float* __restrict__ z, float* __restrict__ stat_part,
+                                                           int B, int C, int P) {
+    __shared__ float s_red[4];
+    const int row = blockIdx.x, b = row / C, c = row - b * C;
+    const float* zr = z + (size_t)row * P;
+    float s1 = 0.f, s2 = 0.f;
+    if ((P & 3) == 0) {
+        for (int p = threadIdx.x * 4; p < P; p += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(zr + p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1 += v[e], s2 += v[e] * v[e];
+        }
+    } else {
+        for (int p = threadIdx.x; p < P; p += 256) s1 += zr[p], s2 += zr[p] * zr[p];
+    }
+    s1 = block_sum_256(s1, s_red);
+    s2 = block_sum_256(s2, s_red);
+    if (threadIdx.x == 0) {
+        stat_part[(size_t)c * B + b] = s1;
+        stat_part[((size_t)C + c) * B + b] = s2;
+    }
 }
 
 // BN statistics, one workgroup per channel: training -> reduce the per-tile partials (double),
@@ -382,15 +520,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
         running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
     }
-}
-
-__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    return t;
 }
 
 // pooled[b][c] = mean_p relu(bn(z[b][c][p]))        one workgroup per (b,c) row
@@ -632,11 +761,43 @@ __global__ __launch_bounds__(256) void ffm_dz_kernel(const float* __restrict__ g
 // =====================================================================================
 // host drivers
 // =====================================================================================
+// Two entry forms share every kernel:
+//   plain : FFM(fsp, fcp)                        -- reference cabinet.py:142-153 as written
+//   up    : FFM(fsp, bilinear_up(low -> H x W))  -- cabinet.py:228-230 + :236 fused.
+// The "up" form never materialises fcp.  The 1x1 conv and the bilinear resize are both linear and act on
+// different indices, so they commute:  W_c . U(low) == U(W_c . low).  The Cc-channel part of the GEMM
+// therefore runs at LOW resolution (16x fewer pixels at the x4 upsample of CABiNet) and its result is added,
+// bilinearly sampled, in the epilogue of the Cs-channel GEMM; in backward dlow = W_c^T . U^T(dz) and
+// dW_c = U^T(dz) . low^T, again at low resolution.  GEMM FLOPs drop from 3 x 2*B*P*Cin*Co to
+// 3 x 2*B*P*Cs*Co + 3 x 2*B*Pl*Cc*Co  (25.8 -> 9.7 GFLOP per product at config 3).
 static size_t wt_bytes(const FfmShape& s) { return align_up((size_t)(s.Cs + s.Cc) * s.Co * sizeof(float), 256); }
-static int fwd_tiles(const FfmShape& s) { return s.B * ceil_div(s.H * s.W, GK_NT); }
+static size_t stat_bytes(const FfmShape& s) { return align_up((size_t)s.B * 2 * s.Co * sizeof(float), 256); }
+static size_t low_bytes(const FfmShape& s, int Hl, int Wl) {
+    return align_up((size_t)s.B * s.Co * Hl * Wl * sizeof(float), 256);
+}
 
-size_t ffm_fwd_workspace(const FfmShape& s) {
-    return wt_bytes(s) + align_up((size_t)fwd_tiles(s) * 2 * s.Co * sizeof(float), 256);
+size_t ffm_fwd_workspace(const FfmShape& s) { return wt_bytes(s) + stat_bytes(s); }
+size_t ffm_up_fwd_workspace(const FfmShape& s, int Hl, int Wl) {
+    return wt_bytes(s) + stat_bytes(s) + low_bytes(s, Hl, Wl);
+}
+
+// everything after z exists: BN statistics, pooling, SE gate, gated output
+static void ffm_fwd_tail(const FfmShape& s, float* stat_part, const float* bn_w, const float* bn_b,
+                         float* run_mean, float* run_var, const float* w1, const float* w2, int training,
+                         float momentum, float eps, float* out, const float* z, float* save_mean,
+                         float* save_invstd, float* pooled, float* gate, hipStream_t stream) {
+    const int P = s.H * s.W;
+    if (training)
+        hipLaunchKernelGGL(bn_rowstats_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, stat_part, s.B, s.Co, P);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(s.Co), dim3(256), 0, stream, stat_part, s.B, s.Co,
+                       (long long)s.B * P, training, momentum, eps, run_mean, run_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w, bn_b,
+                       pooled, s.Co, P);
+    hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(256), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
+                       w2, gate, s.Co, s.Cm);
+    const int cpr = ceil_div(P, 4096);
+    hipLaunchKernelGGL(ffm_gate_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w,
+                       bn_b, gate, out, s.Co, P, cpr);
 }
 
 hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, const float* w_blk,
@@ -651,29 +812,56 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
                        s.Co, Cin);
     GemmKArgs a{};
-    a.at = wt, a.M = s.Co, a.K = Cin;
+    a.at = wt, a.lda = s.Co, a.M = s.Co, a.K = Cin;
     a.src0 = fsp, a.src1 = fcp, a.K0 = s.Cs;
     a.dst0 = z, a.dst1 = z, a.M0 = s.Co;
     a.P = P;
-    a.stat_part = training ? stat_part : nullptr;
     gemm_kmajor(a, s.B, stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(s.Co), dim3(256), 0, stream, stat_part, fwd_tiles(s),
-                       s.Co, (long long)s.B * P, training, momentum, eps, run_mean, run_var, save_mean, save_invstd);
-    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w, bn_b,
-                       pooled, s.Co, P);
-    hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(256), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
-                       w2, gate, s.Co, s.Cm);
-    const int cpr = ceil_div(P, 4096);
-    hipLaunchKernelGGL(ffm_gate_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w,
-                       bn_b, gate, out, s.Co, P, cpr);
+    ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
+                 save_invstd, pooled, gate, stream);
+    return hipGetLastError();
+}
+
+hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, const float* low,
+                          const float* w_blk, const float* bn_w, const float* bn_b, float* run_mean,
+                          float* run_var, const float* w1, const float* w2, int training, float momentum,
+                          float eps, float* out, float* z, float* save_mean, float* save_invstd, float* pooled,
+                          float* gate, void* ws, hipStream_t stream) {
+    const int P = s.H * s.W, Pl = Hl * Wl, Cin = s.Cs + s.Cc;
+    char* base = static_cast<char*>(ws);
+    float* wt = reinterpret_cast<float*>(base);
+    float* stat_part = reinterpret_cast<float*>(base + wt_bytes(s));
+    float* ylow = reinterpret_cast<float*>(base + wt_bytes(s) + stat_bytes(s));
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
+                       s.Co, Cin);
+    {   // y_low = W_c . low   at (Hl x Wl)
+        GemmKArgs a{};
+        a.at = wt + (size_t)s.Cs * s.Co, a.lda = s.Co, a.M = s.Co, a.K = s.Cc;
+        a.src0 = low, a.src1 = low, a.K0 = s.Cc;
+        a.dst0 = ylow, a.dst1 = ylow, a.M0 = s.Co;
+        a.P = Pl;
+        gemm_kmajor(a, s.B, stream);
+    }
+    {   // z = W_s . fsp + U(y_low), BN partial sums in the epilogue
+        GemmKArgs a{};
+        a.at = wt, a.lda = s.Co, a.M = s.Co, a.K = s.Cs;
+        a.src0 = fsp, a.src1 = fsp, a.K0 = s.Cs;
+        a.dst0 = z, a.dst1 = z, a.M0 = s.Co;
+        a.P = P;
+        a.up_src = ylow, a.Hl = Hl, a.Wl = Wl, a.W = s.W;
+        a.rh = (float)Hl / (float)s.H, a.rw = (float)Wl / (float)s.W;
+        gemm_kmajor(a, s.B, stream);
+    }
+    ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
+                 save_invstd, pooled, gate, stream);
     return hipGetLastError();
 }
 
 struct BwdWs {
-    size_t sums, a1, a2, mdy, mdyx, dw1p, dw2p, dbnp, dz, part, total;
+    size_t sums, a1, a2, mdy, mdyx, dw1p, dw2p, dbnp, dz, part, dzl, total;
 };
-static BwdWs bwd_layout(const FfmShape& s) {
-    const int P = s.H * s.W, Cin = s.Cs + s.Cc;
+static BwdWs bwd_layout(const FfmShape& s, int Hl, int Wl) {  // Hl == 0: plain form
+    const int P = s.H * s.W;
     const int total_chunks = s.B * ceil_div(P, G3_BK);
     BwdWs w{};
     size_t off = 0;
@@ -691,35 +879,33 @@ static BwdWs bwd_layout(const FfmShape& s) {
     w.dw2p = take((size_t)s.B * s.Co * s.Cm * sizeof(float));
     w.dbnp = take((size_t)s.B * 2 * s.Co * sizeof(float));
     w.dz = take((size_t)s.B * s.Co * P * sizeof(float));
-    w.part = take((size_t)dw_nsplit(total_chunks) * s.Co * Cin * sizeof(float));
+    (void)total_chunks;
+    w.part = take((size_t)128 * s.Co * (s.Cs > s.Cc ? s.Cs : s.Cc) * sizeof(float));  // worst-case slabs of one dw_product
+    w.dzl = take(Hl ? (size_t)s.B * s.Co * Hl * Wl * sizeof(float) : 0);
     w.total = off;
     return w;
 }
 
-size_t ffm_bwd_workspace(const FfmShape& s) { return bwd_layout(s).total; }
+size_t ffm_bwd_workspace(const FfmShape& s) { return bwd_layout(s, 0, 0).total; }
+size_t ffm_up_bwd_workspace(const FfmShape& s, int Hl, int Wl) { return bwd_layout(s, Hl, Wl).total; }
 
-hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, const float* fcp,
-                       const float* w_blk, const float* bn_w, const float* bn_b, const float* w1,
-                       const float* w2, const float* z, const float* save_mean, const float* save_invstd,
-                       const float* pooled, const float* gate, int training, float* dfsp, float* dfcp,
-                       float* dw_blk, float* dbn_w, float* dbn_b, float* dw1, float* dw2, void* ws,
-                       hipStream_t stream) {
-    const int P = s.H * s.W, Cin = s.Cs + s.Cc;
-    const BwdWs L = bwd_layout(s);
-    char* base = static_cast<char*>(ws);
+// dout -> dz (and the small gradients dw1, dw2, dbn_w, dbn_b): shared by both forms
+static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const float* dout, const float* z,
+                         const float* save_mean, const float* save_invstd, const float* bn_w, const float* bn_b,
+                         const float* w1, const float* w2, const float* pooled, const float* gate, int training,
+                         float* dbn_w, float* dbn_b, float* dw1, float* dw2, hipStream_t stream) {
+    const int P = s.H * s.W;
     float* sums = reinterpret_cast<float*>(base + L.sums);
     float* a1 = reinterpret_cast<float*>(base + L.a1);
     float* a2 = reinterpret_cast<float*>(base + L.a2);
     float* mdy = reinterpret_cast<float*>(base + L.mdy);
     float* mdyx = reinterpret_cast<float*>(base + L.mdyx);
     float* dz = reinterpret_cast<float*>(base + L.dz);
-    float* part = reinterpret_cast<float*>(base + L.part);
-
-    hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
-                       bn_w, bn_b, sums, s.Co, P);
     float* dw1p = reinterpret_cast<float*>(base + L.dw1p);
     float* dw2p = reinterpret_cast<float*>(base + L.dw2p);
     float* dbnp = reinterpret_cast<float*>(base + L.dbnp);
+    hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
+                       bn_w, bn_b, sums, s.Co, P);
     hipLaunchKernelGGL(ffm_bwd_image_kernel, dim3(s.B), dim3(256), (size_t)(3 * s.Co + 2 * s.Cm) * sizeof(float), stream,
                        sums, pooled, gate, w1, w2, s.Co, s.Cm, P, dw1p, dw2p, dbnp, a1, a2);
     hipLaunchKernelGGL(ffm_bwd_combine_kernel, dim3(ceil_div(s.Co * s.Cm, 256)), dim3(256), 0, stream, dw1p, dw2p, dbnp,
@@ -727,17 +913,14 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
     const int cpr = ceil_div(P, 4096);
     hipLaunchKernelGGL(ffm_dz_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
                        bn_w, bn_b, a1, a2, mdy, mdyx, dz, s.Co, P, cpr);
-    // G2: dX[c][p] = sum_o W[o][c] dz[o][p]   (A_t = W_blk as stored: [o][c], c contiguous)
-    GemmKArgs a{};
-    a.at = w_blk, a.M = Cin, a.K = s.Co;
-    a.src0 = dz, a.src1 = dz, a.K0 = s.Co;
-    a.dst0 = dfsp, a.dst1 = dfcp, a.M0 = s.Cs;
-    a.P = P;
-    a.stat_part = nullptr;
-    gemm_kmajor(a, s.B, stream);
-    // G3: dW = dz X^T, split over pixel chunks, then an ordered slab reduction
-    const int chunks_per_img = ceil_div(P, G3_BK), total_chunks = s.B * chunks_per_img;
-    const int nsplit = dw_nsplit(total_chunks), cps = ceil_div(total_chunks, nsplit);
+}
+
+// dW[:, col_off : col_off+Cx] = sum over images and pixels of dzv (B,Co,P) x xs (B,Cx,P)^T
+static hipError_t dw_product(const float* dzv, const float* xs, int B, int Co, int Cx, int P, float* part,
+                             float* dw_blk, int ldo, int col_off, hipStream_t stream) {
+    const int chunks_per_img = ceil_div(P, G3_BK), total_chunks = B * chunks_per_img;
+    const int nsplit = dw_nsplit(total_chunks, ceil_div(Co, G3_T) * ceil_div(Cx, G3_T));
+    const int cps = ceil_div(total_chunks, nsplit);
     const size_t lds = (size_t)(4 * G3_T * G3_STR) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -749,17 +932,94 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const bool interior = (P % G3_BK) == 0 && (s.Co % G3_T) == 0 && (s.Cs % G3_T) == 0 && (s.Cc % G3_T) == 0;
-    const dim3 g3grid(ceil_div(s.Co, G3_T) * ceil_div(Cin, G3_T) * nsplit);
+    const bool interior = (P % G3_BK) == 0 && (Co % G3_T) == 0 && (Cx % G3_T) == 0;
+    const dim3 grid(ceil_div(Co, G3_T) * ceil_div(Cx, G3_T) * nsplit);
     if (interior)
-        hipLaunchKernelGGL(gemm_dw_kernel<true>, g3grid, dim3(256), lds, stream, dz, fsp, fcp, part, s.B, s.Co, s.Cs,
-                           s.Cc, P, chunks_per_img, cps);
+        hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), lds, stream, dzv, xs, (const float*)nullptr, part, B,
+                           Co, Cx, 0, P, chunks_per_img, cps);
     else
-        hipLaunchKernelGGL(gemm_dw_kernel<false>, g3grid, dim3(256), lds, stream, dz, fsp, fcp, part, s.B, s.Co, s.Cs,
-                           s.Cc, P, chunks_per_img, cps);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(s.Co * Cin, 256)), dim3(256), 0, stream, part, dw_blk,
-                       s.Co * Cin, nsplit);
+        hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), lds, stream, dzv, xs, (const float*)nullptr, part, B,
+                           Co, Cx, 0, P, chunks_per_img, cps);
+    hipLaunchKernelGGL(reduce_slabs_strided_kernel, dim3(ceil_div(Co * Cx, 256)), dim3(256), 0, stream, part, dw_blk, Co,
+                       Cx, ldo, col_off, nsplit);
     return hipGetLastError();
+}
+
+hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, const float* fcp,
+                       const float* w_blk, const float* bn_w, const float* bn_b, const float* w1,
+                       const float* w2, const float* z, const float* save_mean, const float* save_invstd,
+                       const float* pooled, const float* gate, int training, float* dfsp, float* dfcp,
+                       float* dw_blk, float* dbn_w, float* dbn_b, float* dw1, float* dw2, void* ws,
+                       hipStream_t stream) {
+    const int P = s.H * s.W, Cin = s.Cs + s.Cc;
+    const BwdWs L = bwd_layout(s, 0, 0);
+    char* base = static_cast<char*>(ws);
+    float* dz = reinterpret_cast<float*>(base + L.dz);
+    float* part = reinterpret_cast<float*>(base + L.part);
+    ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training, dbn_w, dbn_b,
+                 dw1, dw2, stream);
+    // G2: dX[c][p] = sum_o W[o][c] dz[o][p]   (A_t = W_blk as stored: [o][c], c contiguous)
+    GemmKArgs a{};
+    a.at = w_blk, a.lda = Cin, a.M = Cin, a.K = s.Co;
+    a.src0 = dz, a.src1 = dz, a.K0 = s.Co;
+    a.dst0 = dfsp, a.dst1 = dfcp, a.M0 = s.Cs;
+    a.P = P;
+    gemm_kmajor(a, s.B, stream);
+    // G3: dW = dz X^T per source tensor, split over pixel chunks, ordered slab reduction
+    hipError_t e = dw_product(dz, fsp, s.B, s.Co, s.Cs, P, part, dw_blk, Cin, 0, stream);
+    if (e != hipSuccess) return e;
+    return dw_product(dz, fcp, s.B, s.Co, s.Cc, P, part, dw_blk, Cin, s.Cs, stream);
+}
+
+hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, const float* fsp,
+                          const float* low, const float* w_blk, const float* bn_w, const float* bn_b,
+                          const float* w1, const float* w2, const float* z, const float* save_mean,
+                          const float* save_invstd, const float* pooled, const float* gate, int training,
+                          float* dfsp, float* dlow, float* dw_blk, float* dbn_w, float* dbn_b, float* dw1,
+                          float* dw2, void* ws, hipStream_t stream) {
+    const int P = s.H * s.W, Pl = Hl * Wl, Cin = s.Cs + s.Cc;
+    const BwdWs L = bwd_layout(s, Hl, Wl);
+    char* base = static_cast<char*>(ws);
+    float* dz = reinterpret_cast<float*>(base + L.dz);
+    float* part = reinterpret_cast<float*>(base + L.part);
+    float* dzl = reinterpret_cast<float*>(base + L.dzl);
+    ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training, dbn_w, dbn_b,
+                 dw1, dw2, stream);
+    {   // dfsp = W_s^T dz
+        GemmKArgs a{};
+        a.at = w_blk, a.lda = Cin, a.M = s.Cs, a.K = s.Co;
+        a.src0 = dz, a.src1 = dz, a.K0 = s.Co;
+        a.dst0 = dfsp, a.dst1 = dfsp, a.M0 = s.Cs;
+        a.P = P;
+        gemm_kmajor(a, s.B, stream);
+    }
+    // dz_low = U^T dz  (adjoint of the bilinear upsample), then everything on the Cc side is low resolution
+    {
+        // output rows one band of ADJ_BAND source rows can touch (ratio = H / Hl), with slack
+        const int max_rows = (int)((ADJ_BAND + 2) * ((float)s.H / (float)Hl)) + 6;
+        const size_t lds = (size_t)max_rows * s.W * sizeof(float);
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_lds = lds;
+        }
+        hipLaunchKernelGGL(upsample_adjoint_kernel, dim3(s.B * s.Co * ((Hl + ADJ_BAND - 1) / ADJ_BAND)), dim3(256), lds,
+                           stream, dz, dzl, s.H, s.W, Hl, Wl, (float)Hl / (float)s.H, (float)Wl / (float)s.W,
+                           max_rows);
+    }
+    {   // dlow = W_c^T dz_low
+        GemmKArgs a{};
+        a.at = w_blk + s.Cs, a.lda = Cin, a.M = s.Cc, a.K = s.Co;
+        a.src0 = dzl, a.src1 = dzl, a.K0 = s.Co;
+        a.dst0 = dlow, a.dst1 = dlow, a.M0 = s.Cc;
+        a.P = Pl;
+        gemm_kmajor(a, s.B, stream);
+    }
+    hipError_t e = dw_product(dz, fsp, s.B, s.Co, s.Cs, P, part, dw_blk, Cin, 0, stream);
+    if (e != hipSuccess) return e;
+    return dw_product(dzl, low, s.B, s.Co, s.Cc, Pl, part, dw_blk, Cin, s.Cs, stream);
 }
 
 }  // namespace cabinet

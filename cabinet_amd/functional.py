@@ -182,19 +182,102 @@ class _FfmFused(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def ffm_up_fwd_hip(fsp, low, w_blk, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps):
+    lib = _lib.load()
+    B, Cs, H, W = fsp.shape
+    Cc, Hl, Wl = low.shape[1:]
+    Co, Cm = w_blk.shape[0], w1.shape[0]
+    dims = (B, Cs, Cc, Co, Cm, H, W, Hl, Wl)
+    dev = fsp.device
+    out = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
+    z = torch.empty((B, Co, H, W), dtype=torch.float32, device=dev)
+    save_mean = torch.empty(Co, dtype=torch.float32, device=dev)
+    save_invstd = torch.empty(Co, dtype=torch.float32, device=dev)
+    pooled = torch.empty((B, Co), dtype=torch.float32, device=dev)
+    gate = torch.empty((B, Co), dtype=torch.float32, device=dev)
+    ws, nbytes = _workspace(lib.cabinet_ffm_up_fwd_workspace_bytes(*dims), dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ffm_up_fwd(_ptr(fsp), _ptr(low), _ptr(w_blk), _ptr(bn_w), _ptr(bn_b), _ptr(run_mean),
+                                    _ptr(run_var), _ptr(w1), _ptr(w2), *dims, int(training), float(momentum),
+                                    float(eps), _ptr(out), _ptr(z), _ptr(save_mean), _ptr(save_invstd),
+                                    _ptr(pooled), _ptr(gate), _ptr(ws), nbytes, _stream_handle(dev))
+    _lib.check(rc, "cabinet_ffm_up_fwd")
+    return out, z, save_mean, save_invstd, pooled, gate
+
+
+def ffm_up_bwd_hip(g, fsp, low, w_blk, bn_w, bn_b, w1, w2, z, save_mean, save_invstd, pooled, gate, training):
+    lib = _lib.load()
+    B, Cs, H, W = fsp.shape
+    Cc, Hl, Wl = low.shape[1:]
+    dims = (B, Cs, Cc, w_blk.shape[0], w1.shape[0], H, W, Hl, Wl)
+    dev = fsp.device
+    dfsp, dlow = torch.empty_like(fsp), torch.empty_like(low)
+    dw_blk = torch.empty_like(w_blk)
+    dbn_w, dbn_b = torch.empty_like(bn_w), torch.empty_like(bn_b)
+    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    ws, nbytes = _workspace(lib.cabinet_ffm_up_bwd_workspace_bytes(*dims), dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ffm_up_bwd(_ptr(g), _ptr(fsp), _ptr(low), _ptr(w_blk), _ptr(bn_w), _ptr(bn_b), _ptr(w1),
+                                    _ptr(w2), _ptr(z), _ptr(save_mean), _ptr(save_invstd), _ptr(pooled),
+                                    _ptr(gate), *dims, int(training), _ptr(dfsp), _ptr(dlow), _ptr(dw_blk),
+                                    _ptr(dbn_w), _ptr(dbn_b), _ptr(dw1), _ptr(dw2), _ptr(ws), nbytes,
+                                    _stream_handle(dev))
+    _lib.check(rc, "cabinet_ffm_up_bwd")
+    return dfsp, dlow, dw_blk, dbn_w, dbn_b, dw1, dw2
+
+
+class _FfmUpFused(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, fsp, low, w_blk, bn_w, bn_b, w1, w2, run_mean, run_var, training, momentum, eps):
+        fsp, low = _f32c(fsp), _f32c(low)
+        w_blk2 = _f32c(w_blk).view(w_blk.shape[0], -1)
+        w1_2 = _f32c(w1).view(w1.shape[0], -1)
+        w2_2 = _f32c(w2).view(w2.shape[0], -1)
+        bn_w, bn_b = _f32c(bn_w), _f32c(bn_b)
+        out, z, mean, invstd, pooled, gate = ffm_up_fwd_hip(fsp, low, w_blk2, bn_w, bn_b, run_mean, run_var,
+                                                            w1_2, w2_2, training, momentum, eps)
+        fn_ctx.save_for_backward(fsp, low, w_blk2, bn_w, bn_b, w1_2, w2_2, z, mean, invstd, pooled, gate)
+        fn_ctx.training = training
+        fn_ctx.w_shapes = (w_blk.shape, w1.shape, w2.shape)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        fsp, low, w_blk, bn_w, bn_b, w1, w2, z, mean, invstd, pooled, gate = fn_ctx.saved_tensors
+        dfsp, dlow, dw_blk, dbn_w, dbn_b, dw1, dw2 = ffm_up_bwd_hip(
+            _f32c(g), fsp, low, w_blk, bn_w, bn_b, w1, w2, z, mean, invstd, pooled, gate, fn_ctx.training)
+        s_blk, s1, s2 = fn_ctx.w_shapes
+        return (dfsp, dlow, dw_blk.view(s_blk), dbn_w, dbn_b, dw1.view(s1), dw2.view(s2),
+                None, None, None, None, None)
+
+
+def _bn_step(bn):
+    if not (bn.affine and bn.track_running_stats):
+        raise RuntimeError("ffm_fused: BatchNorm2d must be affine with running statistics")
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+        return True, (bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked))
+    return False, 0.0
+
+
+def ffm_fused_upsampled(fsp, low, conv_w, bn, w1, w2):
+    """FFM(fsp, bilinear_upsample(low -> fsp's H x W)) with the upsample fused into the kernels
+    (reference cabinet.py:228-230 + :236).  ``low`` is the attention branch's (B,Cc,H/32,W/32) output."""
+    if fsp.dim() != 4 or low.dim() != 4 or fsp.shape[0] != low.shape[0]:
+        raise RuntimeError(f"ffm_fused_upsampled: bad shapes fsp{tuple(fsp.shape)} low{tuple(low.shape)}")
+    training, momentum = _bn_step(bn)
+    return _FfmUpFused.apply(fsp, low, conv_w, bn.weight, bn.bias, w1, w2, bn.running_mean, bn.running_var,
+                             training, momentum, bn.eps)
+
+
 def ffm_fused(fsp, fcp, conv_w, bn, w1, w2):
     """FeatureFusionModule.forward on HIP tensors (reference cabinet.py:142-153).
 
     ``bn`` is the nn.BatchNorm2d that owns the affine parameters and running buffers;
     its buffers are updated in place in training mode like nn.BatchNorm2d would.
     """
-    if not (bn.affine and bn.track_running_stats):
-        raise RuntimeError("ffm_fused: BatchNorm2d must be affine with running statistics")
-    training = bn.training
-    if training:
-        bn.num_batches_tracked.add_(1)
-        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-    else:
-        momentum = 0.0
+    training, momentum = _bn_step(bn)
     return _FfmFused.apply(fsp, fcp, conv_w, bn.weight, bn.bias, w1, w2, bn.running_mean, bn.running_var,
                            training, momentum, bn.eps)

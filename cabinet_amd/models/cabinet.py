@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import ffm_fused
+from ..functional import ffm_fused, ffm_fused_upsampled
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -118,6 +118,15 @@ class FeatureFusionModule(nn.Module):
         atten = self.sigmoid(self.conv2(self.relu(self.conv1(self.avg_pool(feat)))))
         return feat * atten + feat
 
+    def forward_upsampled(self, fsp: torch.Tensor, low: torch.Tensor) -> torch.Tensor:
+        """``self(fsp, bilinear_upsample(low, fsp.shape[2:]))`` -- the pairing CABiNet.forward uses
+        (reference cabinet.py:228-230, :236).  On HIP tensors the resize is fused into the FFM kernels and
+        the upsampled (B,256,H/8,W/8) tensor is never materialised; host tensors take the composite path."""
+        if fsp.is_cuda:
+            return ffm_fused_upsampled(fsp, low, self.convblk.conv.weight, self.convblk.bn, self.conv1.weight,
+                                       self.conv2.weight)
+        return self.forward(fsp, _resize(low, fsp.shape[2:]))
+
 
 class CABiNetOutput(nn.Module):
     """3x3 ConvBNReLU -> 1x1 classifier (reference cabinet.py:156-172)."""
@@ -157,9 +166,8 @@ class CABiNet(nn.Module):
         size = x.shape[2:]
         feat_sb = self.sb(x)                      # (B,128,H/8,W/8)
         low, high = self.ab(self.mobile(x))       # (B,256,H/32,W/32), (B,ncls,H/32,W/32)
-        low_up = _resize(low, feat_sb.shape[2:])
         high_up = _resize(high, feat_sb.shape[2:])
-        final = self.conv_out(self.ffm(feat_sb, low_up))
+        final = self.conv_out(self.ffm.forward_upsampled(feat_sb, low))  # resize of `low` fused into the FFM
         return _resize(final, size), _resize(high_up, size)
 
     def get_params(self):

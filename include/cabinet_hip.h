@@ -108,6 +108,39 @@ int cabinet_ffm_bwd(const float* dout, const float* fsp, const float* fcp, const
                     float* dw1, float* dw2,
                     void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Feature Fusion Module with the bilinear upsample of its context input fused in.
+ * Replaces src/models/cabinet.py:228-230 + :236 inside CABiNet.forward
+ *     low_res_logit_up = F.interpolate(low_res_logit, size=feat_sb.shape[2:], mode="bilinear",
+ *                                      align_corners=False)
+ *     feat_fuse = self.ffm(feat_sb, low_res_logit_up)
+ * fsp: (B,Cs,H,W)   low: (B,Cc,Hl,Wl)  ->  out (B,Co,H,W); the (B,Cc,H,W) upsampled tensor is never
+ * materialised.  The 1x1 conv and the resize commute (both linear, different indices), so the Cc part of
+ * the conv runs at (Hl,Wl) and is added bilinearly in the GEMM epilogue; backward likewise returns dlow at
+ * (Hl,Wl).  Everything else (BN, gate, saved tensors, argument meaning) is as cabinet_ffm_fwd/bwd.
+ * ------------------------------------------------------------------------- */
+size_t cabinet_ffm_up_fwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl);
+int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk,
+                       const float* bn_weight, const float* bn_bias,
+                       float* running_mean, float* running_var,
+                       const float* w1, const float* w2,
+                       int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl,
+                       int training, float momentum, float eps,
+                       float* out, float* z, float* save_mean, float* save_invstd,
+                       float* pooled, float* gate,
+                       void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+size_t cabinet_ffm_up_bwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl);
+int cabinet_ffm_up_bwd(const float* dout, const float* fsp, const float* low, const float* w_blk,
+                       const float* bn_weight, const float* bn_bias,
+                       const float* w1, const float* w2,
+                       const float* z, const float* save_mean, const float* save_invstd,
+                       const float* pooled, const float* gate,
+                       int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl, int training,
+                       float* dfsp, float* dlow /* (B,Cc,Hl,Wl) */, float* dw_blk, float* dbn_weight,
+                       float* dbn_bias, float* dw1, float* dw2,
+                       void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,5 +41,19 @@ if which in ("all", "ffm"):
         o, z, mean, invstd, pooled, gate = Fh.ffm_fwd_hip(fsp, fcp, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)
     for _ in range(iters):
         Fh.ffm_bwd_hip(dout, fsp, fcp, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)
+if which in ("all", "ffm_up"):
+    Cs, Cc, Co, Cm = 128, 256, 256, 64
+    fsp = torch.randn(B, Cs, h, w, generator=g).to(dev)
+    low = torch.randn(B, Cc, size // 32, size // 32, generator=g).to(dev)
+    wb = (torch.randn(Co, Cs + Cc, generator=g) * 0.07).to(dev)
+    w1 = (torch.randn(Cm, Co, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(Co, Cm, generator=g) * 0.1).to(dev)
+    bw, bb = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+    rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
+    dout = torch.randn(B, Co, h, w, generator=g).to(dev)
+    for _ in range(iters):
+        o, z, mean, invstd, pooled, gate = Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)
+    for _ in range(iters):
+        Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)
 torch.cuda.synchronize()
 print("done")
