@@ -152,9 +152,9 @@ def kernel_rooflines(batch, size, iters):
     fwd = lambda: Fh.ffm_fwd_hip(fsp, fcp, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
     o, z, mean, invstd, pooled, gate = fwd()
     ms = time_kernel(fwd, iters)
-    # this build's pass structure: read fsp,fcp; write z; read z (pool); read z, write out
+    # this build's pass structure: read fsp,fcp; write z; read z (stats); read z (pool); read z, write out
     entry("ffm_fwd (K3: 1x1 GEMM + BN stats, pool, gate)", ms, 2.0 * B * P * (Cs + Cc) * Co,
-          4.0 * B * P * ((Cs + Cc) + 4 * Co), "mfma")
+          4.0 * B * P * ((Cs + Cc) + 5 * Co), "mfma")
     bwd = lambda: Fh.ffm_bwd_hip(dout, fsp, fcp, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
     ms = time_kernel(bwd, iters)
     entry("ffm_bwd (K4: reduce, dz, dX GEMM, dW split-K GEMM)", ms, 4.0 * B * P * (Cs + Cc) * Co,
@@ -169,7 +169,7 @@ def kernel_rooflines(batch, size, iters):
     o, z, mean, invstd, pooled, gate = upf()
     ms = time_kernel(upf, iters)
     fl_f = 2.0 * B * Co * (P * Cs + Pl * Cc)
-    by_f = 4.0 * B * (P * (Cs + 4 * Co) + Pl * (Cc + 2 * Co))
+    by_f = 4.0 * B * (P * (Cs + 5 * Co) + Pl * (Cc + 2 * Co))
     entry("ffm_up_fwd (K3': resize fused, conv commuted to low res)", ms, fl_f, by_f, "hbm")
     upb = lambda: Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
     ms = time_kernel(upb, iters)

@@ -383,7 +383,7 @@ constexpr int ADJ_BAND = 8;
 __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __restrict__ hi, float* __restrict__ lo,
                                                                 int H, int W, int Hl, int Wl, float rh, float rw,
                                                                 int max_rows) {
-    extern __shared__ float rows[];  // [max_rows][W]
+    extern __shared__ float rows[];  // [max_rows][W] staged output rows, then [ADJ_BAND][W] vertical sums
     const int bands = (Hl + ADJ_BAND - 1) / ADJ_BAND, pl = blockIdx.x / bands;
     const int ys_lo = (blockIdx.x % bands) * ADJ_BAND, ys_hi = min(ys_lo + ADJ_BAND, Hl) - 1;
     const int oy_lo = max(0, (int)floorf(((float)ys_lo - 0.5f) / rh - 0.5f) - 1);
@@ -392,30 +392,35 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
     const int n_in = (oy_hi - oy_lo + 1) * W;
     for (int i = threadIdx.x; i < n_in; i += 256) rows[i] = src[i];
     __syncthreads();
-    for (int o = threadIdx.x; o < (ys_hi - ys_lo + 1) * Wl; o += 256) {
-        const int ys = ys_lo + o / Wl, xs = o % Wl;
+    // separable: vertical taps first (weights depend on the row only), then horizontal
+    float* tcol = rows + (size_t)max_rows * W;  // [ADJ_BAND][W]
+    const int nys = ys_hi - ys_lo + 1;
+    for (int o = threadIdx.x; o < nys * W; o += 256) {
+        const int yi = o / W, ox = o - yi * W, ys = ys_lo + yi;
         const int a_lo = max(oy_lo, (int)floorf(((float)ys - 0.5f) / rh - 0.5f) - 1);
         const int a_hi = min(oy_hi, (int)ceilf(((float)ys + 1.5f) / rh - 0.5f) + 1);
-        const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1);
-        const int b_hi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1);
         float acc = 0.f;
         for (int oy = a_lo; oy <= a_hi; ++oy) {
             int y0, y1;
             float ly;
             bilinear_taps(oy, rh, Hl, y0, y1, ly);
-            const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
-            if (wy == 0.f) continue;
-            const float* rr = rows + (oy - oy_lo) * W;
-            float row = 0.f;
-            for (int ox = b_lo; ox <= b_hi; ++ox) {
-                int x0, x1;
-                float lx;
-                bilinear_taps(ox, rw, Wl, x0, x1, lx);
-                row += ((x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f)) * rr[ox];
-            }
-            acc += wy * row;
+            acc += ((y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f)) * rows[(oy - oy_lo) * W + ox];
         }
-        lo[((size_t)pl * Hl + ys) * Wl + xs] = acc;
+        tcol[o] = acc;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nys * Wl; o += 256) {
+        const int yi = o / Wl, xs = o - yi * Wl;
+        const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1);
+        const int b_hi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1);
+        float acc = 0.f;
+        for (int ox = b_lo; ox <= b_hi; ++ox) {
+            int x0, x1;
+            float lx;
+            bilinear_taps(ox, rw, Wl, x0, x1, lx);
+            acc += ((x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f)) * tcol[yi * W + ox];
+        }
+        lo[((size_t)pl * Hl + ys_lo + yi) * Wl + xs] = acc;
     }
 }
 
@@ -997,7 +1002,7 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
     {
         // output rows one band of ADJ_BAND source rows can touch (ratio = H / Hl), with slack
         const int max_rows = (int)((ADJ_BAND + 2) * ((float)s.H / (float)Hl)) + 6;
-        const size_t lds = (size_t)max_rows * s.W * sizeof(float);
+        const size_t lds = (size_t)(max_rows + ADJ_BAND) * s.W * sizeof(float);
         static size_t attr_lds = 0;
         if (lds > attr_lds) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel),
