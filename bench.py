@@ -28,9 +28,20 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # (stock PyTorch-ROCm backbone).  Without it the first step on a fresh box spends ~75 s in MIOpen's
 # solver search; results are identical either way.
 _MIOPEN_DB = os.path.join(ROOT, "cabinet_amd", "miopen_db")
-if os.path.isdir(_MIOPEN_DB) and os.access(_MIOPEN_DB, os.W_OK):
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
-    os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_MIOPEN_DB, "cache"))
+if os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
+    _db = _MIOPEN_DB
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or not os.access(_MIOPEN_DB, os.W_OK):
+        # one private copy per rank: 8 processes appending to one sqlite/text db is asking for lock contention
+        import shutil
+        import tempfile
+        _db = os.path.join(tempfile.gettempdir(), f"cabinet_miopen_db_{os.getuid()}_{os.environ.get('LOCAL_RANK', '0')}")
+        try:
+            shutil.copytree(_MIOPEN_DB, _db, dirs_exist_ok=True)
+        except OSError:
+            _db = None
+    if _db:
+        os.environ["MIOPEN_USER_DB_PATH"] = _db
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_db, "cache"))
 
 import torch  # noqa: E402
 

@@ -551,23 +551,34 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__
 }
 
 // gate[b][c] = sigmoid(W2 relu(W1 pooled[b]))                 one workgroup per image
+// hidden unit j is owned by a group of G = 256/Cm' threads (a power of two dividing 64): one pass, a short
+// in-wave reduction, no per-row loop of dependent wave reductions.
+__device__ __forceinline__ int se_group(int Cm) {  // threads cooperating on one hidden unit
+    int g = 1;
+    while (g < 64 && Cm * g * 2 <= 256) g *= 2;
+    return g;
+}
+
 __global__ __launch_bounds__(256) void ffm_se_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                       const float* __restrict__ w2, float* __restrict__ gate, int Co,
                                                       int Cm) {
     extern __shared__ float sm[];
     float* m = sm;        // [Co]
     float* r = sm + Co;   // [Cm]
-    const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c = threadIdx.x; c < Co; c += 256) m[c] = pooled[(size_t)b * Co + c];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < Co; c += 256) m[c] = pooled[(size_t)b * Co + c];
     __syncthreads();
-    for (int j = wave; j < Cm; j += 4) {
+    const int G = se_group(Cm), per_pass = 256 / G;
+    for (int j0 = 0; j0 < Cm; j0 += per_pass) {
+        const int j = j0 + tid / G, q = tid % G;
         float acc = 0.f;
-        for (int c = lane; c < Co; c += 64) acc += w1[(size_t)j * Co + c] * m[c];
-        acc = wave_sum(acc);
-        if (lane == 0) r[j] = fmaxf(acc, 0.f);
+        if (j < Cm)
+            for (int c = q; c < Co; c += G) acc += w1[(size_t)j * Co + c] * m[c];
+        for (int o = G >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (j < Cm && q == 0) r[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < Co; c += 256) {
+    for (int c = tid; c < Co; c += 256) {
         float acc = 0.f;
         for (int j = 0; j < Cm; ++j) acc += w2[(size_t)c * Cm + j] * r[j];
         gate[(size_t)b * Co + c] = 1.f / (1.f + expf(-acc));
@@ -656,7 +667,7 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
     float* ds = a + Co;       // [Co]
     float* u = ds + Co;       // [Cm]
     float* du = u + Cm;       // [Cm]
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < Co; c += 256) {
         const float av = gate[(size_t)b * Co + c];
         m[c] = pooled[(size_t)b * Co + c];
@@ -664,17 +675,24 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
         ds[c] = sums[((size_t)b * Co + c) * 5 + 0] * av * (1.f - av);
     }
     __syncthreads();
-    for (int j = wave; j < Cm; j += 4) {  // u = W1 m ;  dr = W2^T ds
-        float acc = 0.f, dr = 0.f;
-        for (int c = lane; c < Co; c += 64) {
-            acc += w1[(size_t)j * Co + c] * m[c];
-            dr += w2[(size_t)c * Cm + j] * ds[c];
-        }
-        acc = wave_sum(acc);
-        dr = wave_sum(dr);
-        if (lane == 0) {
-            u[j] = acc;
-            du[j] = acc > 0.f ? dr : 0.f;
+    {   // u = W1 m ;  dr = W2^T ds : a group of G threads per hidden unit
+        const int G = se_group(Cm), per_pass = 256 / G;
+        for (int j0 = 0; j0 < Cm; j0 += per_pass) {
+            const int j = j0 + tid / G, q = tid % G;
+            float acc = 0.f, dr = 0.f;
+            if (j < Cm)
+                for (int c = q; c < Co; c += G) {
+                    acc += w1[(size_t)j * Co + c] * m[c];
+                    dr += w2[(size_t)c * Cm + j] * ds[c];
+                }
+            for (int o = G >> 1; o >= 1; o >>= 1) {
+                acc += __shfl_xor(acc, o, 64);
+                dr += __shfl_xor(dr, o, 64);
+            }
+            if (j < Cm && q == 0) {
+                u[j] = acc;
+                du[j] = acc > 0.f ? dr : 0.f;
+            }
         }
     }
     __syncthreads();

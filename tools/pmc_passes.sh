@@ -3,6 +3,10 @@
 # usage (on the GPU box): bash tools/pmc_passes.sh <tag>
 set -u
 TAG=${1:-r01}
+# the calibration / probe binaries are not tracked: (re)build them for gfx950 when missing
+for t in pmc_calib mfma_probe; do
+  [ -x $GRAFT_REPO_ROOT/tools/$t ] || hipcc --offload-arch=gfx950 -O3 $GRAFT_REPO_ROOT/tools/$t.hip -o $GRAFT_REPO_ROOT/tools/$t
+done
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
