@@ -182,6 +182,13 @@ class TestOhemCELoss:
         torch.manual_seed(3)
         logits, labels = torch.randn(2, 8, 24, 24) * 3, torch.randint(0, 8, (2, 24, 24))
         labels[1, :4] = 255
-        for n_min in (10, 400, 5000):
-            a = OhemCELoss(0.7, n_min)(logits, labels)
-            assert torch.allclose(a, ohem_ce(logits, labels, 0.7, n_min), atol=1e-7)
+        for thresh in (0.7, 2.5, 9.0):          # 9.0: nothing above thresh -> the top-n_min branch
+            for n_min in (10, 400, 5000):       # 5000 > #valid -> clamped
+                la = logits.clone().requires_grad_(True)
+                lb_ = logits.clone().requires_grad_(True)
+                a = OhemCELoss(thresh, n_min)(la, labels)
+                b = ohem_ce(lb_, labels, thresh, n_min)
+                assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (thresh, n_min, float(a), float(b))
+                a.backward()
+                b.backward()
+                assert torch.allclose(la.grad, lb_.grad, rtol=1e-5, atol=1e-9), (thresh, n_min)
