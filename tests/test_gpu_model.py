@@ -183,3 +183,45 @@ def test_hot_path_uses_hip_library_not_aten():
         assert name in calls, name
     loaded = open("/proc/self/maps").read()
     assert "libcabinet_hip.so" in loaded
+
+
+def test_reference_style_autocast_step_runs():
+    """The reference's train_step wraps forward + loss in autocast (train.py:433).  The custom Functions must
+    accept the fp16 activations autocast hands them (custom_fwd casts to fp32), return finite losses and
+    gradients, and stay close to the fp32 step."""
+    from cabinet_amd.train import TrainStep, build_model, make_criteria, synthetic_batch
+
+    im, lb = synthetic_batch(2, 256, 256, 8, "cuda", seed=11)
+    losses, gnorms = [], []
+    for autocast in (False, True):
+        net = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
+        step = TrainStep(net, make_criteria(2, 256, 256, "cuda"), autocast=autocast)
+        losses.append(float(step(im, lb)))
+        g = [p.grad for p in net.parameters() if p.grad is not None]
+        assert all(torch.isfinite(t).all() for t in g)
+        assert all(t.dtype == torch.float32 for t in g)
+        gnorms.append(float(torch.sqrt(sum(t.double().pow(2).sum() for t in g))))
+    assert abs(losses[1] - losses[0]) < 2e-2 * abs(losses[0])
+    assert abs(gnorms[1] - gnorms[0]) < 0.1 * gnorms[0]
+
+
+def test_non_contiguous_and_channels_last_inputs_are_accepted():
+    """Borrowed inputs are made dense NCHW by the binding (the C ABI itself only takes dense pointers)."""
+    from cabinet_amd.functional import cab_attention
+    from cabinet_amd.models.cabinet import FeatureFusionModule
+    from oracle.cab_math import attn_core_fwd
+
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(2, 70, 128, generator=g).cuda().transpose(1, 2)  # (2,128,70) view, non-contiguous
+    k = torch.randn(2, 128, 70, generator=g).cuda()
+    v = torch.randn(2, 128, 70, generator=g).cuda()
+    out = cab_attention(q, k, v, 0.1)
+    ref, _ = attn_core_fwd(q.cpu().contiguous(), k.cpu(), v.cpu(), 0.1)
+    assert_close(out, ref, TOL, "ctx (non-contiguous q)")
+    ffm = FeatureFusionModule(384, 256).cuda().eval()
+    fsp = torch.randn(2, 128, 16, 16, generator=g).cuda()
+    fcp = torch.randn(2, 256, 16, 16, generator=g).cuda()
+    with torch.no_grad():
+        a = ffm(fsp, fcp)
+        b = ffm(fsp.contiguous(memory_format=torch.channels_last), fcp.contiguous(memory_format=torch.channels_last))
+    assert_close(b, a, 1e-6, "channels_last input")
