@@ -255,7 +255,7 @@ template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ ctx, const float* __restrict__ lse,
-    float* __restrict__ dq, float* __restrict__ delta, int n, float scale, int B) {
+    float* __restrict__ dq, float* __restrict__ delta, int n, float scale, int B, int nsplit) {
     constexpr int KB = KC / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qt = smem;                   // [KC][32]  q * scale*log2e   (B operand of S^T)
@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
     float* s_lse = s_delta + 32;        // [32]
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const int nqt = (n + 31) >> 5;
-    const int tile = xcd_chunked_tile(blockIdx.x, nqt * B);
-    const int b = tile / nqt, i0 = (tile - b * nqt) * 32;
+    // small grids (few query tiles) split the KEY range over nsplit workgroups per query tile; partial dq
+    // slabs are summed by sum_parts_kernel.  Tile order: image-major, then split, then query tile.
+    const int nqt = (n + 31) >> 5, per_img = nqt * nsplit;
+    const int tile = xcd_chunked_tile(blockIdx.x, per_img * B);
+    const int b = tile / per_img, rem = tile - b * per_img, split = rem / nqt, i0 = (rem - split * nqt) * 32;
     const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
     const float qscale = scale * LOG2E_F;
     const int row_bytes = n * 4;
@@ -285,7 +287,8 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
 #pragma unroll
         for (int c2 = 0; c2 < VC / 2; ++c2) vv[c2] = bload(v_rs, voff, c2 * 2 * row_bytes);
     };
-    load_kv(wave);  // in flight during the prologue
+    const int tstep = 4 * nsplit, t0 = split * 4 + wave;
+    load_kv(t0);  // in flight during the prologue
 
     {
         const int i = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
         for (int p = 0; p < 8; ++p) d += s_part[p * 32 + threadIdx.x];
         s_delta[threadIdx.x] = d;
         const int ig = i0 + threadIdx.x;
-        if (ig < n) delta[(size_t)b * n + ig] = d;
+        if (ig < n && split == 0) delta[(size_t)b * n + ig] = d;
         s_lse[threadIdx.x] = lse[(size_t)b * n + min(ig, n - 1)] * LOG2E_F;
     }
     __syncthreads();
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
     float* kim = kimg + wave * (KC * 32);
 
-    for (int t = wave; t < NT; t += 4) {
+    for (int t = t0; t < NT; t += tstep) {
         const int j0 = t * 32;
         f32x16 s, dp;
 #pragma unroll
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
 #pragma unroll
         for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(vv[c2], gt[(2 * c2 + h) * 32 + li], dp);
         __builtin_amdgcn_sched_barrier(0);
-        load_kv(t + 4);  // next tile: lands while the dq product below runs
+        load_kv(t + tstep);  // next tile: lands while the dq product below runs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool valid = j0 + acc_row(r) + 4 * h < n;
@@ -358,17 +361,28 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
         }
         __syncthreads();
     }
+    // nsplit == 1: dq is the final tensor; else a partial slab [split][B][KC][n] (scaled already)
+    float* out = dq + (size_t)split * B * KC * n;
     for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
         const int c = idx >> 5, i = idx & 31;
-        if (i0 + i < n) dq[qk_base + (size_t)c * n + i0 + i] = red[idx] * scale;
+        if (i0 + i < n) out[qk_base + (size_t)c * n + i0 + i] = red[idx] * scale;
     }
+}
+
+// out[i] = sum_s part[s][i]  (ordered -> deterministic)
+__global__ void sum_parts_kernel(const float* __restrict__ part, float* __restrict__ out, size_t count, int nsplit) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * count + i];
+    out[i] = s;
 }
 
 template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
-    float* __restrict__ dk, float* __restrict__ dv, int n, float scale, int B) {
+    float* __restrict__ dk, float* __restrict__ dv, int n, float scale, int B, int nsplit) {
     constexpr int KB = KC / 32, VB = VC / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* kt = smem;                    // [KC][32] raw k tile   (B operand of S)
@@ -377,9 +391,10 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     float* red = img;                    // reduction scratch aliases the images after the main loop
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const int nkt = (n + 31) >> 5;
-    const int tile = xcd_chunked_tile(blockIdx.x, nkt * B);
-    const int b = tile / nkt, j0 = (tile - b * nkt) * 32;
+    const int nkt = (n + 31) >> 5, per_img = nkt * nsplit;
+    const int tile = xcd_chunked_tile(blockIdx.x, per_img * B);
+    const int b = tile / per_img, rem = tile - b * per_img, split = rem / nkt, j0 = (rem - split * nkt) * 32;
+    const int tstep = 4 * nsplit, t0 = split * 4 + wave;
     const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
     const float qscale = scale * LOG2E_F;
     const int row_bytes = n * 4;
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
 #pragma unroll
         for (int c2 = 0; c2 < VC / 2; ++c2) gv[c2] = bload(g_rs, voff, c2 * 2 * row_bytes);
     };
-    load_qg(wave);
+    load_qg(t0);
     {
         const int j = threadIdx.x & 31, part = threadIdx.x >> 5;
         const int jg = min(j0 + j, n - 1);
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     float* qim = img + wave * ((KC + VC) * 32);
     float* gim = qim + KC * 32;
 
-    for (int t = wave; t < NT; t += 4) {
+    for (int t = t0; t < NT; t += tstep) {
         const int i0 = t * 32;
         f32x16 s, dp;
 #pragma unroll
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
 #pragma unroll
         for (int c2 = 0; c2 < VC / 2; ++c2) gim[simg(2 * c2 + h, li)] = gv[c2];
         __builtin_amdgcn_sched_barrier(0);
-        load_qg(t + 4);  // next query tile: lands while the dv / dk products run
+        load_qg(t + tstep);  // next query tile: lands while the dv / dk products run
         f32x16 p;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -478,14 +493,24 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
         }
         __syncthreads();
     }
+    float* dk_out = dk + (size_t)split * B * KC * n;
+    float* dv_out = dv + (size_t)split * B * VC * n;
     for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
         const int c = idx >> 5, j = idx & 31;
-        if (j0 + j < n) dk[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
+        if (j0 + j < n) dk_out[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
     }
     for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
         const int c = idx >> 5, j = idx & 31;
-        if (j0 + j < n) dv[v_base + (size_t)c * n + j0 + j] = red[KC * 32 + idx];
+        if (j0 + j < n) dv_out[v_base + (size_t)c * n + j0 + j] = red[KC * 32 + idx];
     }
+}
+
+// workgroups per tile so that a small batch still covers the chip (each wave keeps >= 2 tiles)
+static int bwd_nsplit(int B, int n) {
+    const int nt = (n + 31) / 32;
+    int split = 1;
+    while (nt * B * split < 200 && split * 2 * 8 <= nt && split < 8) split *= 2;
+    return split;
 }
 
 template <int KC, int VC>
@@ -506,9 +531,22 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(((n + 31) / 32) * B);
-    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, dq, delta, n, scale, B);
-    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale, B);
+    const int nsplit = bwd_nsplit(B, n);
+    dim3 grid(((n + 31) / 32) * B * nsplit);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, dq, delta, n, scale, B, 1);
+        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale, B, 1);
+    } else {
+        // partial slabs live behind D_i in the workspace: [nsplit][B][KC][n] then [nsplit][B][VC][n]
+        float* part_k = delta + align_up((size_t)B * n, 64);
+        float* part_v = part_k + (size_t)nsplit * B * KC * n;
+        const size_t cq = (size_t)B * KC * n, cv = (size_t)B * VC * n;
+        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, part_k, delta, n, scale, B, nsplit);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dq, cq, nsplit);
+        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, part_k, part_v, n, scale, B, nsplit);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dk, cq, nsplit);
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cv + 255) / 256)), dim3(256), 0, stream, part_v, dv, cv, nsplit);
+    }
     return hipGetLastError();
 }
 
@@ -537,9 +575,10 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
 }
 
 size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
-    (void)Kc;
-    (void)Vc;
-    return align_up((size_t)B * n * sizeof(float), 256);  // D_i
+    size_t bytes = align_up((size_t)B * n, 64) * sizeof(float);  // D_i
+    const int nsplit = (Kc <= 128 && Kc + Vc <= 256) ? bwd_nsplit(B, n) : 1;
+    if (nsplit > 1) bytes += (size_t)nsplit * B * (Kc + Vc) * n * sizeof(float);  // partial dq|dk and dv slabs
+    return align_up(bytes, 256);
 }
 
 hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, const float* v,
