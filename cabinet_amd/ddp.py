@@ -46,12 +46,13 @@ class BucketedGradReducer:
     """
 
     def __init__(self, module: torch.nn.Module, process_group=None, first_bucket_mb: float = 2.0,
-                 bucket_mb: float = 8.0, broadcast_parameters: bool = True):
+                 bucket_mb: float = 8.0, broadcast_parameters: bool = True, always_reduce: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("BucketedGradReducer needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
+        self.always_reduce = always_reduce  # issue the collectives even at world size 1 (single-GPU bring-up)
         params = [p for p in module.parameters() if p.requires_grad]
         if not params:
             raise RuntimeError("no trainable parameters")
@@ -97,7 +98,7 @@ class BucketedGradReducer:
     # -- per-step machinery --------------------------------------------------------------------
     def _launch(self, b: _Bucket):
         b.launched = True
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return
         if self.backend == "nccl":
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -146,7 +147,8 @@ def init_distributed(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("CABINET_FORCE_DDP") == "1"  # exercise the RCCL path on a single GPU (tests / bring-up)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

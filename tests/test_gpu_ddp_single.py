@@ -31,7 +31,7 @@ def test_rccl_bucketed_reducer_world1():
         ref = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
         TrainStep(ref, make_criteria(2, 128, 128, "cuda"))(im, lb)
         net = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
-        reducer = BucketedGradReducer(net, first_bucket_mb=0.5, bucket_mb=4.0)
+        reducer = BucketedGradReducer(net, first_bucket_mb=0.5, bucket_mb=4.0, always_reduce=True)
         assert reducer.backend == "nccl" and len(reducer.buckets) >= 3
         step = TrainStep(net, make_criteria(2, 128, 128, "cuda"), reducer=reducer)
         step(im, lb)
