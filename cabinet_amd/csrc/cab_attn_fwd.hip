@@ -22,11 +22,27 @@
 //  * The four per-wave partial results are merged through LDS at the end; with
 //    kvsplit > 1 (small batches) partials go to a workspace and a tiny second
 //    kernel merges them, so the grid always covers the chip.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace cabinet {
 
 constexpr float kRescaleThreshold = 12.0f;  // log2 units
+
+// Diagnostic build only (tools/attn_stamps.hip defines CAB_ATTN_STAMPS): s_memtime marks of wave 0 of every
+// workgroup, written to a buffer nothing else reads.  Never compiled into libcabinet_hip.so.
+#ifdef CAB_ATTN_STAMPS
+__device__ unsigned long long cab_stamps[4096][8];
+#define K1_MARK(var)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");     \
+    __builtin_amdgcn_sched_barrier(0);
+#define K1_DECL unsigned long long k1_t0 = 0, k1_t1 = 0, k1_t2 = 0, k1_t3 = 0, k1_t4 = 0, k1_a = 0, k1_b = 0, k1_x = 0, k1_y = 0;
+#else
+#define K1_MARK(var)
+#define K1_DECL
+#endif
 
 template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
@@ -35,6 +51,8 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
     constexpr int VB = VC / 32;
     constexpr int VSTR = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    K1_DECL
+    K1_MARK(k1_t0)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     float* vs = smem + wave * (VC * VSTR);
     float* s_m = smem + 4 * VC * VSTR;  // [4][32] running max per wave / query
@@ -135,29 +153,87 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
         s_chain(p);
         load_k(t + tstep);
         softmax(p, t * 32, alpha);  // O is still zero: nothing to rescale
+        K1_MARK(k1_t1)
         for (; t + tstep < NT; t += tstep) {
-            // ---- phase A ----
-            s_chain(sn);
-            v_to_lds();
+            K1_MARK(k1_x)
+            // ---- phase A: S^T(next) chain; behind each MFMA one row pair of V(t) goes registers -> LDS and
+            // the same registers are refilled with V(next) (needed one iteration from now) ----
+            {
+                const int voff_v = (h * n + min(min(t + tstep, NT - 1) * 32 + li, n - 1)) * 4;
 #pragma unroll
-            for (int i = 0; i < KC / 2; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, (VC + KC - 1) / KC, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- phase B ----
-            load_k(t + 2 * tstep);
-            load_v(t + tstep);
-            pv(p);
-            softmax(sn, (t + tstep) * 32, alpha);
+                for (int r = 0; r < 16; ++r) sn[r] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16 * VB; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-                __builtin_amdgcn_sched_group_barrier(0x20, (KC / 2 + VC / 2 + 16 * VB - 1) / (16 * VB), 1);
-                __builtin_amdgcn_sched_group_barrier(0x2, 3, 1);
+                for (int c2 = 0; c2 < KC / 2; ++c2) {
+                    sn = mfma32(kA[c2], qreg[c2], sn);
+#pragma unroll
+                    for (int u = c2 * (VC / 2) / (KC / 2); u < (c2 + 1) * (VC / 2) / (KC / 2); ++u) {
+                        vs[(2 * u + h) * VSTR + li] = vA[u];
+                        vA[u] = bload(v_rs, voff_v, u * 2 * row_bytes);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            K1_MARK(k1_y)
+#ifdef CAB_ATTN_STAMPS
+            k1_a += k1_y - k1_x;
+#endif
+            // ---- phase B: 64 fenced slots, one PV MFMA each, with that slot's share of everything else issued
+            // right behind it (a K prefetch load, the LDS read of the operand four slots ahead, a slice of the
+            // next tile's softmax).  The wave issues in order: work placed after a group of MFMAs runs with
+            // the matrix pipe idle, and left to itself the scheduler emitted the softmax as one block. ----
+            auto phase_b = [&](auto mask_tag) {
+                constexpr bool MASK = decltype(mask_tag)::value;  // only the last key tile can be ragged
+                const int voff_k = (h * n + min(min(t + 2 * tstep, NT - 1) * 32 + li, n - 1)) * 4;
+                const int jn = (t + tstep) * 32;
+                float mt = -INFINITY, mn = 0.f, rs = 0.f;
+                float va[VB], vb[VB];
+#pragma unroll
+                for (int cb = 0; cb < VB; ++cb) va[cb] = vs[(cb * 32 + li) * VSTR + acc_row(0) + 4 * h];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                    for (int cb = 0; cb < VB; ++cb) {
+                        constexpr int SLOTS = 16 * VB;
+                        const int slot = r * VB + cb;
+                        o[cb] = mfma32(va[cb], p[r], o[cb]);
+                        if (r + 1 < 16) vb[cb] = vs[(cb * 32 + li) * VSTR + acc_row(r + 1) + 4 * h];
+                        // prefetch loads: the KC/2 K rows of tile t + 2*tstep spread over the slots
+#pragma unroll
+                        for (int c2 = slot * (KC / 2) / SLOTS; c2 < (slot + 1) * (KC / 2) / SLOTS; ++c2)
+                            kA[c2] = bload(k_rs, voff_k, c2 * 2 * row_bytes);
+                        // softmax of S^T(next): first half of the slots = masked running max, middle slot =
+                        // row statistics, second half = exponentials
+                        if (slot < SLOTS / 2) {
+#pragma unroll
+                            for (int e = slot * 32 / SLOTS; e < (slot + 1) * 32 / SLOTS; ++e) {
+                                if (MASK) sn[e] = (jn + acc_row(e) + 4 * h >= n) ? -INFINITY : sn[e];
+                                mt = fmaxf(mt, sn[e]);
+                            }
+                        }
+                        if (slot == SLOTS / 2) {
+                            mt = fmaxf(mt, swap_half(mt)) * qscale;
+                            mn = (mt > m + kRescaleThreshold) ? mt : m;
+                            alpha = fast_exp2(m - mn);
+                            m = mn;
+                        }
+                        if (slot >= SLOTS / 2) {
+#pragma unroll
+                            for (int e = (slot - SLOTS / 2) * 32 / SLOTS; e < (slot + 1 - SLOTS / 2) * 32 / SLOTS; ++e) {
+                                sn[e] = fast_exp2(fmaf(sn[e], qscale, -mn));
+                                rs += sn[e];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < VB; ++cb) va[cb] = vb[cb];
+                }
+                l = l * alpha + rs;
+            };
+            if ((t + tstep) * 32 + 32 > n)
+                phase_b(std::true_type{});
+            else
+                phase_b(std::false_type{});
             if (__any(alpha != 1.0f)) {
 #pragma unroll
                 for (int cb = 0; cb < VB; ++cb)
@@ -165,10 +241,16 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
                     for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
             }
             p = sn;
+            K1_MARK(k1_x)
+#ifdef CAB_ATTN_STAMPS
+            k1_b += k1_x - k1_y;
+#endif
         }
+        K1_MARK(k1_t2)
         // ---- last tile of this wave: nothing left to overlap ----
         v_to_lds();
         pv(p);
+        K1_MARK(k1_t3)
     }
 
     // ---- merge the 4 waves (disjoint key subsets) ----
@@ -195,16 +277,39 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
     }
     __syncthreads();
     const size_t out_base = ((size_t)split * B + b) * VC * n;
-    for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
-        const int c = idx >> 5, i = idx & 31;
-        float acc = 0.f;
+    if ((n & 3) == 0) {
+        // four consecutive queries per thread: 16-byte LDS reads and 16-byte coalesced stores
+        for (int idx = threadIdx.x; idx < VC * 8; idx += 256) {
+            const int c = idx >> 3, i = (idx & 7) * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += smem[w * (VC * VSTR) + c * 32 + i] * s_f[w * 32 + i];
-        if (i0 + i < n) ctx[out_base + (size_t)c * n + i0 + i] = acc;
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(smem + w * (VC * VSTR) + c * 32 + i);
+                const f32x4 fv = *reinterpret_cast<const f32x4*>(s_f + w * 32 + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += ov[e] * fv[e];
+            }
+            if (i0 + i < n) *reinterpret_cast<f32x4*>(ctx + out_base + (size_t)c * n + i0 + i) = acc;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
+            const int c = idx >> 5, i = idx & 31;
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc += smem[w * (VC * VSTR) + c * 32 + i] * s_f[w * 32 + i];
+            if (i0 + i < n) ctx[out_base + (size_t)c * n + i0 + i] = acc;
+        }
     }
     if (threadIdx.x < 32 && i0 + threadIdx.x < n)
         lse[((size_t)split * B + b) * n + i0 + threadIdx.x] =
             (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
+#ifdef CAB_ATTN_STAMPS
+    K1_MARK(k1_t4)
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned long long* d = cab_stamps[blockIdx.x];
+        d[0] = k1_t0, d[1] = k1_t1, d[2] = k1_t2, d[3] = k1_t3, d[4] = k1_t4, d[5] = k1_a, d[6] = k1_b;
+    }
+#endif
 }
 
 // merge kvsplit partial results: lse = logsumexp_s(lse_s), ctx = sum_s exp(lse_s - lse) ctx_s
