@@ -251,6 +251,44 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_kernel(
 // =====================================================================================================
 __device__ __forceinline__ constexpr int simg(int c, int pos) { return c * 32 + (pos ^ (c & 31)); }
 
+// The wave issues in order: anything placed after a group of MFMAs runs with the matrix pipe idle.  Both
+// helpers therefore emit ONE MFMA per fenced slot, with the LDS operand of a later slot and the caller's
+// `extra(slot)` work (LDS writes, prefetch loads) issued right behind it.
+//   acc += sum_c2 a[c2] (registers) * bread(c2) (LDS, read four slots ahead)
+template <int N, typename BRead, typename Extra>
+__device__ __forceinline__ void chain_regA_ldsB(f32x16& acc, const float* a, BRead bread, Extra extra) {
+    float bq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bq[u] = bread(u);
+#pragma unroll
+    for (int c2 = 0; c2 < N; ++c2) {
+        const float bcur = bq[c2 & 3];
+        if (c2 + 4 < N) bq[c2 & 3] = bread(c2 + 4);
+        acc = mfma32(a[c2], bcur, acc);
+        extra(c2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+//   accs[cb] += aread(cb, r) (LDS image, read one r-step ahead) * bvec[r]      for r < 16, cb < NB
+template <int NB, typename ARead, typename Extra>
+__device__ __forceinline__ void product_ldsA(f32x16* accs, ARead aread, const f32x16& bvec, Extra extra) {
+    float va[NB], vb[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) va[cb] = aread(cb, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            accs[cb] = mfma32(va[cb], bvec[r], accs[cb]);
+            if (r + 1 < 16) vb[cb] = aread(cb, r + 1);
+            extra(r * NB + cb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) va[cb] = vb[cb];
+    }
+}
+
 template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
@@ -324,29 +362,32 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
 
     for (int t = t0; t < NT; t += tstep) {
         const int j0 = t * 32;
+        const int voff_n = (h * n + min(min(t + tstep, NT - 1) * 32 + li, n - 1)) * 4;  // next tile
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
-        // S^T chain; the K registers are also laid down as the transposed image the dq product reads
+        // S^T chain; behind each MFMA the K row pair it used is laid down in the transposed image
+        chain_regA_ldsB<KC / 2>(s, kv, [&](int c2) { return qt[(2 * c2 + h) * 32 + li]; },
+                                [&](int c2) { kim[simg(2 * c2 + h, li)] = kv[c2]; });
+        // dP^T chain; the K registers are free now: refill them with the next tile behind the MFMAs
+        chain_regA_ldsB<VC / 2>(dp, vv, [&](int c2) { return gt[(2 * c2 + h) * 32 + li]; }, [&](int c2) {
 #pragma unroll
-        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(kv[c2], qt[(2 * c2 + h) * 32 + li], s);
-#pragma unroll
-        for (int c2 = 0; c2 < KC / 2; ++c2) kim[simg(2 * c2 + h, li)] = kv[c2];
-#pragma unroll
-        for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(vv[c2], gt[(2 * c2 + h) * 32 + li], dp);
-        __builtin_amdgcn_sched_barrier(0);
-        load_kv(t + tstep);  // next tile: lands while the dq product below runs
+            for (int u = c2 * (KC / 2) / (VC / 2); u < (c2 + 1) * (KC / 2) / (VC / 2); ++u)
+                kv[u] = bload(k_rs, voff_n, u * 2 * row_bytes);
+        });
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool valid = j0 + acc_row(r) + 4 * h < n;
             const float p = valid ? fast_exp2(s[r] - my_lse2) : 0.f;
             s[r] = p * (dp[r] - my_delta);  // dS^T[key][query]
         }
+        // dq^T += K dS^T from the image; the V registers are refilled with the next tile meanwhile
+        product_ldsA<KB>(acc, [&](int cb, int r) { return kim[simg(cb * 32 + li, acc_row(r) + 4 * h)]; }, s,
+                         [&](int slot) {
 #pragma unroll
-        for (int cb = 0; cb < KB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[cb] = mfma32(kim[simg(cb * 32 + li, acc_row(r) + 4 * h)], s[r], acc[cb]);
+                             for (int u = slot * (VC / 2) / (16 * KB); u < (slot + 1) * (VC / 2) / (16 * KB); ++u)
+                                 vv[u] = bload(v_rs, voff_n, u * 2 * row_bytes);
+                         });
     }
 
     for (int w = 0; w < 4; ++w) {
@@ -433,6 +474,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
 
     for (int t = t0; t < NT; t += tstep) {
         const int i0 = t * 32;
+        const int voff_n = (h * n + min(min(t + tstep, NT - 1) * 32 + li, n - 1)) * 4;  // next query tile
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
@@ -444,16 +486,16 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
             l2[r] = lse[si];
             dl[r] = delta[si];
         }
+        // S chain (A = q registers, B = k tile in LDS); q row pairs go to the transposed image behind it
+        chain_regA_ldsB<KC / 2>(s, qv, [&](int c2) { return kt[(2 * c2 + h) * 32 + li]; },
+                                [&](int c2) { qim[simg(2 * c2 + h, li)] = qv[c2]; });
+        // dP chain (A = g registers); g rows to its image, q registers refilled with the next tile
+        chain_regA_ldsB<VC / 2>(dp, gv, [&](int c2) { return vt[(2 * c2 + h) * 32 + li]; }, [&](int c2) {
+            gim[simg(2 * c2 + h, li)] = gv[c2];
 #pragma unroll
-        for (int c2 = 0; c2 < KC / 2; ++c2) s = mfma32(qv[c2], kt[(2 * c2 + h) * 32 + li], s);
-#pragma unroll
-        for (int c2 = 0; c2 < KC / 2; ++c2) qim[simg(2 * c2 + h, li)] = qv[c2];
-#pragma unroll
-        for (int c2 = 0; c2 < VC / 2; ++c2) dp = mfma32(gv[c2], vt[(2 * c2 + h) * 32 + li], dp);
-#pragma unroll
-        for (int c2 = 0; c2 < VC / 2; ++c2) gim[simg(2 * c2 + h, li)] = gv[c2];
-        __builtin_amdgcn_sched_barrier(0);
-        load_qg(t + tstep);  // next query tile: lands while the dv / dk products run
+            for (int u = c2 * (KC / 2) / (VC / 2); u < (c2 + 1) * (KC / 2) / (VC / 2); ++u)
+                qv[u] = bload(q_rs, voff_n, u * 2 * row_bytes);
+        });
         f32x16 p;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -461,16 +503,15 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
             p[r] = valid ? fast_exp2(fmaf(s[r], qscale, -l2[r] * LOG2E_F)) : 0.f;  // P[query][key]
             s[r] = p[r] * (dp[r] - dl[r]);                                          // dS[query][key]
         }
+        // dv += g P (g registers refilled with the next tile meanwhile), dk += q dS
+        product_ldsA<VB>(dva, [&](int cb, int r) { return gim[simg(cb * 32 + li, acc_row(r) + 4 * h)]; }, p,
+                         [&](int slot) {
 #pragma unroll
-        for (int cb = 0; cb < VB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dva[cb] = mfma32(gim[simg(cb * 32 + li, acc_row(r) + 4 * h)], p[r], dva[cb]);
-#pragma unroll
-        for (int cb = 0; cb < KB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dka[cb] = mfma32(qim[simg(cb * 32 + li, acc_row(r) + 4 * h)], s[r], dka[cb]);
+                             for (int u = slot * (VC / 2) / (16 * VB); u < (slot + 1) * (VC / 2) / (16 * VB); ++u)
+                                 gv[u] = bload(g_rs, voff_n, u * 2 * row_bytes);
+                         });
+        product_ldsA<KB>(dka, [&](int cb, int r) { return qim[simg(cb * 32 + li, acc_row(r) + 4 * h)]; }, s,
+                         [&](int) {});
     }
 
     __syncthreads();  // every wave is done with its images: reuse them as reduction scratch
