@@ -49,6 +49,15 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
                        const float* pooled, const float* gate, int training, float* dfsp, float* dfcp,
                        float* dw_blk, float* dbn_w, float* dbn_b, float* dw1, float* dw2, void* ws,
                        hipStream_t stream);
+// ohem.hip
+int ohem_blocks(int B, int H, int W);
+hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
+                           float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
+                           hipStream_t stream);
+size_t ohem_up_bwd_workspace(int B, int C, int H, int Wl);
+hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const float* loss_px, int B, int C, int Hl,
+                           int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
+                           hipStream_t stream);
 }  // namespace cabinet
 
 static thread_local char g_err[512] = "";
@@ -248,6 +257,50 @@ int cabinet_ffm_up_bwd(const float* dout, const float* fsp, const float* low, co
                                               dfsp, dlow, dw_blk, dbn_weight, dbn_bias, dw1, dw2, workspace,
                                               static_cast<hipStream_t>(stream)),
                       "ffm_up_bwd launch");
+}
+
+// ------------------------------------------------------ OHEM-CE + fused upsample
+static int check_ohem(int B, int C, int Hl, int Wl, int H, int W) {
+    if (B <= 0 || C <= 0 || Hl <= 0 || Wl <= 0 || H <= 0 || W <= 0)
+        return fail(CABINET_ERR_INVALID_ARG, "ohem_up: non-positive dimension");
+    if (C > 32) return fail(CABINET_ERR_UNSUPPORTED, "ohem_up: C=%d classes (max 32)", C);
+    if (B > 65535 || H > 65535) return fail(CABINET_ERR_UNSUPPORTED, "ohem_up: B or H exceeds grid limits");
+    return CABINET_OK;
+}
+
+int cabinet_ohem_up_blocks(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return cabinet::ohem_blocks(B, H, W);
+}
+
+int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
+                        float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
+                        cabinet_stream_t stream) {
+    if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
+    if (!logits_low || !labels || !loss_px || !blk_sum || !blk_cnt)
+        return fail(CABINET_ERR_INVALID_ARG, "ohem_up_fwd: null tensor pointer");
+    return hip_status(cabinet::ohem_up_fwd_run(logits_low, labels, B, C, Hl, Wl, H, W, thresh, ignore_lb, loss_px,
+                                               blk_sum, blk_cnt, static_cast<hipStream_t>(stream)),
+                      "ohem_up_fwd launch");
+}
+
+size_t cabinet_ohem_up_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, int W) {
+    if (B <= 0 || C <= 0 || Hl <= 0 || Wl <= 0 || H <= 0 || W <= 0) return 0;
+    return cabinet::ohem_up_bwd_workspace(B, C, H, Wl);
+}
+
+int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const float* loss_px, int B, int C, int Hl,
+                        int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlogits_low,
+                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
+    if (!logits_low || !labels || !loss_px || !dlogits_low)
+        return fail(CABINET_ERR_INVALID_ARG, "ohem_up_bwd: null tensor pointer");
+    const size_t need = cabinet_ohem_up_bwd_workspace_bytes(B, C, Hl, Wl, H, W);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "ohem_up_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::ohem_up_bwd_run(logits_low, labels, loss_px, B, C, Hl, Wl, H, W, thresh, ignore_lb, coef,
+                                               dlogits_low, workspace, static_cast<hipStream_t>(stream)),
+                      "ohem_up_bwd launch");
 }
 
 }  // extern "C"

@@ -281,3 +281,58 @@ def ffm_fused(fsp, fcp, conv_w, bn, w1, w2):
     training, momentum = _bn_step(bn)
     return _FfmFused.apply(fsp, fcp, conv_w, bn.weight, bn.bias, w1, w2, bn.running_mean, bn.running_var,
                            training, momentum, bn.eps)
+
+
+# --------------------------------------------------------------------------- OHEM-CE fused with the final upsample
+
+
+def ohem_up_fwd_hip(logits_low, labels, size, thresh, ignore_lb):
+    """Per-pixel CE of bilinear_upsample(logits_low -> size) vs labels, never materialising the upsample.
+    Returns loss_px (B,H,W) and the three reduced statistics as ONE device tensor [n_valid, n_above, sum_above]."""
+    lib = _lib.load()
+    B, C, Hl, Wl = logits_low.shape
+    H, W = size
+    dev = logits_low.device
+    nblk = lib.cabinet_ohem_up_blocks(B, H, W)
+    loss_px = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    blk_sum = torch.empty(nblk, dtype=torch.float32, device=dev)
+    blk_cnt = torch.empty((nblk, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ohem_up_fwd(_ptr(logits_low), _ptr(labels), B, C, Hl, Wl, H, W, float(thresh), int(ignore_lb),
+                                     _ptr(loss_px), _ptr(blk_sum), _ptr(blk_cnt), _stream_handle(dev))
+    _lib.check(rc, "cabinet_ohem_up_fwd")
+    stats = torch.cat([blk_cnt.sum(dim=0).double(), blk_sum.double().sum().reshape(1)])
+    return loss_px, stats
+
+
+def ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, coef):
+    lib = _lib.load()
+    B, C, Hl, Wl = logits_low.shape
+    H, W = size
+    dev = logits_low.device
+    dlow = torch.empty_like(logits_low)
+    ws, nbytes = _workspace(lib.cabinet_ohem_up_bwd_workspace_bytes(B, C, Hl, Wl, H, W), dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ohem_up_bwd(_ptr(logits_low), _ptr(labels), _ptr(loss_px), B, C, Hl, Wl, H, W, float(thresh),
+                                     int(ignore_lb), float(coef), _ptr(dlow), _ptr(ws), nbytes, _stream_handle(dev))
+    _lib.check(rc, "cabinet_ohem_up_bwd")
+    return dlow
+
+
+class _OhemUpSelected(torch.autograd.Function):
+    """loss = sum_above / n_above for the 'at least n_min pixels above thresh' branch (reference loss.py:74-75);
+    forward statistics were produced by ohem_up_fwd_hip, backward runs the two adjoint kernels."""
+
+    @staticmethod
+    def forward(fn_ctx, logits_low, labels, loss_px, sum_above, n_above, size, thresh, ignore_lb):
+        fn_ctx.save_for_backward(logits_low, labels, loss_px)
+        fn_ctx.meta = (size, thresh, ignore_lb, n_above)
+        return (sum_above / n_above).to(torch.float32)
+
+    @staticmethod
+    def backward(fn_ctx, g):
+        logits_low, labels, loss_px = fn_ctx.saved_tensors
+        size, thresh, ignore_lb, n_above = fn_ctx.meta
+        # the upstream gradient is a device scalar: fold it in after the kernels (coef = 1/n_above inside)
+        dlow = ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, 1.0 / n_above)
+        return dlow * g, None, None, None, None, None, None, None

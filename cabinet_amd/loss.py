@@ -45,5 +45,28 @@ class OhemCELoss(nn.Module):
         hardest = torch.topk(loss.masked_fill(~valid, float("-inf")).flatten(), n_min, sorted=False).values
         return hardest.mean()
 
+    def forward_upsampled(self, logits_low, labels, size=None):
+        """``self(F.interpolate(logits_low, size, mode="bilinear", align_corners=False), labels)`` -- the pairing
+        of reference cabinet.py:240-245 with loss.py:38-80 -- with the upsample, the softmax and the selection fused
+        into hand-written kernels on HIP tensors (``cabinet_ohem_up_fwd/bwd``): neither the (B,C,H,W) logits nor
+        their log-softmax nor the per-pixel gradient are materialised.  The kernels implement the branch
+        "at least n_min pixels above thresh"; class weights or the top-n_min branch take the composite path."""
+        size = tuple(size) if size is not None else tuple(labels.shape[-2:])
+        fused = logits_low.is_cuda and not isinstance(self.weight, torch.Tensor) and logits_low.shape[1] <= 32
+        if fused:
+            from .functional import _OhemUpSelected, _f32c, ohem_up_fwd_hip
+
+            low = _f32c(logits_low)
+            lab = labels.contiguous()
+            loss_px, stats = ohem_up_fwd_hip(low.detach(), lab, size, self.thresh, self.ignore_lb)
+            n_valid, n_above, _ = stats.tolist()  # the step's one host sync
+            n_valid, n_above = int(n_valid), int(n_above)
+            if n_valid == 0:
+                return torch.zeros((), device=logits_low.device, requires_grad=True)
+            if n_above >= min(self.n_min, n_valid):
+                return _OhemUpSelected.apply(low, lab, loss_px, stats[2], n_above, size, self.thresh, self.ignore_lb)
+        up = F.interpolate(logits_low, size=size, mode="bilinear", align_corners=False)
+        return self.forward(up, labels)
+
     def extra_repr(self):
         return f"thresh={self.thresh}, n_min={self.n_min}, ignore_lb={self.ignore_lb}"

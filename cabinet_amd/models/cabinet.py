@@ -162,6 +162,15 @@ class CABiNet(nn.Module):
         self.ffm = FeatureFusionModule(128 + 256, 256)
         self.conv_out = CABiNetOutput(256, 256, n_classes)
 
+    def forward_lowres(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Both heads at H/8 x W/8, i.e. ``forward`` without its two final x8 bilinear upsamples (reference
+        cabinet.py:240-245).  ``OhemCELoss.forward_upsampled`` fuses exactly those resizes into the loss."""
+        feat_sb = self.sb(x)
+        low, high = self.ab(self.mobile(x))
+        high_up = _resize(high, feat_sb.shape[2:])
+        final = self.conv_out(self.ffm.forward_upsampled(feat_sb, low))
+        return final, high_up
+
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         size = x.shape[2:]
         feat_sb = self.sb(x)                      # (B,128,H/8,W/8)

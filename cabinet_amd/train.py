@@ -44,9 +44,12 @@ def make_criteria(batch, height, width, device, thresh=DEFAULT_SCORE_THRESHOLD, 
 class TrainStep:
     """fwd + 2x OHEM-CE + bwd (+ gradient all-reduce when a reducer is given)."""
 
-    def __init__(self, net, criteria, reducer=None, optimizer=None, autocast=False):
+    def __init__(self, net, criteria, reducer=None, optimizer=None, autocast=False, fused_loss=None):
         self.net, (self.crit_p, self.crit_16) = net, criteria
         self.reducer, self.optimizer, self.autocast = reducer, optimizer, autocast
+        # fused_loss: run the two final x8 upsamples inside the OHEM-CE kernels (device tensors only);
+        # default = on whenever the model lives on a GPU
+        self.fused_loss = fused_loss
 
     def zero_grad(self):
         if self.reducer is not None:
@@ -57,9 +60,15 @@ class TrainStep:
 
     def __call__(self, im, lb):
         self.zero_grad()
+        fused = im.is_cuda if self.fused_loss is None else self.fused_loss
         with torch.amp.autocast(device_type=im.device.type, enabled=self.autocast):
-            out, out16 = self.net(im)
-            loss = self.crit_p(out, lb) + self.crit_16(out16, lb)
+            if fused:
+                low, low16 = self.net.forward_lowres(im)
+                size = im.shape[2:]
+                loss = self.crit_p.forward_upsampled(low, lb, size) + self.crit_16.forward_upsampled(low16, lb, size)
+            else:
+                out, out16 = self.net(im)
+                loss = self.crit_p(out, lb) + self.crit_16(out16, lb)
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()

@@ -141,6 +141,28 @@ int cabinet_ffm_up_bwd(const float* dout, const float* fsp, const float* low, co
                        float* dbn_bias, float* dw1, float* dw2,
                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * OHEM cross-entropy fused with the final bilinear upsample (one call per head).
+ * Replaces src/models/cabinet.py:240-245 (F.interpolate of the (B,C,Hl,Wl) logits to (H,W), bilinear,
+ * align_corners=False) + src/utils/loss.py:51-80 (per-pixel CE with ignore_index, OHEM selection, mean)
+ * for the selection branch "at least n_min pixels have loss > thresh" (loss.py:74-75).  The other branch
+ * (top-n_min) needs an order statistic; callers take the unfused path for it.
+ *   fwd : loss_px (B,H,W) per-pixel CE (0 at ignored pixels); per-workgroup partials
+ *         blk_cnt[2*i] = #valid, blk_cnt[2*i+1] = #(loss > thresh), blk_sum[i] = sum of those losses,
+ *         i < cabinet_ohem_up_blocks(B,H,W); the caller reduces them (and decides the branch)
+ *   bwd : dlogits_low (B,C,Hl,Wl) = coef * U^T[ sel * (softmax - onehot) ],  sel = valid & (loss_px > thresh),
+ *         coef = upstream_grad / #selected.  Deterministic (no atomics).   C <= 32.
+ * labels are int64 (torch.long), (B,H,W).
+ * ------------------------------------------------------------------------- */
+int cabinet_ohem_up_blocks(int B, int H, int W);
+int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels,
+                        int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb,
+                        float* loss_px, float* blk_sum, int* blk_cnt, cabinet_stream_t stream);
+size_t cabinet_ohem_up_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, int W);
+int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const float* loss_px,
+                        int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef,
+                        float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
