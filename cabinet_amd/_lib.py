@@ -37,6 +37,9 @@ SIGNATURES = {
     "cabinet_ohem_up_fwd": (_INT, [_PTR, _PTR] + [_INT] * 6 + [_FLT, _INT] + [_PTR] * 3 + [_PTR]),
     "cabinet_ohem_up_bwd_workspace_bytes": (_SZ, [_INT] * 6),
     "cabinet_ohem_up_bwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_FLT, _INT, _FLT] + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_cab_local_supported": (_INT, [_INT] * 4),
+    "cabinet_cab_local_fwd": (_INT, [_PTR] * 3 + [_PTR] * 5 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR]),
+    "cabinet_cab_local_bwd": (_INT, [_PTR] * 4 + [_PTR] * 3 + [_PTR] * 2 + [_INT] * 5 + [_PTR] * 3 + [_PTR] * 3 + [_PTR]),
 }
 
 _lock = threading.Lock()

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include "cab_local.hpp"
 #include "common.hpp"
 
 namespace cabinet {
@@ -301,6 +302,65 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
     return hip_status(cabinet::ohem_up_bwd_run(logits_low, labels, loss_px, B, C, Hl, Wl, H, W, thresh, ignore_lb, coef,
                                                dlogits_low, workspace, static_cast<hipStream_t>(stream)),
                       "ohem_up_bwd launch");
+}
+
+// ------------------------------------------------------ CAB local branch + block output
+static int check_local(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(CABINET_ERR_INVALID_ARG, "cab_local: non-positive dimension");
+    if (!cabinet::local_shape_supported(B, H, W))
+        return fail(CABINET_ERR_UNSUPPORTED, "cab_local: B*H*W = %lld exceeds the 8192 elements one channel may occupy",
+                    (long long)B * H * W);
+    return CABINET_OK;
+}
+
+int cabinet_cab_local_supported(int B, int C, int H, int W) {
+    return B > 0 && C > 0 && H > 0 && W > 0 && cabinet::local_shape_supported(B, H, W) ? 1 : 0;
+}
+
+int cabinet_cab_local_fwd(const float* x, const float* glob, const float* gamma, const float* const* dw_w,
+                          const float* const* bn_weight, const float* const* bn_bias, float* const* running_mean,
+                          float* const* running_var, int B, int C, int H, int W, int training, float momentum,
+                          float eps, float* out, float* save_mean, float* save_invstd, cabinet_stream_t stream) {
+    if (int rc = check_local(B, C, H, W)) return rc;
+    if (!x || !out || !save_mean || !save_invstd || !dw_w || !bn_weight || !bn_bias || !running_mean || !running_var)
+        return fail(CABINET_ERR_INVALID_ARG, "cab_local_fwd: null tensor pointer");
+    if (glob && !gamma) return fail(CABINET_ERR_INVALID_ARG, "cab_local_fwd: glob given without gamma");
+    cabinet::LocalArgs a{};
+    a.x = x, a.glob = glob, a.gamma = gamma;
+    for (int s = 0; s < 3; ++s) {
+        if (!dw_w[s] || !bn_weight[s] || !bn_bias[s] || !running_mean[s] || !running_var[s])
+            return fail(CABINET_ERR_INVALID_ARG, "cab_local_fwd: null parameter pointer (stage %d)", s);
+        a.st[s].w = dw_w[s], a.st[s].bn_w = bn_weight[s], a.st[s].bn_b = bn_bias[s];
+        a.st[s].run_mean = running_mean[s], a.st[s].run_var = running_var[s];
+    }
+    a.B = B, a.C = C, a.H = H, a.W = W, a.training = training, a.momentum = momentum, a.eps = eps;
+    a.out = out, a.save_mean = save_mean, a.save_invstd = save_invstd;
+    return hip_status(cabinet::cab_local_fwd_run(a, static_cast<hipStream_t>(stream)), "cab_local_fwd launch");
+}
+
+int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, const float* gamma,
+                          const float* const* dw_w, const float* const* bn_weight, const float* const* bn_bias,
+                          const float* save_mean, const float* save_invstd, int B, int C, int H, int W, int training,
+                          float* dx, float* dglob, float* dgamma_part, float* const* ddw_w, float* const* dbn_weight,
+                          float* const* dbn_bias, cabinet_stream_t stream) {
+    if (int rc = check_local(B, C, H, W)) return rc;
+    if (!dout || !x || !dx || !save_mean || !save_invstd || !dw_w || !bn_weight || !bn_bias || !ddw_w || !dbn_weight ||
+        !dbn_bias)
+        return fail(CABINET_ERR_INVALID_ARG, "cab_local_bwd: null tensor pointer");
+    if (glob && (!gamma || !dglob || !dgamma_part))
+        return fail(CABINET_ERR_INVALID_ARG, "cab_local_bwd: glob given without gamma / dglob / dgamma_part");
+    cabinet::LocalArgs a{};
+    a.x = x, a.glob = glob, a.gamma = gamma, a.dout = dout;
+    for (int s = 0; s < 3; ++s) {
+        if (!dw_w[s] || !bn_weight[s] || !bn_bias[s] || !ddw_w[s] || !dbn_weight[s] || !dbn_bias[s])
+            return fail(CABINET_ERR_INVALID_ARG, "cab_local_bwd: null parameter pointer (stage %d)", s);
+        a.st[s].w = dw_w[s], a.st[s].bn_w = bn_weight[s], a.st[s].bn_b = bn_bias[s];
+        a.st[s].dw = ddw_w[s], a.st[s].dbn_w = dbn_weight[s], a.st[s].dbn_b = dbn_bias[s];
+    }
+    a.B = B, a.C = C, a.H = H, a.W = W, a.training = training;
+    a.save_mean = const_cast<float*>(save_mean), a.save_invstd = const_cast<float*>(save_invstd);
+    a.dx = dx, a.dglob = dglob, a.dgamma_part = dgamma_part;
+    return hip_status(cabinet::cab_local_bwd_run(a, static_cast<hipStream_t>(stream)), "cab_local_bwd launch");
 }
 
 }  // extern "C"

@@ -11,6 +11,8 @@ checkpoint surgery, EMA copies and CPU unit tests, exactly like any nn.Module.
 
 from __future__ import annotations
 
+import ctypes as _ct
+
 import torch
 import torch.nn.functional as F
 
@@ -336,3 +338,103 @@ class _OhemUpSelected(torch.autograd.Function):
         # the upstream gradient is a device scalar: fold it in after the kernels (coef = 1/n_above inside)
         dlow = ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, 1.0 / n_above)
         return dlow * g, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- CAB local branch + block output (K5)
+
+
+def _ptr3(ts):
+    return (_ct.c_void_p * 3)(*[t.data_ptr() for t in ts])
+
+
+def cab_local_supported(x):
+    return x.dim() == 4 and bool(_lib.load().cabinet_cab_local_supported(*x.shape))
+
+
+def cab_local_fwd_hip(x, glob, gamma, dw_w, bn_w, bn_b, run_mean, run_var, training, momentum, eps):
+    """out = [gamma*glob +] x*(1 + sigmoid(refine(x))); returns out and the (3,C) saved mean / invstd."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    mean = torch.empty((3, C), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((3, C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.cabinet_cab_local_fwd(_ptr(x), _ptr(glob), _ptr(gamma), _ptr3(dw_w), _ptr3(bn_w), _ptr3(bn_b),
+                                       _ptr3(run_mean), _ptr3(run_var), B, C, H, W, int(training), float(momentum),
+                                       float(eps), _ptr(out), _ptr(mean), _ptr(invstd), _stream_handle(x.device))
+    _lib.check(rc, "cabinet_cab_local_fwd")
+    return out, mean, invstd
+
+
+def cab_local_bwd_hip(g, x, glob, gamma, dw_w, bn_w, bn_b, mean, invstd, training):
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dglob = torch.empty_like(x) if glob is not None else None
+    dgamma_part = torch.empty(C, dtype=torch.float32, device=x.device) if glob is not None else None
+    ddw = [torch.empty_like(w) for w in dw_w]
+    dbw = [torch.empty_like(w) for w in bn_w]
+    dbb = [torch.empty_like(w) for w in bn_b]
+    with torch.cuda.device(x.device):
+        rc = lib.cabinet_cab_local_bwd(_ptr(g), _ptr(x), _ptr(glob), _ptr(gamma), _ptr3(dw_w), _ptr3(bn_w),
+                                       _ptr3(bn_b), _ptr(mean), _ptr(invstd), B, C, H, W, int(training), _ptr(dx),
+                                       _ptr(dglob), _ptr(dgamma_part), _ptr3(ddw), _ptr3(dbw), _ptr3(dbb),
+                                       _stream_handle(x.device))
+    _lib.check(rc, "cabinet_cab_local_bwd")
+    return dx, dglob, dgamma_part, ddw, dbw, dbb
+
+
+class _CabLocal(torch.autograd.Function):
+    """args: x, glob|None, gamma|None, 3 dw weights, 3 bn weights, 3 bn biases, 3 running means, 3 running vars,
+    training, momentum, eps."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, glob, gamma, *rest):
+        dw_w, bn_w, bn_b = [_f32c(t) for t in rest[0:3]], [_f32c(t) for t in rest[3:6]], [_f32c(t) for t in rest[6:9]]
+        run_mean, run_var = list(rest[9:12]), list(rest[12:15])
+        training, momentum, eps = rest[15:18]
+        x = _f32c(x)
+        glob = _f32c(glob) if glob is not None else None
+        gamma = _f32c(gamma) if glob is not None else None
+        out, mean, invstd = cab_local_fwd_hip(x, glob, gamma, dw_w, bn_w, bn_b, run_mean, run_var, training,
+                                              momentum, eps)
+        fn_ctx.save_for_backward(x, glob, gamma, mean, invstd, *dw_w, *bn_w, *bn_b)
+        fn_ctx.training = bool(training)
+        fn_ctx.w_shapes = [t.shape for t in rest[0:3]]
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        x, glob, gamma, mean, invstd, *params = fn_ctx.saved_tensors
+        dw_w, bn_w, bn_b = params[0:3], params[3:6], params[6:9]
+        dx, dglob, dgamma_part, ddw, dbw, dbb = cab_local_bwd_hip(_f32c(g), x, glob, gamma, dw_w, bn_w, bn_b, mean,
+                                                                  invstd, fn_ctx.training)
+        dgamma = dgamma_part.sum().reshape(gamma.shape) if glob is not None else None
+        ddw = [d.view(s) for d, s in zip(ddw, fn_ctx.w_shapes)]
+        return (dx, dglob, dgamma, *ddw, *dbw, *dbb) + (None,) * 9
+
+
+def cab_local(x, refine, glob=None, gamma=None):
+    """LocalAttention.forward (reference cab.py:182-184), plus ``gamma * glob +`` (cab.py:213-216) when given.
+
+    ``refine`` is the nn.Sequential of three DWConv blocks (conv, BatchNorm2d, ReLU) that owns the parameters
+    and running buffers; the buffers are updated in place in training mode like nn.BatchNorm2d would.
+    """
+    if not x.is_cuda:
+        raise RuntimeError("cab_local: device tensors only (host tensors take the composite ATen path)")
+    convs = [blk.block[0] for blk in refine]
+    bns = [blk.block[1] for blk in refine]
+    if len(convs) != 3 or any(c.kernel_size != (3, 3) or c.stride != (1, 1) or c.padding != (1, 1)
+                              or c.groups != x.shape[1] or c.bias is not None for c in convs):
+        raise RuntimeError("cab_local: expects three depthwise 3x3, stride 1, pad 1, bias-free convolutions")
+    if len({(bn.eps, bn.momentum) for bn in bns}) != 1:
+        raise RuntimeError("cab_local: the three BatchNorm2d must share eps and momentum")
+    steps = [_bn_step(bn) for bn in bns]
+    training, momentum = steps[0]
+    if any(s[0] != training for s in steps):
+        raise RuntimeError("cab_local: BatchNorm2d layers disagree on training mode")
+    return _CabLocal.apply(x, glob, gamma, *[c.weight for c in convs], *[bn.weight for bn in bns],
+                           *[bn.bias for bn in bns], *[bn.running_mean for bn in bns],
+                           *[bn.running_var for bn in bns], training, momentum, bns[0].eps)

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import cab_attention
+from ..functional import cab_attention, cab_local, cab_local_supported
 
 
 def _conv_bn_relu_1x1(cin, cout):
@@ -95,6 +95,8 @@ class LocalAttention(nn.Module):
         self.gate = nn.Sigmoid()
 
     def forward(self, x):
+        if x.is_cuda and cab_local_supported(x):  # one channel-resident kernel each way (K5)
+            return cab_local(x, self.refine)
         return x + x * self.gate(self.refine(x))
 
 
@@ -110,4 +112,6 @@ class ContextAggregationBlock(nn.Module):
         self.gamma = nn.Parameter(torch.zeros(1))
 
     def forward(self, x):
+        if x.is_cuda and cab_local_supported(x):  # local branch and the gamma-combine in the same kernel
+            return cab_local(x, self.local_attn.refine, self.global_attn(x), self.gamma)
         return self.gamma * self.global_attn(x) + self.local_attn(x)

@@ -163,6 +163,37 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
                         int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef,
                         float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * CAB local branch + block output, one kernel each way.
+ * Replaces src/models/cab.py:175-184 (LocalAttention.forward: three DWConv = depthwise 3x3 conv (cab.py:36-45)
+ * + BatchNorm2d + ReLU, sigmoid gate, x + x*mask) and, when `glob` is given, cab.py:213-216
+ * (ContextAggregationBlock.forward: gamma * global + local).
+ *   x, glob, out, dout, dx, dglob : (B,C,H,W);  B*H*W <= 8192 (one channel lives in the LDS of one CU)
+ *   dw_w[s] (C,9) depthwise weights (C,1,3,3), bn_weight[s] / bn_bias[s] / running_mean[s] / running_var[s] (C),
+ *   s = 0..2: HOST arrays of three DEVICE pointers (the three DWConv stages own separate parameter tensors)
+ *   gamma : device scalar (cab.py:208); glob == NULL  ->  out = x * (1 + sigmoid(mask)) only (gamma, dglob and
+ *           dgamma_part are then ignored and may be NULL)
+ *   training != 0 : batch statistics per channel (biased variance for normalisation, unbiased into running_var,
+ *           running = (1-momentum)*running + momentum*stat), save_mean / save_invstd (3,C) hold them;
+ *           training == 0 : running statistics are used (and copied into save_*).
+ *   bwd : recomputes the chain from x (nothing else is saved); writes dx, dglob = gamma*dout,
+ *         dgamma_part (C) = per-channel <dout, glob> (caller sums it: d gamma), ddw_w[s] (C,9),
+ *         dbn_weight[s], dbn_bias[s] (C).  Deterministic (no atomics).
+ * ------------------------------------------------------------------------- */
+int cabinet_cab_local_supported(int B, int C, int H, int W);   /* 1 if the shape fits, else 0 */
+int cabinet_cab_local_fwd(const float* x, const float* glob, const float* gamma,
+                          const float* const* dw_w, const float* const* bn_weight, const float* const* bn_bias,
+                          float* const* running_mean, float* const* running_var,
+                          int B, int C, int H, int W, int training, float momentum, float eps,
+                          float* out, float* save_mean, float* save_invstd, cabinet_stream_t stream);
+int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, const float* gamma,
+                          const float* const* dw_w, const float* const* bn_weight, const float* const* bn_bias,
+                          const float* save_mean, const float* save_invstd,
+                          int B, int C, int H, int W, int training,
+                          float* dx, float* dglob, float* dgamma_part,
+                          float* const* ddw_w, float* const* dbn_weight, float* const* dbn_bias,
+                          cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

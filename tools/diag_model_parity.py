@@ -41,6 +41,7 @@ def run_gpu(hip):
         import cabinet_amd.models.cab as cabmod
         import cabinet_amd.models.cabinet as cm
         cabmod.cab_attention = attn
+        cabmod.cab_local_supported = lambda x: False
 
         def ffm_fwd(self, fsp, fcp):
             feat = self.convblk(torch.cat([fsp, fcp], dim=1))
@@ -55,7 +56,7 @@ def run_gpu(hip):
     return out, out16, loss, {k: p.grad for k, p in n.named_parameters() if p.grad is not None}
 
 
-res = {"hip": run_gpu(True), "aten": run_gpu(False)}
+res = {"hip": run_gpu(True), "hip_again": run_gpu(True), "aten": run_gpu(False), "aten_again": run_gpu(False)}
 for tag, (out, out16, loss, g) in res.items():
     print(f"== {tag}: loss {float(loss):.6f} (cpu32 {float(o32[2]):.6f}, cpu64 {float(o64[2]):.6f})")
     print(f"   logits rel vs cpu32 {rel(out, o32[0]):.2e} / vs fp64 {rel(out, o64[0]):.2e};  cpu32 vs fp64 {rel(o32[0], o64[0]):.2e}")
@@ -66,4 +67,8 @@ for tag, (out, out16, loss, g) in res.items():
     hot = [r for r in rows if r[3].startswith(("ffm.", "ab.a2block."))]
     print("   worst hot-path grads:")
     for r in hot[:6]:
+        print("   %.2e %.2e %.2e %s" % r)
+    ill = [r for r in rows if r[3].startswith(("mobile.", "sb.")) and 5e-4 < r[1] < 1.0]
+    print("   ill-conditioned backbone grads (5e-4 < rel(gpu,fp64) < 1):")
+    for r in ill:
         print("   %.2e %.2e %.2e %s" % r)
