@@ -37,6 +37,17 @@ SIGNATURES = {
     "cabinet_ohem_up_fwd": (_INT, [_PTR, _PTR] + [_INT] * 6 + [_FLT, _INT] + [_PTR] * 3 + [_PTR]),
     "cabinet_ohem_up_bwd_workspace_bytes": (_SZ, [_INT] * 6),
     "cabinet_ohem_up_bwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_FLT, _INT, _FLT] + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_cab_qkv_supported": (_INT, [_INT] * 7 + [_PTR]),
+    "cabinet_cab_qkv_padded_bins": (_INT, [_INT, _PTR]),
+    "cabinet_cab_qkv_fwd_workspace_bytes": (_SZ, [_INT] * 7 + [_PTR]),
+    "cabinet_cab_qkv_fwd": (_INT, [_PTR] * 14 + [_INT] * 7 + [_PTR] + [_INT, _FLT, _FLT] + [_PTR] * 10
+                            + [_PTR, _SZ, _PTR]),
+    "cabinet_cab_qkv_bwd_workspace_bytes": (_SZ, [_INT] * 7 + [_PTR]),
+    "cabinet_cab_qkv_bwd": (_INT, [_PTR] * 20 + [_INT] * 7 + [_PTR] + [_INT] + [_PTR] * 9 + [_PTR, _SZ, _PTR]),
+    "cabinet_conv1x1_fwd_workspace_bytes": (_SZ, [_INT] * 2),
+    "cabinet_conv1x1_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_conv1x1_bwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_conv1x1_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
     "cabinet_cab_local_supported": (_INT, [_INT] * 4),
     "cabinet_cab_local_fwd": (_INT, [_PTR] * 3 + [_PTR] * 5 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR]),
     "cabinet_cab_local_bwd": (_INT, [_PTR] * 4 + [_PTR] * 3 + [_PTR] * 2 + [_INT] * 5 + [_PTR] * 3 + [_PTR] * 3 + [_PTR]),

@@ -1,0 +1,614 @@
+// K6 -- q/k/v producers of the CAB global branch, forward and backward.
+//
+// Replaces reference src/models/cab.py:137-146, i.e. for x (B,C,H,W):
+//   q = ReLU(BN_q(W_q x))                         cab.py:107-112, 137
+//   k = PSP_k(ReLU(BN_k(W_k x)))                  cab.py:113-118, 122, 141
+//   v = PSP_v(W_v x)                              cab.py:119-121, 123, 145
+//   PSP(u) = W_p . cat[u, U(A_s1 u), U(A_s2 u), ...]        cab.py:46-76   (A_s adaptive avg pool to s x s,
+//                                                            U bilinear resize back, align_corners=False)
+// The reference runs this as ~30 ATen launches forward and ~60 backward (4.1 ms of a 73 ms step at config 3,
+// most of it in pooling / resize / cat kernels on tiny tensors and atomics-based resize backward).
+//
+// MI355X-first restructuring: a 1x1 convolution acts on channels, pooling and resizing act on positions, so
+// they commute:  W_p . cat[u, U A_s u ...] = W_0 u + sum_s U( W_s (A_s u) ).  The 5*Kc-channel concat and the
+// four full-resolution pyramid maps are never formed; the pyramid terms are (Kc x Kc) x (Kc x s^2) products on
+// the pooled bins (110 positions for sizes 1,3,6,8), done as ONE GEMM per branch over a block-expanded
+// operand, and come back as a 4-tap gather from LDS.  The three projections share one GEMM (stacked weights).
+//   fwd : transposes, G(x -> zq|zk|vv), BN row statistics, BN finalize (x2), plane pass (BN+ReLU, q, kk, pooled bins),
+//         G(pooled -> T) x2, G(kk -> k), G(vv -> v), pyramid add                       = 11 launches
+//   bwd : the adjoint chain, ~20 launches, all deterministic (no atomics)
+// GEMMs are the exact-fp32 MFMA kernels of ffm.hip (blocks.hpp).
+#include "cab_qkv.hpp"
+
+#include "blocks.hpp"
+#include "common.hpp"
+
+namespace cabinet {
+
+// geometry of the pooling pyramid, passed by value to the plane kernels
+struct PyrGeom {
+    int ns, s[4], off[4], coff[4];  // sizes, first bin of each size, first column-bin of each size
+    int NB, NBp, NCB;               // bins, bins padded to a multiple of 4, column bins (sum of sizes)
+    int H, W;
+};
+
+static PyrGeom make_geom(const QkvShape& q) {
+    PyrGeom g{};
+    g.ns = q.ns, g.H = q.H, g.W = q.W;
+    int nb = 0, ncb = 0;
+    for (int i = 0; i < q.ns; ++i) {
+        g.s[i] = q.sizes[i], g.off[i] = nb, g.coff[i] = ncb;
+        nb += q.sizes[i] * q.sizes[i], ncb += q.sizes[i];
+    }
+    g.NB = nb, g.NBp = (nb + 3) & ~3, g.NCB = ncb;
+    return g;
+}
+
+__device__ __forceinline__ int bin_start(int r, int n, int s) { return (r * n) / s; }            // floor(r*n/s)
+__device__ __forceinline__ int bin_end(int r, int n, int s) { return ((r + 1) * n + s - 1) / s; }  // ceil((r+1)*n/s)
+
+// one axis of F.interpolate(mode="bilinear", align_corners=False)
+__device__ __forceinline__ void lerp_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
+    const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
+    i0 = min((int)src, in_size - 1);
+    i1 = min(i0 + 1, in_size - 1);
+    lam = src - (float)i0;
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
+}
+
+// ------------------------------------------------------------------------------- weight staging
+struct TrJob {
+    const float* in;  // rows x cols, row stride ldi
+    float* out;       // transpose: out[c * ldo + off + r]      copy: out[(off + r) * ldo + c]
+    int ldi, rows, cols, ldo, off, copy;
+};
+struct TrJobs {
+    TrJob j[8];
+};
+
+__global__ void stage_weights_kernel(TrJobs jobs) {
+    __shared__ float tile[32][33];
+    const TrJob& t = jobs.j[blockIdx.z];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (c0 >= t.cols || r0 >= t.rows) return;
+    if (t.copy) {
+        for (int j = threadIdx.y; j < 32; j += 8) {
+            const int r = r0 + j, c = c0 + threadIdx.x;
+            if (r < t.rows && c < t.cols) t.out[(size_t)(t.off + r) * t.ldo + c] = t.in[(size_t)r * t.ldi + c];
+        }
+        return;
+    }
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < t.rows && c < t.cols) tile[j][threadIdx.x] = t.in[(size_t)r * t.ldi + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < t.rows && c < t.cols) t.out[(size_t)c * t.ldo + t.off + r] = tile[threadIdx.x][j];
+    }
+}
+
+static void stage_weights(const TrJobs& jobs, int n, hipStream_t stream) {
+    int mr = 0, mc = 0;
+    for (int i = 0; i < n; ++i) {
+        mr = jobs.j[i].rows > mr ? jobs.j[i].rows : mr;
+        mc = jobs.j[i].cols > mc ? jobs.j[i].cols : mc;
+    }
+    hipLaunchKernelGGL(stage_weights_kernel, dim3(ceil_div(mc, 32), ceil_div(mr, 32), n), dim3(32, 8), 0, stream, jobs);
+}
+
+// ------------------------------------------------------------------------------- forward plane pass
+// one workgroup per (b, m) plane of the stacked projection [zq | zk | vv]:
+//   zq -> q = relu(bn(zq));   zk -> kk = relu(bn(zk)) and its pooled bins;   vv -> its pooled bins.
+// pooled is written block-expanded: row (i, c) holds the bins of size i of channel c and zeros elsewhere, so
+// that  T[m][bin] = sum_{(i,c)} W_p[m][Kc + i*Kc + c] * pooled[(i,c)][bin]  is a plain GEMM.
+__global__ __launch_bounds__(256) void qkv_plane_fwd_kernel(const float* __restrict__ zqk, const float* __restrict__ vv,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ bnq_w, const float* __restrict__ bnq_b,
+                                                             const float* __restrict__ bnk_w, const float* __restrict__ bnk_b,
+                                                             int Kc, int Vc, PyrGeom g, float* __restrict__ q,
+                                                             float* __restrict__ kk, float* __restrict__ pooled_k,
+                                                             float* __restrict__ pooled_v) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = g.H * g.W, Mtot = 2 * Kc + Vc;
+    const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot, tid = threadIdx.x;
+    float* plane = smem;               // [P]
+    float* rowpart = smem + P;         // [H][NCB]
+    float* binv = rowpart + g.H * g.NCB;  // [NBp]
+    float* pooled;
+    int ch, nch;
+    if (m < 2 * Kc) {
+        const float* src = zqk + ((size_t)b * 2 * Kc + m) * P;
+        const bool is_q = m < Kc;
+        ch = is_q ? m : m - Kc;
+        const float gam = is_q ? bnq_w[ch] : bnk_w[ch], bet = is_q ? bnq_b[ch] : bnk_b[ch];
+        const float mu = mean[m], inv = invstd[m];
+        float* dst = (is_q ? q : kk) + ((size_t)b * Kc + ch) * P;
+        for (int p = tid; p < P; p += 256) {
+            const float v = fmaxf(fmaf((src[p] - mu) * inv, gam, bet), 0.f);  // same expression as the backward mask
+            dst[p] = v;
+            plane[p] = v;
+        }
+        if (is_q) return;
+        pooled = pooled_k, nch = Kc;
+    } else {
+        ch = m - 2 * Kc, nch = Vc, pooled = pooled_v;
+        const float* src = vv + ((size_t)b * Vc + ch) * P;
+        for (int p = tid; p < P; p += 256) plane[p] = src[p];
+    }
+    __syncthreads();
+    // separable adaptive average pooling: column bins per row, then row bins
+    for (int it = tid; it < g.H * g.NCB; it += 256) {
+        const int y = it / g.NCB, cb = it - y * g.NCB;
+        int i = 0;
+        while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
+        const int c = cb - g.coff[i], xs = bin_start(c, g.W, g.s[i]), xe = bin_end(c, g.W, g.s[i]);
+        float acc = 0.f;
+        for (int x = xs; x < xe; ++x) acc += plane[y * g.W + x];
+        rowpart[it] = acc;
+    }
+    __syncthreads();
+    for (int t = tid; t < g.NBp; t += 256) {
+        float val = 0.f;
+        if (t < g.NB) {
+            int i = 0;
+            while (i + 1 < g.ns && t >= g.off[i + 1]) ++i;
+            const int s = g.s[i], r = (t - g.off[i]) / s, c = (t - g.off[i]) - r * s;
+            const int ys = bin_start(r, g.H, s), ye = bin_end(r, g.H, s);
+            const int xs = bin_start(c, g.W, s), xe = bin_end(c, g.W, s);
+            float acc = 0.f;
+            for (int y = ys; y < ye; ++y) acc += rowpart[y * g.NCB + g.coff[i] + c];
+            val = acc / (float)((ye - ys) * (xe - xs));
+        }
+        binv[t] = val;
+    }
+    __syncthreads();
+    for (int it = tid; it < g.ns * g.NBp; it += 256) {
+        const int i = it / g.NBp, t = it - i * g.NBp;
+        const bool mine = t >= g.off[i] && t < g.off[i] + g.s[i] * g.s[i];
+        pooled[(((size_t)b * g.ns + i) * nch + ch) * g.NBp + t] = mine ? binv[t] : 0.f;
+    }
+}
+
+// k[b][m][p] += sum_i U_i(T[b][m][bins of size i])(p), same for v; one workgroup per plane
+__global__ __launch_bounds__(256) void pyramid_add_kernel(const float* __restrict__ Tk, const float* __restrict__ Tv, int Kc,
+                                                           int Vc, PyrGeom g, float* __restrict__ k,
+                                                           float* __restrict__ v) {
+    __shared__ float t[256];
+    const int P = g.H * g.W, Mtot = Kc + Vc;
+    const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot;
+    const bool is_k = m < Kc;
+    const float* src = is_k ? Tk + ((size_t)b * Kc + m) * g.NBp : Tv + ((size_t)b * Vc + (m - Kc)) * g.NBp;
+    float* dst = is_k ? k + ((size_t)b * Kc + m) * P : v + ((size_t)b * Vc + (m - Kc)) * P;
+    if ((int)threadIdx.x < g.NBp) t[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const int oy = p / g.W, ox = p - oy * g.W;
+        float acc = 0.f;
+        for (int i = 0; i < g.ns; ++i) {
+            const int s = g.s[i];
+            int y0, y1, x0, x1;
+            float ly, lx;
+            lerp_taps(oy, (float)s / (float)g.H, s, y0, y1, ly);
+            lerp_taps(ox, (float)s / (float)g.W, s, x0, x1, lx);
+            const float* ti = t + g.off[i];
+            acc += (1.f - ly) * ((1.f - lx) * ti[y0 * s + x0] + lx * ti[y0 * s + x1]) +
+                   ly * ((1.f - lx) * ti[y1 * s + x0] + lx * ti[y1 * s + x1]);
+        }
+        dst[p] += acc;
+    }
+}
+
+// ------------------------------------------------------------------------------- backward plane passes
+// dT[b][m][bin] = sum_p U_i[p][bin] * d[b][m][p]   (adjoint of the pyramid resize), d = dk | dv; separable:
+// colpart[oy][(i,xs)] = sum_ox wx_i(ox,xs) d[oy][ox], then dT[(i,ys,xs)] = sum_oy wy_i(oy,ys) colpart[oy][(i,xs)]
+__global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __restrict__ dk, const float* __restrict__ dv,
+                                                               int Kc, int Vc, PyrGeom g, float* __restrict__ dTk,
+                                                               float* __restrict__ dTv) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = g.H * g.W, Mtot = Kc + Vc, tid = threadIdx.x;
+    const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot;
+    const bool is_k = m < Kc;
+    const float* src = is_k ? dk + ((size_t)b * Kc + m) * P : dv + ((size_t)b * Vc + (m - Kc)) * P;
+    float* dst = is_k ? dTk + ((size_t)b * Kc + m) * g.NBp : dTv + ((size_t)b * Vc + (m - Kc)) * g.NBp;
+    float* plane = smem;                     // [P]
+    float* wx = smem + P;                    // [NCB][W]
+    float* wy = wx + g.NCB * g.W;            // [NCB][H]
+    float* colpart = wy + g.NCB * g.H;       // [H][NCB]
+    for (int p = tid; p < P; p += 256) plane[p] = src[p];
+    for (int it = tid; it < g.NCB * g.W; it += 256) {
+        const int cb = it / g.W, ox = it - cb * g.W;
+        int i = 0;
+        while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
+        const int xs = cb - g.coff[i];
+        int x0, x1;
+        float lx;
+        lerp_taps(ox, (float)g.s[i] / (float)g.W, g.s[i], x0, x1, lx);
+        wx[it] = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+    }
+    for (int it = tid; it < g.NCB * g.H; it += 256) {
+        const int cb = it / g.H, oy = it - cb * g.H;
+        int i = 0;
+        while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
+        const int ys = cb - g.coff[i];
+        int y0, y1;
+        float ly;
+        lerp_taps(oy, (float)g.s[i] / (float)g.H, g.s[i], y0, y1, ly);
+        wy[it] = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+    }
+    __syncthreads();
+    for (int it = tid; it < g.H * g.NCB; it += 256) {
+        const int oy = it / g.NCB, cb = it - oy * g.NCB;
+        const float* w = wx + cb * g.W;
+        const float* row = plane + oy * g.W;
+        float acc = 0.f;
+        for (int ox = 0; ox < g.W; ++ox) acc += w[ox] * row[ox];
+        colpart[it] = acc;
+    }
+    __syncthreads();
+    for (int t = tid; t < g.NBp; t += 256) {
+        float acc = 0.f;
+        if (t < g.NB) {
+            int i = 0;
+            while (i + 1 < g.ns && t >= g.off[i + 1]) ++i;
+            const int s = g.s[i], ys = (t - g.off[i]) / s, xs = (t - g.off[i]) - ys * s;
+            const float* w = wy + (g.coff[i] + ys) * g.H;
+            for (int oy = 0; oy < g.H; ++oy) acc += w[oy] * colpart[oy * g.NCB + g.coff[i] + xs];
+        }
+        dst[t] = acc;
+    }
+}
+
+// one workgroup per (b, m) plane of [q | k | v]:
+//   q : dy = dq * 1[bn(zq) > 0]                                      -> dzqk rows [0,Kc),  BN-backward partial sums
+//   k : dy = (lin_k + A^T dpooled_k) * 1[bn(zk) > 0]                 -> dzqk rows [Kc,2Kc), BN-backward partial sums
+//   v : dvv += A^T dpooled_v                                          (in place)
+// A^T = adjoint of the adaptive average pools; dpooled comes block-expanded (row (i,c) holds the bins of size i)
+__global__ __launch_bounds__(256) void qkv_plane_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ lin_k,
+                                                             const float* __restrict__ zqk, const float* __restrict__ dpe_k,
+                                                             const float* __restrict__ dpe_v, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ bnq_w, const float* __restrict__ bnq_b,
+                                                             const float* __restrict__ bnk_w, const float* __restrict__ bnk_b,
+                                                             int B, int Kc, int Vc, PyrGeom g, float* __restrict__ dzqk,
+                                                             float* __restrict__ dvv, float* __restrict__ bnpart) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red[4];
+    const int P = g.H * g.W, Mtot = 2 * Kc + Vc, tid = threadIdx.x;
+    const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot;
+    float* dp = smem;            // [NBp]   dpooled / bin size
+    float* E = smem + g.NBp;     // [H][NCB] row-expanded
+    const bool is_q = m < Kc, is_v = m >= 2 * Kc;
+    if (!is_q) {
+        const int ch = is_v ? m - 2 * Kc : m - Kc, nch = is_v ? Vc : Kc;
+        const float* dpe = is_v ? dpe_v : dpe_k;
+        for (int t = tid; t < g.NBp; t += 256) {
+            float val = 0.f;
+            if (t < g.NB) {
+                int i = 0;
+                while (i + 1 < g.ns && t >= g.off[i + 1]) ++i;
+                const int s = g.s[i], r = (t - g.off[i]) / s, c = (t - g.off[i]) - r * s;
+                const int cnt = (bin_end(r, g.H, s) - bin_start(r, g.H, s)) * (bin_end(c, g.W, s) - bin_start(c, g.W, s));
+                val = dpe[(((size_t)b * g.ns + i) * nch + ch) * g.NBp + t] / (float)cnt;
+            }
+            dp[t] = val;
+        }
+        __syncthreads();
+        for (int it = tid; it < g.H * g.NCB; it += 256) {
+            const int y = it / g.NCB, cb = it - y * g.NCB;
+            int i = 0;
+            while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
+            const int s = g.s[i], c = cb - g.coff[i];
+            float acc = 0.f;
+            for (int r = 0; r < s; ++r)
+                if (bin_start(r, g.H, s) <= y && y < bin_end(r, g.H, s)) acc += dp[g.off[i] + r * s + c];
+            E[it] = acc;
+        }
+        __syncthreads();
+    }
+    auto pool_adjoint = [&](int p) {
+        const int y = p / g.W, x = p - y * g.W;
+        float acc = 0.f;
+        for (int i = 0; i < g.ns; ++i) {
+            const int s = g.s[i], c0 = (x * s) / g.W;
+            // a pixel lies in its nominal bin and possibly a neighbour (bins overlap when W % s != 0);
+            // with more bins than pixels several bins share it, so scan them all
+            const int lo = s <= g.W ? max(c0 - 1, 0) : 0, hi = s <= g.W ? min(c0 + 1, s - 1) : s - 1;
+            for (int c = lo; c <= hi; ++c)
+                if (bin_start(c, g.W, s) <= x && x < bin_end(c, g.W, s)) acc += E[y * g.NCB + g.coff[i] + c];
+        }
+        return acc;
+    };
+    if (is_v) {
+        float* d = dvv + ((size_t)b * Vc + (m - 2 * Kc)) * P;
+        for (int p = tid; p < P; p += 256) d[p] += pool_adjoint(p);
+        return;
+    }
+    const int ch = is_q ? m : m - Kc;
+    const float mu = mean[m], inv = invstd[m];
+    const float gam = is_q ? bnq_w[ch] : bnk_w[ch], bet = is_q ? bnq_b[ch] : bnk_b[ch];
+    const float* z = zqk + ((size_t)b * 2 * Kc + m) * P;
+    const float* din = is_q ? dq + ((size_t)b * Kc + ch) * P : lin_k + ((size_t)b * Kc + ch) * P;
+    float* dout = dzqk + ((size_t)b * 2 * Kc + m) * P;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = tid; p < P; p += 256) {
+        const float xh = (z[p] - mu) * inv;
+        float d = din[p];
+        if (!is_q) d += pool_adjoint(p);
+        const float dy = fmaf(xh, gam, bet) > 0.f ? d : 0.f;
+        dout[p] = dy;
+        s1 += dy, s2 += dy * xh;
+    }
+    s1 = block_sum256(s1, red);
+    s2 = block_sum256(s2, red);
+    if (tid == 0) {
+        bnpart[(size_t)m * B + b] = s1;
+        bnpart[((size_t)2 * Kc + m) * B + b] = s2;
+    }
+}
+
+// BN backward, in place on dzqk (B, 2Kc, P):  dz = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat))  (training)
+// or gamma*invstd*dy (eval); planes with b == 0 also write dgamma = sum dy*xhat, dbeta = sum dy
+__global__ __launch_bounds__(256) void qkv_bn_bwd_kernel(const float* __restrict__ zqk, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ bnq_w,
+                                                          const float* __restrict__ bnk_w, const float* __restrict__ bnpart,
+                                                          int B, int Kc, int P, int training, float* __restrict__ dzqk,
+                                                          float* __restrict__ dbnq_w, float* __restrict__ dbnq_b,
+                                                          float* __restrict__ dbnk_w, float* __restrict__ dbnk_b) {
+    const int b = blockIdx.x / (2 * Kc), m = blockIdx.x - b * 2 * Kc;
+    float S1 = 0.f, S2 = 0.f;
+    for (int i = 0; i < B; ++i) {
+        S1 += bnpart[(size_t)m * B + i];
+        S2 += bnpart[((size_t)2 * Kc + m) * B + i];
+    }
+    const bool is_q = m < Kc;
+    const int ch = is_q ? m : m - Kc;
+    if (b == 0 && threadIdx.x == 0) {
+        (is_q ? dbnq_w : dbnk_w)[ch] = S2;
+        (is_q ? dbnq_b : dbnk_b)[ch] = S1;
+    }
+    const float inv_n = 1.f / ((float)B * (float)P);
+    const float m1 = training ? S1 * inv_n : 0.f, m2 = training ? S2 * inv_n : 0.f;
+    const float mu = mean[m], inv = invstd[m], gi = (is_q ? bnq_w[ch] : bnk_w[ch]) * inv;
+    const float* z = zqk + ((size_t)b * 2 * Kc + m) * P;
+    float* d = dzqk + ((size_t)b * 2 * Kc + m) * P;
+    for (int p = threadIdx.x; p < P; p += 256) d[p] = gi * (d[p] - m1 - (z[p] - mu) * inv * m2);
+}
+
+// ------------------------------------------------------------------------------- host side
+static size_t fbytes(size_t n) { return align_up(n * sizeof(float), 256); }
+
+static size_t lds_fwd_plane(const PyrGeom& g) { return ((size_t)g.H * g.W + (size_t)g.H * g.NCB + g.NBp) * sizeof(float); }
+static size_t lds_adjoint(const PyrGeom& g) {
+    return ((size_t)g.H * g.W + (size_t)g.NCB * (g.W + g.H) + (size_t)g.H * g.NCB) * sizeof(float);
+}
+static size_t lds_bwd_plane(const PyrGeom& g) { return ((size_t)g.NBp + (size_t)g.H * g.NCB) * sizeof(float); }
+
+const char* qkv_unsupported(const QkvShape& s) {
+    if (s.ns < 1 || s.ns > 4) return "1..4 pyramid sizes";
+    for (int i = 0; i < s.ns; ++i)
+        if (s.sizes[i] < 1 || s.sizes[i] > 16) return "pyramid sizes in 1..16";
+    const PyrGeom g = make_geom(s);
+    if (g.NBp > 256) return "at most 256 pyramid bins";
+    if ((s.C % 16) || (s.Kc % 16) || (s.Vc % 16)) return "channel counts that are multiples of 16";
+    if (lds_fwd_plane(g) > 64 * 1024 || lds_adjoint(g) > 64 * 1024) return "H*W small enough for one plane in LDS";
+    return nullptr;
+}
+
+struct FwdWs {
+    size_t at1, at2k, at2v, atpk, atpv, stat, tk, tv, total;
+};
+static FwdWs fwd_layout(const QkvShape& s) {
+    const PyrGeom g = make_geom(s);
+    const int Mtot = 2 * s.Kc + s.Vc;
+    FwdWs w{};
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        const size_t o = off;
+        off += fbytes(floats);
+        return o;
+    };
+    w.at1 = take((size_t)s.C * Mtot);
+    w.at2k = take((size_t)s.Kc * s.Kc);
+    w.at2v = take((size_t)s.Vc * s.Vc);
+    w.atpk = take((size_t)s.ns * s.Kc * s.Kc);
+    w.atpv = take((size_t)s.ns * s.Vc * s.Vc);
+    w.stat = take((size_t)2 * 2 * s.Kc * s.B);
+    w.tk = take((size_t)s.B * s.Kc * g.NBp);
+    w.tv = take((size_t)s.B * s.Vc * g.NBp);
+    w.total = off;
+    return w;
+}
+size_t qkv_fwd_workspace(const QkvShape& s) { return fwd_layout(s).total; }
+int qkv_padded_bins(const QkvShape& s) { return make_geom(s).NBp; }
+
+hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, int training, float momentum, float eps,
+                       const QkvSaved& sv, float* q, float* k, float* v, void* ws, hipStream_t stream) {
+    const PyrGeom g = make_geom(s);
+    const int P = s.H * s.W, Mtot = 2 * s.Kc + s.Vc, ldk = (s.ns + 1) * s.Kc, ldv = (s.ns + 1) * s.Vc;
+    const FwdWs L = fwd_layout(s);
+    char* base = static_cast<char*>(ws);
+    auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
+    TrJobs jobs{};
+    jobs.j[0] = {w.wq, at(L.at1), s.C, s.Kc, s.C, Mtot, 0, 0};
+    jobs.j[1] = {w.wk, at(L.at1), s.C, s.Kc, s.C, Mtot, s.Kc, 0};
+    jobs.j[2] = {w.wv, at(L.at1), s.C, s.Vc, s.C, Mtot, 2 * s.Kc, 0};
+    jobs.j[3] = {w.wpk, at(L.at2k), ldk, s.Kc, s.Kc, s.Kc, 0, 0};
+    jobs.j[4] = {w.wpv, at(L.at2v), ldv, s.Vc, s.Vc, s.Vc, 0, 0};
+    jobs.j[5] = {w.wpk + s.Kc, at(L.atpk), ldk, s.Kc, s.ns * s.Kc, s.Kc, 0, 0};
+    jobs.j[6] = {w.wpv + s.Vc, at(L.atpv), ldv, s.Vc, s.ns * s.Vc, s.Vc, 0, 0};
+    stage_weights(jobs, 7, stream);
+    {   // [zq | zk | vv] = [W_q; W_k; W_v] x
+        GemmKArgs a{};
+        a.at = at(L.at1), a.lda = Mtot, a.M = Mtot, a.K = s.C;
+        a.src0 = x, a.src1 = x, a.K0 = s.C;
+        a.dst0 = sv.zqk, a.dst1 = sv.vv, a.M0 = 2 * s.Kc;
+        a.P = P;
+        gemm_kmajor(a, s.B, stream);
+    }
+    if (training) bn_rowstats(sv.zqk, at(L.stat), s.B, 2 * s.Kc, P, stream);
+    bn_finalize(at(L.stat), s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps, w.bnq_rm, w.bnq_rv,
+                sv.mean, sv.invstd, stream);
+    bn_finalize(at(L.stat) + (size_t)s.Kc * s.B, s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps,
+                w.bnk_rm, w.bnk_rv, sv.mean + s.Kc, sv.invstd + s.Kc, stream);
+    hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
+                       sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);
+    for (int br = 0; br < 2; ++br) {  // T = W_p[:, Kc:] . pooled (block-expanded), then k = W_0 kk (+ pyramid below)
+        const int Kch = br ? s.Vc : s.Kc;
+        GemmKArgs a{};
+        a.at = at(br ? L.atpv : L.atpk), a.lda = Kch, a.M = Kch, a.K = s.ns * Kch;
+        a.src0 = a.src1 = br ? sv.pooled_v : sv.pooled_k, a.K0 = a.K;
+        a.dst0 = a.dst1 = at(br ? L.tv : L.tk), a.M0 = Kch;
+        a.P = g.NBp;
+        gemm_kmajor(a, s.B, stream);
+        GemmKArgs c{};
+        c.at = at(br ? L.at2v : L.at2k), c.lda = Kch, c.M = Kch, c.K = Kch;
+        c.src0 = c.src1 = br ? sv.vv : sv.kk, c.K0 = Kch;
+        c.dst0 = c.dst1 = br ? v : k, c.M0 = Kch;
+        c.P = P;
+        gemm_kmajor(c, s.B, stream);
+    }
+    hipLaunchKernelGGL(pyramid_add_kernel, dim3(s.B * (s.Kc + s.Vc)), dim3(256), 0, stream, at(L.tk), at(L.tv), s.Kc, s.Vc,
+                       g, k, v);
+    return hipGetLastError();
+}
+
+struct BwdWs {
+    size_t dtk, dtv, dpek, dpev, link, dzqk, dvv, bnpart, wstack, part, total;
+};
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+static BwdWs bwd_layout(const QkvShape& s) {
+    const PyrGeom g = make_geom(s);
+    const int P = s.H * s.W, Mtot = 2 * s.Kc + s.Vc;
+    BwdWs w{};
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        const size_t o = off;
+        off += fbytes(floats);
+        return o;
+    };
+    w.dtk = take((size_t)s.B * s.Kc * g.NBp);
+    w.dtv = take((size_t)s.B * s.Vc * g.NBp);
+    w.dpek = take((size_t)s.B * s.ns * s.Kc * g.NBp);
+    w.dpev = take((size_t)s.B * s.ns * s.Vc * g.NBp);
+    w.link = take((size_t)s.B * s.Kc * P);
+    w.dzqk = take((size_t)s.B * 2 * s.Kc * P);
+    w.dvv = take((size_t)s.B * s.Vc * P);
+    w.bnpart = take((size_t)2 * 2 * s.Kc * s.B);
+    w.wstack = take((size_t)Mtot * s.C);
+    size_t part = dw_part_floats(s.B, 2 * s.Kc, s.C, P);
+    part = max_sz(part, dw_part_floats(s.B, s.Vc, s.C, P));
+    part = max_sz(part, dw_part_floats(s.B, s.Kc, s.Kc, P));
+    part = max_sz(part, dw_part_floats(s.B, s.Vc, s.Vc, P));
+    part = max_sz(part, dw_part_floats(s.B, s.Kc, s.ns * s.Kc, g.NBp));
+    part = max_sz(part, dw_part_floats(s.B, s.Vc, s.ns * s.Vc, g.NBp));
+    w.part = take(part);
+    w.total = off;
+    return w;
+}
+size_t qkv_bwd_workspace(const QkvShape& s) { return bwd_layout(s).total; }
+
+hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, const float* dk, const float* dv,
+                       const float* x, int training, const QkvSaved& sv, const QkvGrads& gr, void* ws,
+                       hipStream_t stream) {
+    const PyrGeom g = make_geom(s);
+    const int P = s.H * s.W, Mtot = 2 * s.Kc + s.Vc, ldk = (s.ns + 1) * s.Kc, ldv = (s.ns + 1) * s.Vc;
+    const BwdWs L = bwd_layout(s);
+    char* base = static_cast<char*>(ws);
+    auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
+    float* part = at(L.part);
+    hipError_t e;
+    TrJobs jobs{};
+    jobs.j[0] = {w.wq, at(L.wstack), s.C, s.Kc, s.C, s.C, 0, 1};
+    jobs.j[1] = {w.wk, at(L.wstack), s.C, s.Kc, s.C, s.C, s.Kc, 1};
+    jobs.j[2] = {w.wv, at(L.wstack), s.C, s.Vc, s.C, s.C, 2 * s.Kc, 1};
+    stage_weights(jobs, 3, stream);
+    // pyramid terms: dT = U^T d,  dW_p[:, Kc:] = sum dT (x) pooled,  dpooled = W_p[:, Kc:]^T dT
+    hipLaunchKernelGGL(pyramid_adjoint_kernel, dim3(s.B * (s.Kc + s.Vc)), dim3(256), lds_adjoint(g), stream, dk, dv, s.Kc,
+                       s.Vc, g, at(L.dtk), at(L.dtv));
+    for (int br = 0; br < 2; ++br) {
+        const int Kch = br ? s.Vc : s.Kc, ld = br ? ldv : ldk;
+        const float* wp = br ? w.wpv : w.wpk;
+        float* dT = at(br ? L.dtv : L.dtk);
+        if ((e = dw_product(dT, br ? sv.pooled_v : sv.pooled_k, s.B, Kch, s.ns * Kch, g.NBp, part, br ? gr.dwpv : gr.dwpk,
+                            ld, Kch, stream)) != hipSuccess)
+            return e;
+        GemmKArgs a{};  // dpooled[(i,c)][bin] = sum_m W_p[m][Kc + (i,c)] dT[m][bin]
+        a.at = wp + Kch, a.lda = ld, a.M = s.ns * Kch, a.K = Kch;
+        a.src0 = a.src1 = dT, a.K0 = Kch;
+        a.dst0 = a.dst1 = at(br ? L.dpev : L.dpek), a.M0 = a.M;
+        a.P = g.NBp;
+        gemm_kmajor(a, s.B, stream);
+        GemmKArgs c{};  // identity-branch term: W_0^T d
+        c.at = wp, c.lda = ld, c.M = Kch, c.K = Kch;
+        c.src0 = c.src1 = br ? dv : dk, c.K0 = Kch;
+        c.dst0 = c.dst1 = at(br ? L.dvv : L.link), c.M0 = Kch;
+        c.P = P;
+        gemm_kmajor(c, s.B, stream);
+        // dW_p[:, :Kc] = sum d (x) u,  u = kk | vv
+        if ((e = dw_product(br ? dv : dk, br ? sv.vv : sv.kk, s.B, Kch, Kch, P, part, br ? gr.dwpv : gr.dwpk, ld, 0,
+                            stream)) != hipSuccess)
+            return e;
+    }
+    hipLaunchKernelGGL(qkv_plane_bwd_kernel, dim3(s.B * Mtot), dim3(256), lds_bwd_plane(g), stream, dq, at(L.link), sv.zqk,
+                       at(L.dpek), at(L.dpev), sv.mean, sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.B, s.Kc, s.Vc, g,
+                       at(L.dzqk), at(L.dvv), at(L.bnpart));
+    hipLaunchKernelGGL(qkv_bn_bwd_kernel, dim3(s.B * 2 * s.Kc), dim3(256), 0, stream, sv.zqk, sv.mean, sv.invstd, w.bnq_w,
+                       w.bnk_w, at(L.bnpart), s.B, s.Kc, P, training, at(L.dzqk), gr.dbnq_w, gr.dbnq_b, gr.dbnk_w,
+                       gr.dbnk_b);
+    {   // dx = [W_q; W_k; W_v]^T [dzq; dzk; dvv]
+        GemmKArgs a{};
+        a.at = at(L.wstack), a.lda = s.C, a.M = s.C, a.K = Mtot;
+        a.src0 = at(L.dzqk), a.src1 = at(L.dvv), a.K0 = 2 * s.Kc;
+        a.dst0 = a.dst1 = gr.dx, a.M0 = s.C;
+        a.P = P;
+        gemm_kmajor(a, s.B, stream);
+    }
+    if ((e = dw_product(at(L.dzqk), x, s.B, 2 * s.Kc, s.C, P, part, gr.dwqk, s.C, 0, stream)) != hipSuccess) return e;
+    if ((e = dw_product(at(L.dvv), x, s.B, s.Vc, s.C, P, part, gr.dwv, s.C, 0, stream)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- plain 1x1 convolution (no bias)
+size_t conv1x1_fwd_workspace(int Ci, int Co) { return fbytes((size_t)Ci * Co); }
+size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P) { return fbytes(dw_part_floats(B, Co, Ci, P)); }
+
+hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int Co, int P, float* y, void* ws,
+                           hipStream_t stream) {
+    float* wt = static_cast<float*>(ws);
+    TrJobs jobs{};
+    jobs.j[0] = {wgt, wt, Ci, Co, Ci, Co, 0, 0};
+    stage_weights(jobs, 1, stream);
+    GemmKArgs a{};
+    a.at = wt, a.lda = Co, a.M = Co, a.K = Ci;
+    a.src0 = a.src1 = x, a.K0 = Ci;
+    a.dst0 = a.dst1 = y, a.M0 = Co;
+    a.P = P;
+    gemm_kmajor(a, B, stream);
+    return hipGetLastError();
+}
+
+hipError_t conv1x1_bwd_run(const float* dy, const float* x, const float* wgt, int B, int Ci, int Co, int P, float* dx,
+                           float* dw, void* ws, hipStream_t stream) {
+    if (dx) {  // dx = W^T dy: the (Co x Ci) weight is already the K-major A operand
+        GemmKArgs a{};
+        a.at = wgt, a.lda = Ci, a.M = Ci, a.K = Co;
+        a.src0 = a.src1 = dy, a.K0 = Co;
+        a.dst0 = a.dst1 = dx, a.M0 = Ci;
+        a.P = P;
+        gemm_kmajor(a, B, stream);
+    }
+    if (dw) return dw_product(dy, x, B, Co, Ci, P, static_cast<float*>(ws), dw, Ci, 0, stream);
+    return hipGetLastError();
+}
+
+}  // namespace cabinet

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "cab_local.hpp"
+#include "cab_qkv.hpp"
 #include "common.hpp"
 
 namespace cabinet {
@@ -361,6 +362,135 @@ int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, 
     a.save_mean = const_cast<float*>(save_mean), a.save_invstd = const_cast<float*>(save_invstd);
     a.dx = dx, a.dglob = dglob, a.dgamma_part = dgamma_part;
     return hip_status(cabinet::cab_local_bwd_run(a, static_cast<hipStream_t>(stream)), "cab_local_bwd launch");
+}
+
+// ------------------------------------------------------ q/k/v producers
+static int qkv_shape(int B, int C, int Kc, int Vc, int H, int W, int ns, const int* sizes, cabinet::QkvShape& s,
+                     const char* who) {
+    if (B <= 0 || C <= 0 || Kc <= 0 || Vc <= 0 || H <= 0 || W <= 0 || !sizes)
+        return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension or null sizes", who);
+    if (ns < 1 || ns > 4) return fail(CABINET_ERR_UNSUPPORTED, "%s: n_sizes=%d (1..4)", who, ns);
+    s = cabinet::QkvShape{B, C, Kc, Vc, H, W, ns, {0, 0, 0, 0}};
+    for (int i = 0; i < ns; ++i) s.sizes[i] = sizes[i];
+    if (const char* need = cabinet::qkv_unsupported(s)) return fail(CABINET_ERR_UNSUPPORTED, "%s: needs %s", who, need);
+    if ((long long)B * (2 * Kc + Vc) > 2147483647LL / 2) return fail(CABINET_ERR_UNSUPPORTED, "%s: grid too large", who);
+    return CABINET_OK;
+}
+
+int cabinet_cab_qkv_supported(int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes) {
+    cabinet::QkvShape s;
+    return qkv_shape(B, C, Kc, Vc, H, W, n_sizes, sizes, s, "cab_qkv") == CABINET_OK ? 1 : 0;
+}
+
+int cabinet_cab_qkv_padded_bins(int n_sizes, const int* sizes) {
+    if (n_sizes < 1 || n_sizes > 4 || !sizes) return 0;
+    cabinet::QkvShape s{1, 16, 16, 16, 1, 1, n_sizes, {0, 0, 0, 0}};
+    for (int i = 0; i < n_sizes; ++i) s.sizes[i] = sizes[i];
+    return cabinet::qkv_padded_bins(s);
+}
+
+size_t cabinet_cab_qkv_fwd_workspace_bytes(int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes) {
+    cabinet::QkvShape s;
+    if (qkv_shape(B, C, Kc, Vc, H, W, n_sizes, sizes, s, "cab_qkv_fwd")) return 0;
+    return cabinet::qkv_fwd_workspace(s);
+}
+
+int cabinet_cab_qkv_fwd(const float* x, const float* wq, const float* wk, const float* wv, const float* bnq_weight,
+                        const float* bnq_bias, float* bnq_running_mean, float* bnq_running_var,
+                        const float* bnk_weight, const float* bnk_bias, float* bnk_running_mean,
+                        float* bnk_running_var, const float* wpk, const float* wpv, int B, int C, int Kc, int Vc, int H,
+                        int W, int n_sizes, const int* sizes, int training, float momentum, float eps, float* q,
+                        float* k, float* v, float* zqk, float* vv, float* kk, float* pooled_k, float* pooled_v,
+                        float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                        cabinet_stream_t stream) {
+    cabinet::QkvShape s;
+    if (int rc = qkv_shape(B, C, Kc, Vc, H, W, n_sizes, sizes, s, "cab_qkv_fwd")) return rc;
+    if (!x || !wq || !wk || !wv || !bnq_weight || !bnq_bias || !bnq_running_mean || !bnq_running_var || !bnk_weight ||
+        !bnk_bias || !bnk_running_mean || !bnk_running_var || !wpk || !wpv || !q || !k || !v || !zqk || !vv || !kk ||
+        !pooled_k || !pooled_v || !save_mean || !save_invstd)
+        return fail(CABINET_ERR_INVALID_ARG, "cab_qkv_fwd: null tensor pointer");
+    const size_t need = cabinet::qkv_fwd_workspace(s);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "cab_qkv_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    const cabinet::QkvParams w{wq, wk, wv, bnq_weight, bnq_bias, bnk_weight, bnk_bias, bnq_running_mean,
+                               bnq_running_var, bnk_running_mean, bnk_running_var, wpk, wpv};
+    const cabinet::QkvSaved sv{zqk, vv, kk, pooled_k, pooled_v, save_mean, save_invstd};
+    return hip_status(cabinet::qkv_fwd_run(s, w, x, training, momentum, eps, sv, q, k, v, workspace,
+                                           static_cast<hipStream_t>(stream)),
+                      "cab_qkv_fwd launch");
+}
+
+size_t cabinet_cab_qkv_bwd_workspace_bytes(int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes) {
+    cabinet::QkvShape s;
+    if (qkv_shape(B, C, Kc, Vc, H, W, n_sizes, sizes, s, "cab_qkv_bwd")) return 0;
+    return cabinet::qkv_bwd_workspace(s);
+}
+
+int cabinet_cab_qkv_bwd(const float* dq, const float* dk, const float* dv, const float* x, const float* wq,
+                        const float* wk, const float* wv, const float* bnq_weight, const float* bnq_bias,
+                        const float* bnk_weight, const float* bnk_bias, const float* wpk, const float* wpv,
+                        const float* zqk, const float* vv, const float* kk, const float* pooled_k,
+                        const float* pooled_v, const float* save_mean, const float* save_invstd, int B, int C, int Kc,
+                        int Vc, int H, int W, int n_sizes, const int* sizes, int training, float* dx, float* dwqk,
+                        float* dwv, float* dbnq_weight, float* dbnq_bias, float* dbnk_weight, float* dbnk_bias,
+                        float* dwpk, float* dwpv, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    cabinet::QkvShape s;
+    if (int rc = qkv_shape(B, C, Kc, Vc, H, W, n_sizes, sizes, s, "cab_qkv_bwd")) return rc;
+    if (!dq || !dk || !dv || !x || !wq || !wk || !wv || !bnq_weight || !bnq_bias || !bnk_weight || !bnk_bias || !wpk ||
+        !wpv || !zqk || !vv || !kk || !pooled_k || !pooled_v || !save_mean || !save_invstd || !dx || !dwqk || !dwv ||
+        !dbnq_weight || !dbnq_bias || !dbnk_weight || !dbnk_bias || !dwpk || !dwpv)
+        return fail(CABINET_ERR_INVALID_ARG, "cab_qkv_bwd: null tensor pointer");
+    const size_t need = cabinet::qkv_bwd_workspace(s);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "cab_qkv_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    const cabinet::QkvParams w{wq, wk, wv, bnq_weight, bnq_bias, bnk_weight, bnk_bias, nullptr, nullptr, nullptr,
+                               nullptr, wpk, wpv};
+    const cabinet::QkvSaved sv{const_cast<float*>(zqk), const_cast<float*>(vv), const_cast<float*>(kk),
+                               const_cast<float*>(pooled_k), const_cast<float*>(pooled_v),
+                               const_cast<float*>(save_mean), const_cast<float*>(save_invstd)};
+    const cabinet::QkvGrads gr{dx, dwqk, dwv, dbnq_weight, dbnq_bias, dbnk_weight, dbnk_bias, dwpk, dwpv};
+    return hip_status(cabinet::qkv_bwd_run(s, w, dq, dk, dv, x, training, sv, gr, workspace,
+                                           static_cast<hipStream_t>(stream)),
+                      "cab_qkv_bwd launch");
+}
+
+// ------------------------------------------------------ bias-free 1x1 convolution
+static int check_conv1x1(int B, int Ci, int Co, int P, const char* who) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || P <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if ((Ci % 16) || (Co % 16))
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: Ci=%d, Co=%d must be multiples of 16", who, Ci, Co);
+    if (B > 65535) return fail(CABINET_ERR_UNSUPPORTED, "%s: B exceeds grid limits", who);
+    return CABINET_OK;
+}
+
+size_t cabinet_conv1x1_fwd_workspace_bytes(int Ci, int Co) {
+    return Ci > 0 && Co > 0 ? cabinet::conv1x1_fwd_workspace(Ci, Co) : 0;
+}
+
+int cabinet_conv1x1_fwd(const float* x, const float* w, int B, int Ci, int Co, int P, float* y, void* workspace,
+                        size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_conv1x1(B, Ci, Co, P, "conv1x1_fwd")) return rc;
+    if (!x || !w || !y) return fail(CABINET_ERR_INVALID_ARG, "conv1x1_fwd: null tensor pointer");
+    const size_t need = cabinet::conv1x1_fwd_workspace(Ci, Co);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "conv1x1_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::conv1x1_fwd_run(x, w, B, Ci, Co, P, y, workspace, static_cast<hipStream_t>(stream)),
+                      "conv1x1_fwd launch");
+}
+
+size_t cabinet_conv1x1_bwd_workspace_bytes(int B, int Ci, int Co, int P) {
+    return B > 0 && Ci > 0 && Co > 0 && P > 0 ? cabinet::conv1x1_bwd_workspace(B, Ci, Co, P) : 0;
+}
+
+int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P, float* dx,
+                        float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_conv1x1(B, Ci, Co, P, "conv1x1_bwd")) return rc;
+    if (!dy || !x || !w) return fail(CABINET_ERR_INVALID_ARG, "conv1x1_bwd: null tensor pointer");
+    const size_t need = cabinet::conv1x1_bwd_workspace(B, Ci, Co, P);
+    if (dw && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "conv1x1_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::conv1x1_bwd_run(dy, x, w, B, Ci, Co, P, dx, dw, workspace, static_cast<hipStream_t>(stream)),
+                      "conv1x1_bwd launch");
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 // contiguous (pixel or output-channel) index on the lane: G1/G2 are "K-major" products
 // (A_t[k][m], B[k][p]) that need no transposition at all; G3 contracts over pixels, so both
 // operands go through padded (stride 33) LDS images.
+#include "blocks.hpp"
 #include "common.hpp"
 
 namespace cabinet {
@@ -29,23 +30,6 @@ struct FfmShape {
 // =====================================================================================
 // G1 / G2:  D[m][p] = sum_k At[k][m] * Bm[k][p]   per image
 // =====================================================================================
-struct GemmKArgs {
-    const float* at;   // [K][lda], M (<= lda) contiguous entries per row (shared by all images)
-    int lda;
-    int M, K;
-    const float* src0; // B-operand rows k <  K0 : (B, K0, P)
-    const float* src1; // B-operand rows k >= K0 : (B, K-K0, P)
-    int K0;
-    float* dst0;       // output rows m <  M0 : (B, M0, P)
-    float* dst1;       // output rows m >= M0 : (B, M-M0, P)
-    int M0;
-    int P;
-    // optional epilogue term: D[m][p] += bilinear_upsample(up_src[b][m])(p), align_corners=False semantics
-    // of F.interpolate (reference cabinet.py:228-230); up_src: (B, M, Hl, Wl), output pixels p = oy*W + ox
-    const float* up_src;
-    int Hl, Wl, W;
-    float rh, rw;      // Hl / H, Wl / W
-};
 
 // one axis of F.interpolate(mode="bilinear", align_corners=False): source taps and weight of the upper tap
 __device__ __forceinline__ void bilinear_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
@@ -229,7 +213,7 @@ static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_kmajor_kernel<WM, INTERIOR>), grid, dim3(512), lds, stream, a);
 }
 
-static void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
+void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
     int wm = a.M <= 128 ? 1 : (a.M > 256 && a.M <= 384) ? 3 : 2;
     if (wm > 1 && (a.M % 128) == 0 && ceil_div(a.P, GK_NT) * B * ceil_div(a.M, 128 * wm) < 200) wm = 1;  // small grid
     const bool interior = (a.P % GK_NT) == 0 && (a.M % (128 * wm)) == 0 && (a.lda % 4) == 0;
@@ -525,6 +509,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
         running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
     }
+}
+
+void bn_rowstats(const float* z, float* stat_part, int B, int C, int P, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_rowstats_kernel, dim3(B * C), dim3(256), 0, stream, z, stat_part, B, C, P);
+}
+void bn_finalize(const float* stat_part, int ntiles, int C, int nch, long long count, int training, float momentum, float eps,
+                 float* running_mean, float* running_var, float* save_mean, float* save_invstd, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(nch), dim3(256), 0, stream, stat_part, ntiles, C, count, training,
+                       momentum, eps, running_mean, running_var, save_mean, save_invstd);
 }
 
 // pooled[b][c] = mean_p relu(bn(z[b][c][p]))        one workgroup per (b,c) row
@@ -938,8 +931,13 @@ static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const fl
                        bn_w, bn_b, a1, a2, mdy, mdyx, dz, s.Co, P, cpr);
 }
 
+size_t dw_part_floats(int B, int Co, int Cx, int P) {
+    const int total_chunks = B * ceil_div(P, G3_BK);
+    return (size_t)dw_nsplit(total_chunks, ceil_div(Co, G3_T) * ceil_div(Cx, G3_T)) * Co * Cx;
+}
+
 // dW[:, col_off : col_off+Cx] = sum over images and pixels of dzv (B,Co,P) x xs (B,Cx,P)^T
-static hipError_t dw_product(const float* dzv, const float* xs, int B, int Co, int Cx, int P, float* part,
+hipError_t dw_product(const float* dzv, const float* xs, int B, int Co, int Cx, int P, float* part,
                              float* dw_blk, int ldo, int col_off, hipStream_t stream) {
     const int chunks_per_img = ceil_div(P, G3_BK), total_chunks = B * chunks_per_img;
     const int nsplit = dw_nsplit(total_chunks, ceil_div(Co, G3_T) * ceil_div(Cx, G3_T));

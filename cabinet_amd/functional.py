@@ -438,3 +438,149 @@ def cab_local(x, refine, glob=None, gamma=None):
     return _CabLocal.apply(x, glob, gamma, *[c.weight for c in convs], *[bn.weight for bn in bns],
                            *[bn.bias for bn in bns], *[bn.running_mean for bn in bns],
                            *[bn.running_var for bn in bns], training, momentum, bns[0].eps)
+
+
+# --------------------------------------------------------------------------- q/k/v producers (K6) and 1x1 convolution
+
+
+def _sizes_arg(sizes):
+    return (_ct.c_int * len(sizes))(*[int(s) for s in sizes])
+
+
+def cab_qkv_supported(x, Kc, Vc, sizes):
+    if x.dim() != 4 or not 1 <= len(sizes) <= 4:
+        return False
+    B, C, H, W = x.shape
+    return bool(_lib.load().cabinet_cab_qkv_supported(B, C, Kc, Vc, H, W, len(sizes), _sizes_arg(sizes)))
+
+
+class _CabQkv(torch.autograd.Function):
+    """args: x, wq, wk, wv, bnq_w, bnq_b, bnk_w, bnk_b, wpk, wpv, bnq_rm, bnq_rv, bnk_rm, bnk_rv, sizes, training,
+    momentum, eps  ->  q (B,Kc,n), k (B,Kc,n), v (B,Vc,n)"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, wq, wk, wv, bnq_w, bnq_b, bnk_w, bnk_b, wpk, wpv, bnq_rm, bnq_rv, bnk_rm, bnk_rv, sizes,
+                training, momentum, eps):
+        lib = _lib.load()
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        Kc, Vc, n, ns = wq.shape[0], wv.shape[0], H * W, len(sizes)
+        shapes = (wq.shape, wk.shape, wv.shape, wpk.shape, wpv.shape)
+        wq2, wk2, wv2 = (_f32c(t).view(t.shape[0], C) for t in (wq, wk, wv))
+        wpk2, wpv2 = _f32c(wpk).view(Kc, (ns + 1) * Kc), _f32c(wpv).view(Vc, (ns + 1) * Vc)
+        bnq_w, bnq_b, bnk_w, bnk_b = _f32c(bnq_w), _f32c(bnq_b), _f32c(bnk_w), _f32c(bnk_b)
+        sz = _sizes_arg(sizes)
+        dims = (B, C, Kc, Vc, H, W, ns, sz)
+        nbp = lib.cabinet_cab_qkv_padded_bins(ns, sz)
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)  # noqa: E731
+        q, k, v = new(B, Kc, n), new(B, Kc, n), new(B, Vc, n)
+        zqk, vv, kk = new(B, 2 * Kc, n), new(B, Vc, n), new(B, Kc, n)
+        pooled_k, pooled_v = new(B, ns * Kc, nbp), new(B, ns * Vc, nbp)
+        mean, invstd = new(2 * Kc), new(2 * Kc)
+        ws, nbytes = _workspace(lib.cabinet_cab_qkv_fwd_workspace_bytes(*dims), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_cab_qkv_fwd(_ptr(x), _ptr(wq2), _ptr(wk2), _ptr(wv2), _ptr(bnq_w), _ptr(bnq_b), _ptr(bnq_rm),
+                                         _ptr(bnq_rv), _ptr(bnk_w), _ptr(bnk_b), _ptr(bnk_rm), _ptr(bnk_rv), _ptr(wpk2),
+                                         _ptr(wpv2), *dims, int(training), float(momentum), float(eps), _ptr(q),
+                                         _ptr(k), _ptr(v), _ptr(zqk), _ptr(vv), _ptr(kk), _ptr(pooled_k),
+                                         _ptr(pooled_v), _ptr(mean), _ptr(invstd), _ptr(ws), nbytes,
+                                         _stream_handle(x.device))
+        _lib.check(rc, "cabinet_cab_qkv_fwd")
+        fn_ctx.save_for_backward(x, wq2, wk2, wv2, bnq_w, bnq_b, bnk_w, bnk_b, wpk2, wpv2, zqk, vv, kk, pooled_k,
+                                 pooled_v, mean, invstd)
+        fn_ctx.sizes, fn_ctx.training, fn_ctx.shapes = tuple(sizes), bool(training), shapes
+        return q, k, v
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, dq, dk, dv):
+        lib = _lib.load()
+        (x, wq, wk, wv, bnq_w, bnq_b, bnk_w, bnk_b, wpk, wpv, zqk, vv, kk, pooled_k, pooled_v, mean,
+         invstd) = fn_ctx.saved_tensors
+        B, C, H, W = x.shape
+        Kc, Vc, ns = wq.shape[0], wv.shape[0], len(fn_ctx.sizes)
+        sz = _sizes_arg(fn_ctx.sizes)
+        dims = (B, C, Kc, Vc, H, W, ns, sz)
+        dq = _f32c(dq) if dq is not None else torch.zeros(B, Kc, H * W, device=x.device)
+        dk = _f32c(dk) if dk is not None else torch.zeros(B, Kc, H * W, device=x.device)
+        dv = _f32c(dv) if dv is not None else torch.zeros(B, Vc, H * W, device=x.device)
+        dx = torch.empty_like(x)
+        dwqk, dwv = torch.empty(2 * Kc, C, device=x.device), torch.empty(Vc, C, device=x.device)
+        dbn = [torch.empty(Kc, device=x.device) for _ in range(4)]
+        dwpk, dwpv = torch.empty_like(wpk), torch.empty_like(wpv)
+        ws, nbytes = _workspace(lib.cabinet_cab_qkv_bwd_workspace_bytes(*dims), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_cab_qkv_bwd(_ptr(dq), _ptr(dk), _ptr(dv), _ptr(x), _ptr(wq), _ptr(wk), _ptr(wv),
+                                         _ptr(bnq_w), _ptr(bnq_b), _ptr(bnk_w), _ptr(bnk_b), _ptr(wpk), _ptr(wpv),
+                                         _ptr(zqk), _ptr(vv), _ptr(kk), _ptr(pooled_k), _ptr(pooled_v), _ptr(mean),
+                                         _ptr(invstd), *dims, int(fn_ctx.training), _ptr(dx), _ptr(dwqk), _ptr(dwv),
+                                         _ptr(dbn[0]), _ptr(dbn[1]), _ptr(dbn[2]), _ptr(dbn[3]), _ptr(dwpk),
+                                         _ptr(dwpv), _ptr(ws), nbytes, _stream_handle(x.device))
+        _lib.check(rc, "cabinet_cab_qkv_bwd")
+        s_q, s_k, s_v, s_pk, s_pv = fn_ctx.shapes
+        return (dx, dwqk[:Kc].view(s_q), dwqk[Kc:].view(s_k), dwv.view(s_v), dbn[0], dbn[1], dbn[2], dbn[3],
+                dwpk.view(s_pk), dwpv.view(s_pv)) + (None,) * 8
+
+
+def cab_qkv(x, gca):
+    """q, k, v of GlobalContextAttention (reference cab.py:137-146) from its sub-modules, on device tensors.
+
+    ``gca`` owns to_query / to_key (Conv2d 1x1, BatchNorm2d, ReLU), to_value (Conv2d 1x1), psp_key / psp_value
+    (PSPModule); BatchNorm running buffers are updated in place in training mode."""
+    bn_q, bn_k = gca.to_query[1], gca.to_key[1]
+    sizes = [int(st.output_size[0]) for st in gca.psp_key.stages]
+    if sizes != [int(st.output_size[0]) for st in gca.psp_value.stages]:
+        raise RuntimeError("cab_qkv: psp_key and psp_value must use the same pyramid sizes")
+    if (bn_q.eps, bn_q.momentum, bn_q.training) != (bn_k.eps, bn_k.momentum, bn_k.training):
+        raise RuntimeError("cab_qkv: the two BatchNorm2d must share eps, momentum and training mode")
+    training, momentum = _bn_step(bn_q)
+    _bn_step(bn_k)
+    return _CabQkv.apply(x, gca.to_query[0].weight, gca.to_key[0].weight, gca.to_value.weight, bn_q.weight, bn_q.bias,
+                         bn_k.weight, bn_k.bias, gca.psp_key.project.weight, gca.psp_value.project.weight,
+                         bn_q.running_mean, bn_q.running_var, bn_k.running_mean, bn_k.running_var, sizes, training,
+                         momentum, bn_q.eps)
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, weight):
+        lib = _lib.load()
+        x = _f32c(x)
+        Co, Ci = weight.shape[0], weight.shape[1]
+        w2 = _f32c(weight).view(Co, Ci)
+        B, P = x.shape[0], x[0, 0].numel()
+        y = torch.empty((B, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        ws, nbytes = _workspace(lib.cabinet_conv1x1_fwd_workspace_bytes(Ci, Co), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_conv1x1_fwd(_ptr(x), _ptr(w2), B, Ci, Co, P, _ptr(y), _ptr(ws), nbytes,
+                                         _stream_handle(x.device))
+        _lib.check(rc, "cabinet_conv1x1_fwd")
+        fn_ctx.save_for_backward(x, w2)
+        fn_ctx.w_shape = weight.shape
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, w2 = fn_ctx.saved_tensors
+        g = _f32c(g)
+        Co, Ci = w2.shape
+        B, P = x.shape[0], x[0, 0].numel()
+        dx = torch.empty_like(x) if fn_ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w2) if fn_ctx.needs_input_grad[1] else None
+        ws, nbytes = _workspace(lib.cabinet_conv1x1_bwd_workspace_bytes(B, Ci, Co, P), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_conv1x1_bwd(_ptr(g), _ptr(x), _ptr(w2), B, Ci, Co, P, _ptr(dx), _ptr(dw), _ptr(ws), nbytes,
+                                         _stream_handle(x.device))
+        _lib.check(rc, "cabinet_conv1x1_bwd")
+        return dx, (dw.view(fn_ctx.w_shape) if dw is not None else None)
+
+
+def conv1x1(x, weight):
+    """Bias-free 1x1 convolution of a (B,Ci,...) device tensor with a (Co,Ci[,1,1]) weight (reference cab.py:155)."""
+    if not x.is_cuda:
+        raise RuntimeError("conv1x1: device tensors only")
+    return _Conv1x1.apply(x, weight)

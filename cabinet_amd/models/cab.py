@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import cab_attention, cab_local, cab_local_supported
+from ..functional import (cab_attention, cab_local, cab_local_supported, cab_qkv, cab_qkv_supported,
+                          conv1x1)
 
 
 def _conv_bn_relu_1x1(cin, cout):
@@ -69,11 +70,25 @@ class GlobalContextAttention(nn.Module):
         self.project_out = nn.Conv2d(value_channels, self.out_channels, kernel_size=1, bias=False)
         nn.init.constant_(self.project_out.weight, 0)  # reference cab.py:129
 
+    def _native_producers(self, xd):
+        wq, wv = self.to_query[0].weight, self.to_value.weight
+        sizes = [st.output_size[0] for st in self.psp_key.stages]
+        return (wq.shape[0] % 16 == 0 and self.project_out.weight.shape[0] % 16 == 0
+                and cab_qkv_supported(xd, wq.shape[0], wv.shape[0], sizes))
+
     def forward(self, x):
         b, _, h, w = x.shape
         xd = self.pool(x)
         hd, wd = xd.shape[2:]
         n = hd * wd
+        if xd.is_cuda and self._native_producers(xd):
+            # K6: projections, BatchNorm, ReLU and both pyramid poolings as a short chain of MFMA GEMMs and
+            # plane passes (no concat, no full-resolution pyramid maps), then K1/K2 and the output projection
+            q, k, v = cab_qkv(xd, self)
+            ctx = conv1x1(cab_attention(q, k, v, k.shape[1] ** -0.5).reshape(b, -1, hd, wd), self.project_out.weight)
+            if self.scale > 1:
+                ctx = F.interpolate(ctx, size=(h, w), mode="bilinear", align_corners=False)
+            return ctx
         # NCHW-flattened operands: q,k (B,Kc,n), v (B,Vc,n); the reference's transposes
         # (cab.py:138,146,154) only exist to feed torch.bmm and are not needed here
         q = self.to_query(xd).reshape(b, -1, n)

@@ -194,6 +194,61 @@ int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, 
                           float* const* ddw_w, float* const* dbn_weight, float* const* dbn_bias,
                           cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * q/k/v producers of the CAB global branch (1x1 projections + BatchNorm + ReLU + pyramid pooling).
+ * Replaces src/models/cab.py:137,141,145 with the modules of cab.py:107-123 and PSPModule.forward cab.py:65-76:
+ *   q = relu(bn_q(W_q x));  k = PSP_k(relu(bn_k(W_k x)));  v = PSP_v(W_v x)
+ *   PSP(u) = W_p . cat[u, U(A_s u) for s in sizes]   (A_s = AdaptiveAvgPool2d((s,s)), U = bilinear resize to
+ *   (H,W), align_corners=False); evaluated as W_p[:, :Kc] u + sum_s U(W_p[:, block s] A_s u), no concat.
+ *   x (B,C,H,W); wq, wk (Kc,C); wv (Vc,C)  [Conv2d 1x1 weights, no bias]; bn*_ (Kc);
+ *   wpk (Kc,(n_sizes+1)*Kc), wpv (Vc,(n_sizes+1)*Vc)  [PSP project weights, identity block first]
+ *   sizes: HOST array of n_sizes (1..4) pyramid sizes (each 1..16); C, Kc, Vc multiples of 16; H*W <= ~8192
+ *   outputs q, k (B,Kc,H*W), v (B,Vc,H*W) -- the NCHW-flattened operands cabinet_cab_attn_fwd takes
+ *   saved for backward (caller-allocated): zqk (B,2Kc,H*W), vv (B,Vc,H*W), kk (B,Kc,H*W),
+ *   pooled_k (B,n_sizes*Kc,NBp), pooled_v (B,n_sizes*Vc,NBp) with NBp = cabinet_cab_qkv_padded_bins(),
+ *   save_mean / save_invstd (2Kc) = [bn_q | bn_k]
+ *   BatchNorm semantics and running-stat updates as in cabinet_ffm_fwd (training flag, momentum, eps).
+ *   bwd: dq, dk (B,Kc,H*W), dv (B,Vc,H*W) -> dx, dwqk (2Kc,C) = [dW_q; dW_k], dwv, dbn*, dwpk, dwpv.
+ *   Deterministic (no atomics).
+ * ------------------------------------------------------------------------- */
+int cabinet_cab_qkv_supported(int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes);
+int cabinet_cab_qkv_padded_bins(int n_sizes, const int* sizes);
+size_t cabinet_cab_qkv_fwd_workspace_bytes(int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes);
+int cabinet_cab_qkv_fwd(const float* x, const float* wq, const float* wk, const float* wv,
+                        const float* bnq_weight, const float* bnq_bias, float* bnq_running_mean, float* bnq_running_var,
+                        const float* bnk_weight, const float* bnk_bias, float* bnk_running_mean, float* bnk_running_var,
+                        const float* wpk, const float* wpv,
+                        int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes,
+                        int training, float momentum, float eps,
+                        float* q, float* k, float* v,
+                        float* zqk, float* vv, float* kk, float* pooled_k, float* pooled_v,
+                        float* save_mean, float* save_invstd,
+                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+size_t cabinet_cab_qkv_bwd_workspace_bytes(int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes);
+int cabinet_cab_qkv_bwd(const float* dq, const float* dk, const float* dv, const float* x,
+                        const float* wq, const float* wk, const float* wv,
+                        const float* bnq_weight, const float* bnq_bias, const float* bnk_weight, const float* bnk_bias,
+                        const float* wpk, const float* wpv,
+                        const float* zqk, const float* vv, const float* kk, const float* pooled_k,
+                        const float* pooled_v, const float* save_mean, const float* save_invstd,
+                        int B, int C, int Kc, int Vc, int H, int W, int n_sizes, const int* sizes, int training,
+                        float* dx, float* dwqk, float* dwv,
+                        float* dbnq_weight, float* dbnq_bias, float* dbnk_weight, float* dbnk_bias,
+                        float* dwpk, float* dwpv,
+                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Bias-free 1x1 convolution, y (B,Co,P) = W (Co,Ci) . x (B,Ci,P), on the exact-fp32 MFMA GEMMs.
+ * Replaces src/models/cab.py:155 (project_out of the attention context).  Ci, Co multiples of 16.
+ * bwd: dx = W^T dy (skipped if dx == NULL), dw = sum_{b,p} dy (x) x (skipped if dw == NULL).
+ * ------------------------------------------------------------------------- */
+size_t cabinet_conv1x1_fwd_workspace_bytes(int Ci, int Co);
+int cabinet_conv1x1_fwd(const float* x, const float* w, int B, int Ci, int Co, int P, float* y,
+                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+size_t cabinet_conv1x1_bwd_workspace_bytes(int B, int Ci, int Co, int P);
+int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P,
+                        float* dx, float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

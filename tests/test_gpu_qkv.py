@@ -1,0 +1,122 @@
+"""HIP q/k/v producers (K6) and the 1x1 output projection (through the C ABI) vs the oracle.
+
+The golden CAB vectors (g2_cab.npz, from the reference) cover the same kernels end to end through
+ContextAggregationBlock (test_gpu_model.py::test_cab_module_golden).  Here the producer op is checked on its
+own against oracle/model_ref.py (_bn, _psp: the restatement of cab.py:107-123,46-76) in fp64, over shapes where
+the pooling bins overlap (H % s != 0), where there are more bins than pixels (s > H), non-square maps, generic
+channel counts, and both BatchNorm modes.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # north_star: 1e-3 relative (||a-b||/||b|| per tensor), fp32
+
+
+def _make(C, Kc, Vc, sizes, seed):
+    from cabinet_amd.models.cab import GlobalContextAttention
+
+    torch.manual_seed(seed)
+    m = GlobalContextAttention(C, Kc, Vc, C, scale=1, psp_sizes=sizes)
+    with torch.no_grad():
+        torch.nn.init.kaiming_normal_(m.project_out.weight)
+        for bn in (m.to_query[1], m.to_key[1]):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+            bn.running_mean.uniform_(-0.2, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+    return m
+
+
+def _oracle_qkv(m, x, grads, training, sizes):
+    from oracle.model_ref import Weights, _bn, _psp
+
+    w = Weights({k: v.clone() for k, v in m.state_dict().items()}, dtype=torch.float64)
+    xo = x.detach().cpu().double().requires_grad_(True)
+    b, _, h, wd = xo.shape
+    q = F.relu(_bn(w, F.conv2d(xo, w["to_query.0.weight"]), "to_query.1", training))
+    k = F.relu(_bn(w, F.conv2d(xo, w["to_key.0.weight"]), "to_key.1", training))
+    k = _psp(w, k, "psp_key", sizes)
+    v = _psp(w, F.conv2d(xo, w["to_value.weight"]), "psp_value", sizes)
+    q, k, v = (t.reshape(b, -1, h * wd) for t in (q, k, v))
+    torch.autograd.backward([q, k, v], [g.cpu().double() for g in grads])
+    return (q.detach(), k.detach(), v.detach()), xo.grad, w.grads(), w.buffers()
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("B,C,Kc,Vc,H,W,sizes", [
+    (2, 256, 128, 128, 16, 16, (1, 3, 6, 8)),   # golden-fixture shape
+    (8, 256, 128, 128, 32, 32, (1, 3, 6, 8)),   # config 3
+    (1, 64, 32, 48, 5, 7, (1, 3, 6, 8)),        # more bins than pixels, ragged, Kc != Vc
+    (2, 32, 16, 16, 8, 20, (2, 5)),             # overlapping bins, non-square, two sizes
+    (1, 512, 256, 128, 32, 64, (1, 3, 6, 8)),   # the reference's own test block (test_models.py:49): n = 2048
+])
+def test_qkv_vs_oracle(B, C, Kc, Vc, H, W, sizes, training):
+    from cabinet_amd.functional import cab_qkv
+
+    m = _make(C, Kc, Vc, sizes, 5).cuda()
+    m.train(training)
+    ref_m = _make(C, Kc, Vc, sizes, 5)
+    g0 = torch.Generator().manual_seed(9)
+    x = torch.randn(B, C, H, W, generator=g0).cuda().requires_grad_(True)
+    grads = [torch.randn(B, ch, H * W, generator=g0) for ch in (Kc, Kc, Vc)]
+    q, k, v = cab_qkv(x, m)
+    torch.autograd.backward([q, k, v], [g.cuda() for g in grads])
+    torch.cuda.synchronize()
+    (oq, ok, ov), o_dx, o_grads, o_buf = _oracle_qkv(ref_m, x, grads, training, sizes)
+    assert_close(q, oq, TOL, "q")
+    assert_close(k, ok, TOL, "k")
+    assert_close(v, ov, TOL, "v")
+    assert_close(x.grad, o_dx, TOL, "dx")
+    for name, p in m.named_parameters():
+        if name.startswith("project_out"):
+            continue
+        assert_close(p.grad, o_grads[name], TOL, f"grad {name}")
+    for name, b in m.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == int(o_buf[name]), name
+        else:
+            assert_close(b, o_buf[name], 1e-5, name)
+
+
+@pytest.mark.parametrize("B,Ci,Co,shape", [(2, 128, 256, (16, 16)), (8, 128, 256, (32, 32)), (1, 48, 16, (5, 7)),
+                                           (3, 16, 32, (1, 1))])
+def test_conv1x1_vs_oracle(B, Ci, Co, shape):
+    from cabinet_amd.functional import conv1x1
+
+    g0 = torch.Generator().manual_seed(2)
+    x = torch.randn(B, Ci, *shape, generator=g0)
+    w = torch.randn(Co, Ci, 1, 1, generator=g0)
+    g = torch.randn(B, Co, *shape, generator=g0)
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = conv1x1(xd, wd)
+    y.backward(g.cuda())
+    xo, wo = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yo = F.conv2d(xo, wo)  # reference cab.py:155
+    yo.backward(g.double())
+    assert_close(y, yo, TOL, "y")
+    assert_close(xd.grad, xo.grad, TOL, "dx")
+    assert_close(wd.grad, wo.grad, TOL, "dw")
+
+
+def test_global_branch_runs_native_kernels_and_is_deterministic():
+    from cabinet_amd import _lib
+
+    m = _make(256, 128, 128, (1, 3, 6, 8), 1).cuda().train()
+    x = torch.randn(2, 256, 16, 16, device="cuda", requires_grad=True)
+    g = torch.randn_like(x)
+    runs = []
+    for _ in range(2):
+        m.zero_grad()
+        x.grad = None
+        m(x).backward(g)
+        runs.append([x.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)  # no atomics on the whole global branch
+    lib = _lib.load()
+    sizes = (torch.tensor([1, 3, 6, 8], dtype=torch.int32)).numpy()
+    assert lib.cabinet_cab_qkv_supported(8, 256, 128, 128, 32, 32, 4, sizes.ctypes.data) == 1
+    assert lib.cabinet_cab_qkv_supported(8, 250, 128, 128, 32, 32, 4, sizes.ctypes.data) == 0  # C % 16 != 0
