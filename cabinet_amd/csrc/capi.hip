@@ -51,6 +51,14 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
                        const float* pooled, const float* gate, int training, float* dfsp, float* dfcp,
                        float* dw_blk, float* dbn_w, float* dbn_b, float* dw1, float* dw2, void* ws,
                        hipStream_t stream);
+// bn_act.hip
+size_t bn_act_workspace(int B, int C, int P);
+hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias, float* running_mean,
+                          float* running_var, int B, int C, int P, int act, int training, float momentum, float eps,
+                          float* y, float* save_mean, float* save_invstd, void* ws, hipStream_t stream);
+hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, const float* bias,
+                          const float* save_mean, const float* save_invstd, int B, int C, int P, int act, int training,
+                          float* dx, float* dweight, float* dbias, void* ws, hipStream_t stream);
 // ohem.hip
 int ohem_blocks(int B, int H, int W);
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
@@ -491,6 +499,49 @@ int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, 
         return fail(CABINET_ERR_WORKSPACE, "conv1x1_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     return hip_status(cabinet::conv1x1_bwd_run(dy, x, w, B, Ci, Co, P, dx, dw, workspace, static_cast<hipStream_t>(stream)),
                       "conv1x1_bwd launch");
+}
+
+// ------------------------------------------------------ BatchNorm2d + activation
+static int check_bn_act(int B, int C, int P, int act, const char* who) {
+    if (B <= 0 || C <= 0 || P <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if (act < 0 || act > 2) return fail(CABINET_ERR_INVALID_ARG, "%s: act=%d (0 none, 1 relu, 2 hardswish)", who, act);
+    if ((long long)B * C * ((P + 8191) / 8192) > 2147483647LL)
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: grid too large", who);
+    return CABINET_OK;
+}
+
+size_t cabinet_bn_act_workspace_bytes(int B, int C, int P) {
+    return B > 0 && C > 0 && P > 0 ? cabinet::bn_act_workspace(B, C, P) : 0;
+}
+
+int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                       int B, int C, int P, int act, int training, float momentum, float eps, float* y,
+                       float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                       cabinet_stream_t stream) {
+    if (int rc = check_bn_act(B, C, P, act, "bn_act_fwd")) return rc;
+    if (!x || !weight || !bias || !running_mean || !running_var || !y || !save_mean || !save_invstd)
+        return fail(CABINET_ERR_INVALID_ARG, "bn_act_fwd: null tensor pointer");
+    const size_t need = cabinet::bn_act_workspace(B, C, P);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "bn_act_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::bn_act_fwd_run(x, weight, bias, running_mean, running_var, B, C, P, act, training,
+                                              momentum, eps, y, save_mean, save_invstd, workspace,
+                                              static_cast<hipStream_t>(stream)),
+                      "bn_act_fwd launch");
+}
+
+int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, const float* bias, const float* save_mean,
+                       const float* save_invstd, int B, int C, int P, int act, int training, float* dx, float* dweight,
+                       float* dbias, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_bn_act(B, C, P, act, "bn_act_bwd")) return rc;
+    if (!dy || !x || !weight || !bias || !save_mean || !save_invstd || !dx || !dweight || !dbias)
+        return fail(CABINET_ERR_INVALID_ARG, "bn_act_bwd: null tensor pointer");
+    const size_t need = cabinet::bn_act_workspace(B, C, P);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "bn_act_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::bn_act_bwd_run(dy, x, weight, bias, save_mean, save_invstd, B, C, P, act, training, dx,
+                                              dweight, dbias, workspace, static_cast<hipStream_t>(stream)),
+                      "bn_act_bwd launch");
 }
 
 }  // extern "C"

@@ -584,3 +584,60 @@ def conv1x1(x, weight):
     if not x.is_cuda:
         raise RuntimeError("conv1x1: device tensors only")
     return _Conv1x1.apply(x, weight)
+
+
+# --------------------------------------------------------------------------- BatchNorm2d + activation (K7)
+
+_ACT_CODES = {None: 0, "none": 0, "relu": 1, "hardswish": 2}
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, weight, bias, run_mean, run_var, act, training, momentum, eps):
+        lib = _lib.load()
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        B, C = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws, nbytes = _workspace(lib.cabinet_bn_act_workspace_bytes(B, C, P), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_bn_act_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(run_mean), _ptr(run_var), B, C, P, act,
+                                        int(training), float(momentum), float(eps), _ptr(y), _ptr(mean), _ptr(invstd),
+                                        _ptr(ws), nbytes, _stream_handle(x.device))
+        _lib.check(rc, "cabinet_bn_act_fwd")
+        fn_ctx.save_for_backward(x, weight, bias, mean, invstd)
+        fn_ctx.act, fn_ctx.training = act, bool(training)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, weight, bias, mean, invstd = fn_ctx.saved_tensors
+        g = _f32c(g)
+        B, C = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        dx, dw, db = torch.empty_like(x), torch.empty_like(weight), torch.empty_like(bias)
+        ws, nbytes = _workspace(lib.cabinet_bn_act_workspace_bytes(B, C, P), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_bn_act_bwd(_ptr(g), _ptr(x), _ptr(weight), _ptr(bias), _ptr(mean), _ptr(invstd), B, C, P,
+                                        fn_ctx.act, int(fn_ctx.training), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
+                                        nbytes, _stream_handle(x.device))
+        _lib.check(rc, "cabinet_bn_act_bwd")
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def bn_act(x, bn, act=None):
+    """act(bn(x)) for a device tensor; ``bn`` is the nn.BatchNorm2d owning parameters and running buffers
+    (updated in place in training mode), ``act`` one of None / "relu" / "hardswish"
+    (reference cabinet.py:42-44, mobilenetv3.py:86-99)."""
+    if not x.is_cuda:
+        raise RuntimeError("bn_act: device tensors only (host tensors take the composite ATen path)")
+    if act not in _ACT_CODES:
+        raise RuntimeError(f"bn_act: unknown activation {act!r}")
+    training, momentum = _bn_step(bn)
+    return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _ACT_CODES[act], training, momentum,
+                        bn.eps)

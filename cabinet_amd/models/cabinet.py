@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import ffm_fused, ffm_fused_upsampled
+from ..functional import bn_act, ffm_fused, ffm_fused_upsampled
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -43,7 +43,10 @@ class ConvBNReLU(nn.Module):
         self.init_weight()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.relu(self.bn(self.conv(x)))
+        x = self.conv(x)
+        if x.is_cuda:  # K7: BatchNorm + ReLU in one streaming pass pair instead of two library launches
+            return bn_act(x, self.bn, "relu")
+        return self.relu(self.bn(x))
 
     def init_weight(self) -> None:
         nn.init.kaiming_normal_(self.conv.weight, a=1)
@@ -67,6 +70,10 @@ class AttentionBranch(nn.Module):
         self.init_weight()
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        if x.is_cuda:
+            feat = self.a2block(bn_act(self.conva[0](x), self.conva[1], "relu"))
+            low_res_out = self.convb(feat)
+            return low_res_out, self.b4(bn_act(self.b1(torch.cat([x, feat], dim=1)), self.b2, "relu"))
         feat = self.a2block(self.conva(x))
         low_res_out = self.convb(feat)
         high_res_out = self.b4(self.b3(self.b2(self.b1(torch.cat([x, feat], dim=1)))))

@@ -1,10 +1,13 @@
 """MobileNetV3 backbone -- mirror of reference ``src/models/mobilenetv3.py``.
 
-Out of the hot path (BASELINE.json north_star keeps the backbone on stock
+Out of the hot path (BASELINE.json north_star keeps the backbone's convolutions on stock
 PyTorch-ROCm / MIOpen); it exists so that ``CABiNet`` is a drop-in with identical
 ``state_dict`` keys and an identical random-initialisation stream.  Layer order inside
 every ``nn.Sequential`` and the order in which sub-modules are constructed therefore
-follow the reference exactly (reference mobilenetv3.py:102-198).
+follow the reference exactly (reference mobilenetv3.py:102-198).  The one thing that is
+not stock: on device tensors every BatchNorm2d (+ ReLU / HardSwish) runs through the fused
+streaming kernel written for ConvBNReLU (:func:`cabinet_amd.functional.bn_act`), because it
+is the same operator and costs the step 13 ms when left to the library.
 """
 
 from __future__ import annotations
@@ -68,12 +71,38 @@ def _act(use_hs):
     return HardSwish() if use_hs else nn.ReLU(inplace=True)
 
 
+class _FusedSequential(nn.Sequential):
+    """nn.Sequential (same children, same state_dict keys) that, on device tensors, runs every
+    BatchNorm2d -> ReLU / HardSwish pair -- and every lone BatchNorm2d -- through the fused HIP op."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        from ..functional import bn_act
+
+        layers = list(self)
+        i = 0
+        while i < len(layers):
+            m = layers[i]
+            if isinstance(m, nn.BatchNorm2d):
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                if isinstance(nxt, nn.ReLU):
+                    x, i = bn_act(x, m, "relu"), i + 2
+                elif isinstance(nxt, HardSwish):
+                    x, i = bn_act(x, m, "hardswish"), i + 2
+                else:
+                    x, i = bn_act(x, m, None), i + 1
+            else:
+                x, i = m(x), i + 1
+        return x
+
+
 def conv_3x3_bn(inp, oup, stride):
-    return nn.Sequential(nn.Conv2d(inp, oup, 3, stride, 1, bias=False), nn.BatchNorm2d(oup), HardSwish())
+    return _FusedSequential(nn.Conv2d(inp, oup, 3, stride, 1, bias=False), nn.BatchNorm2d(oup), HardSwish())
 
 
 def conv_1x1_bn(inp, oup):
-    return nn.Sequential(nn.Conv2d(inp, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup), HardSwish())
+    return _FusedSequential(nn.Conv2d(inp, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup), HardSwish())
 
 
 class InvertedResidual(nn.Module):
@@ -98,7 +127,7 @@ class InvertedResidual(nn.Module):
             layers += [depthwise(), nn.BatchNorm2d(hidden_dim)]
             layers += [SELayer(hidden_dim) if use_se else nn.Identity(), _act(use_hs)]
         layers += [nn.Conv2d(hidden_dim, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup)]
-        self.conv = nn.Sequential(*layers)
+        self.conv = _FusedSequential(*layers)
 
     def forward(self, x):
         y = self.conv(x)

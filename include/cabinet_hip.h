@@ -249,6 +249,31 @@ size_t cabinet_conv1x1_bwd_workspace_bytes(int B, int Ci, int Co, int P);
 int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P,
                         float* dx, float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * BatchNorm2d fused with the activation that follows it (NCHW fp32, P = H*W).
+ * Replaces the bn -> relu tail of ConvBNReLU.forward, src/models/cabinet.py:42-44, and the same
+ * BatchNorm2d -> ReLU / HardSwish pairs at cabinet.py:59-63,67-68 and src/models/mobilenetv3.py:86-99,118-152
+ * (HardSwish: x * relu6(x + 3) / 6, mobilenetv3.py:48-50,63-65).
+ *   act: 0 = none, 1 = ReLU, 2 = HardSwish.   y = act(weight * xhat + bias), xhat = (x - mean) * invstd
+ *   training != 0: batch statistics (biased variance; unbiased into running_var; running buffers updated with
+ *   `momentum`), save_mean / save_invstd (C) receive them; training == 0: running statistics.
+ *   bwd needs only x, save_mean, save_invstd (the pre-activation is recomputed):
+ *     du = dy * act'(u);  dweight = sum du * xhat;  dbias = sum du;
+ *     dx = weight * invstd * (du - mean(du) - xhat * mean(du * xhat))   (training)   or  weight * invstd * du  (eval)
+ *   Deterministic (no atomics).  One workspace size serves both directions.
+ * ------------------------------------------------------------------------- */
+size_t cabinet_bn_act_workspace_bytes(int B, int C, int P);
+int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias,
+                       float* running_mean, float* running_var,
+                       int B, int C, int P, int act, int training, float momentum, float eps,
+                       float* y, float* save_mean, float* save_invstd,
+                       void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, const float* bias,
+                       const float* save_mean, const float* save_invstd,
+                       int B, int C, int P, int act, int training,
+                       float* dx, float* dweight, float* dbias,
+                       void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""HIP BatchNorm2d + activation (K7, through the C ABI) vs the oracle (fp64 F.batch_norm + activation, the
+restatement used by oracle/model_ref.py::_bn, _hswish) -- ragged planes, planes longer than one chunk, all three
+activations, both BatchNorm modes, running-buffer side effects."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # north_star: 1e-3 relative (||a-b||/||b|| per tensor), fp32
+
+
+def _oracle(x, g, bn, act, training):
+    from oracle.model_ref import _hswish
+
+    xo = x.detach().cpu().double().requires_grad_(True)
+    w = bn.weight.detach().cpu().double().requires_grad_(True)
+    b = bn.bias.detach().cpu().double().requires_grad_(True)
+    rm, rv = bn.running_mean.detach().cpu().double().clone(), bn.running_var.detach().cpu().double().clone()
+    u = F.batch_norm(xo, rm, rv, w, b, training, 0.1, 1e-5)
+    y = {"relu": F.relu, "hardswish": _hswish, None: lambda t: t}[act](u)
+    y.backward(g.cpu().double())
+    return y.detach(), xo.grad, w.grad, b.grad, rm, rv
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act", [None, "relu", "hardswish"])
+@pytest.mark.parametrize("shape", [(4, 16, 128, 128), (2, 5, 7, 9), (1, 3, 100, 100), (3, 8, 1, 1), (2, 24, 90, 91)])
+def test_bn_act_vs_oracle(shape, act, training):
+    from cabinet_amd.functional import bn_act
+
+    g0 = torch.Generator().manual_seed(4)
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g0) + 0.5)
+        bn.bias.copy_(torch.rand(C, generator=g0) - 0.5)
+        bn.running_mean.copy_(torch.rand(C, generator=g0) - 0.5)
+        bn.running_var.copy_(torch.rand(C, generator=g0) + 0.5)
+    x = torch.randn(*shape, generator=g0) * 1.7 + 0.6  # non-zero mean: exercises the variance computation
+    g = torch.randn(*shape, generator=g0)
+    if shape[0] * shape[2] * shape[3] == 1 and training:
+        pytest.skip("batch statistics of a single value are undefined")
+    ref = _oracle(x, g, bn, act, training)
+    bn = bn.cuda().train(training)
+    xd = x.cuda().requires_grad_(True)
+    y = bn_act(xd, bn, act)
+    y.backward(g.cuda())
+    torch.cuda.synchronize()
+    assert_close(y, ref[0], TOL, "y")
+    assert_close(xd.grad, ref[1], TOL, "dx")
+    assert_close(bn.weight.grad, ref[2], TOL, "dweight")
+    assert_close(bn.bias.grad, ref[3], TOL, "dbias")
+    assert_close(bn.running_mean, ref[4], 1e-5, "running_mean")
+    assert_close(bn.running_var, ref[5], 1e-5, "running_var")
+    assert int(bn.num_batches_tracked) == int(training)
+
+
+def test_bn_act_matches_stock_modules_and_is_deterministic():
+    """The fused sequential of the backbone equals the stock nn.Sequential on the same device."""
+    from cabinet_amd.models.mobilenetv3 import InvertedResidual
+
+    torch.manual_seed(0)
+    blk = InvertedResidual(16, 64, 24, 3, 2, True, True).cuda().train()
+    x = torch.randn(2, 16, 40, 40, device="cuda", requires_grad=True)
+    g = torch.randn(2, 24, 20, 20, device="cuda")
+    import copy
+
+    ref = copy.deepcopy(blk)
+    out = blk(x)
+    out.backward(g)
+    gx = x.grad.clone()
+    x.grad = None
+    out_ref = torch.nn.Sequential.forward(ref.conv, x)  # stock ATen / MIOpen path
+    out_ref.backward(g)
+    assert_close(out, out_ref, 1e-4, "block output")
+    assert_close(gx, x.grad, 1e-3, "block dx")
+    for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, 2e-3, k, atol=1e-5)
+    for (k, p), (_, q) in zip(blk.named_buffers(), ref.named_buffers()):
+        assert_close(p.double(), q.double(), 1e-5, k)
+    bn = torch.nn.BatchNorm2d(16).cuda().train()
+    from cabinet_amd.functional import bn_act
+
+    runs = []
+    for _ in range(2):
+        bn.zero_grad()
+        x.grad = None
+        bn_act(x, bn, "hardswish").backward(torch.ones(2, 16, 40, 40, device="cuda"))
+        runs.append((x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*runs))  # fixed reduction order, no atomics
