@@ -187,6 +187,59 @@ def kernel_rooflines(batch, size, iters):
     fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
     by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))
     entry("ffm_up_bwd (K4': reduce, dz, dfsp GEMM, U^T dz, low-res GEMMs, dW)", ms, fl_b, by_b, "hbm")
+    del fsp, fcp, dout, o, z, low
+    torch.cuda.empty_cache()
+
+    # ---- K7: BatchNorm + activation at the largest plane of the model (sb.conv1 / features.2: 64 x size/2 x size/2);
+    # algorithmic bytes = the passes a training-mode BatchNorm cannot avoid: fwd read x twice + write y,
+    # bwd read dy and x twice + write dx
+    Cb, hb = 64, size // 2
+    xb = torch.randn(B, Cb, hb, hb, generator=g).to(dev)
+    gb = torch.randn(B, Cb, hb, hb, generator=g).to(dev)
+    bnw, bnb = torch.ones(Cb, device=dev), torch.zeros(Cb, device=dev)
+    brm, brv = torch.zeros(Cb, device=dev), torch.ones(Cb, device=dev)
+    fwd = lambda: Fh._BnAct.apply(xb, bnw, bnb, brm, brv, 2, True, 0.1, 1e-5)  # noqa: E731
+    ms = time_kernel(fwd, iters)
+    nbytes = 4.0 * xb.numel()
+    entry("bn_act_fwd (K7: BatchNorm + HardSwish, stats + apply)", ms, 12.0 * xb.numel(), 3 * nbytes, "hbm")
+    xg = xb.clone().requires_grad_(True)
+    yb = Fh._BnAct.apply(xg, bnw, bnb, brm, brv, 2, True, 0.1, 1e-5)
+    ms = time_kernel(lambda: torch.autograd.grad(yb, xg, gb, retain_graph=True), iters)
+    entry("bn_act_bwd (K7: reduce + dx, pre-activation recomputed)", ms, 30.0 * xb.numel(), 5 * nbytes, "hbm")
+    del xb, gb, xg, yb
+    torch.cuda.empty_cache()
+
+    # ---- f3: OHEM-CE fused with the final x8 upsample (per head)
+    ncls = 8
+    lowl = torch.randn(B, ncls, size // 8, size // 8, generator=g).to(dev)
+    lab = torch.randint(0, ncls, (B, size, size), generator=g).to(dev)
+    ms = time_kernel(lambda: Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255), iters)
+    px = float(B * size * size)
+    entry("ohem_up_fwd (f3: upsample + CE + OHEM partials)", ms, px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
+    loss_px = Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255)[0]
+    ms = time_kernel(lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (size, size), 0.7, 255, 1e-6), iters)
+    entry("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)", ms, px * ncls * 16,
+          px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * size * (size // 8), "hbm")
+
+    # ---- K5 / K6: the rest of the Context Aggregation Block at (B, 256, size/32, size/32)
+    from cabinet_amd.models.cab import ContextAggregationBlock
+
+    cab = ContextAggregationBlock(256, 128).to(dev).train()
+    xc = torch.randn(B, 256, size // 32, size // 32, generator=g).to(dev).requires_grad_(True)
+    gc = torch.randn(B, 256, size // 32, size // 32, generator=g).to(dev)
+    elems = float(xc.numel())
+    yl = cab.local_attn(xc)
+    ms = time_kernel(lambda: cab.local_attn(xc.detach()), iters)
+    entry("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", ms, elems * 3 * 22, 8.0 * elems, "hbm")
+    ms = time_kernel(lambda: torch.autograd.grad(yl, xc, gc, retain_graph=True), iters)
+    entry("cab_local_bwd (K5: chain recomputed in LDS)", ms, elems * 3 * 60, 12.0 * elems, "hbm")
+    q3 = Fh.cab_qkv(xc, cab.global_attn)
+    gq = [torch.randn_like(t) for t in q3]
+    ms = time_kernel(lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), iters)
+    fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
+    entry("cab_qkv_fwd (K6: projections + BN + PSP, 11 launches)", ms, fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
+    ms = time_kernel(lambda: torch.autograd.grad(q3, xc, gq, retain_graph=True), iters)
+    entry("cab_qkv_bwd (K6: adjoint chain, ~20 launches)", ms, 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
     return out
 
 
