@@ -59,6 +59,13 @@ hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias
 hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, const float* bias,
                           const float* save_mean, const float* save_invstd, int B, int C, int P, int act, int training,
                           float* dx, float* dweight, float* dbias, void* ws, hipStream_t stream);
+// dwconv.hip
+bool dwconv_supported(int K, int S);
+size_t dwconv_bwd_workspace(int B, int C, int H, int W, int K);
+hipError_t dwconv_fwd_run(const float* x, const float* w, int B, int C, int H, int W, int K, int S, float* y,
+                          hipStream_t stream);
+hipError_t dwconv_bwd_run(const float* dy, const float* x, const float* w, int B, int C, int H, int W, int K, int S,
+                          float* dx, float* dw, void* ws, hipStream_t stream);
 // ohem.hip
 int ohem_blocks(int B, int H, int W);
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
@@ -542,6 +549,44 @@ int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, con
     return hip_status(cabinet::bn_act_bwd_run(dy, x, weight, bias, save_mean, save_invstd, B, C, P, act, training, dx,
                                               dweight, dbias, workspace, static_cast<hipStream_t>(stream)),
                       "bn_act_bwd launch");
+}
+
+// ------------------------------------------------------ depthwise convolution
+static int check_dwconv(int B, int C, int H, int W, int K, int S, const char* who) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if (!cabinet::dwconv_supported(K, S))
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: kernel %d stride %d (kernel 3|5, stride 1|2)", who, K, S);
+    if ((long long)B * C * ((H + 15) / 16) * ((W + 7) / 8) > 2147483647LL)
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: grid too large", who);
+    return CABINET_OK;
+}
+
+int cabinet_dwconv_supported(int K, int stride) { return cabinet::dwconv_supported(K, stride) ? 1 : 0; }
+
+int cabinet_dwconv_fwd(const float* x, const float* weight, int B, int C, int H, int W, int K, int stride, float* y,
+                       cabinet_stream_t stream) {
+    if (int rc = check_dwconv(B, C, H, W, K, stride, "dwconv_fwd")) return rc;
+    if (!x || !weight || !y) return fail(CABINET_ERR_INVALID_ARG, "dwconv_fwd: null tensor pointer");
+    return hip_status(cabinet::dwconv_fwd_run(x, weight, B, C, H, W, K, stride, y, static_cast<hipStream_t>(stream)),
+                      "dwconv_fwd launch");
+}
+
+size_t cabinet_dwconv_bwd_workspace_bytes(int B, int C, int H, int W, int K, int stride) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !cabinet::dwconv_supported(K, stride)) return 0;
+    return cabinet::dwconv_bwd_workspace(B, C, H, W, K);
+}
+
+int cabinet_dwconv_bwd(const float* dy, const float* x, const float* weight, int B, int C, int H, int W, int K,
+                       int stride, float* dx, float* dw, void* workspace, size_t workspace_bytes,
+                       cabinet_stream_t stream) {
+    if (int rc = check_dwconv(B, C, H, W, K, stride, "dwconv_bwd")) return rc;
+    if (!dy || !x || !weight || !dx || !dw) return fail(CABINET_ERR_INVALID_ARG, "dwconv_bwd: null tensor pointer");
+    const size_t need = cabinet::dwconv_bwd_workspace(B, C, H, W, K);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "dwconv_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::dwconv_bwd_run(dy, x, weight, B, C, H, W, K, stride, dx, dw, workspace,
+                                              static_cast<hipStream_t>(stream)),
+                      "dwconv_bwd launch");
 }
 
 }  // extern "C"

@@ -641,3 +641,55 @@ def bn_act(x, bn, act=None):
     training, momentum = _bn_step(bn)
     return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _ACT_CODES[act], training, momentum,
                         bn.eps)
+
+
+# --------------------------------------------------------------------------- depthwise convolution (K8)
+
+
+def dwconv_supported(conv):
+    """True for the depthwise nn.Conv2d shapes the HIP kernels cover (reference mobilenetv3.py:118-126)."""
+    k, s = conv.kernel_size, conv.stride
+    return (conv.groups == conv.in_channels == conv.out_channels and conv.bias is None and k[0] == k[1]
+            and s[0] == s[1] and conv.padding == (k[0] // 2, k[0] // 2) and conv.dilation == (1, 1)
+            and conv.padding_mode == "zeros" and k[0] in (3, 5) and s[0] in (1, 2))
+
+
+class _DwConv(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, weight, stride):
+        lib = _lib.load()
+        x, w = _f32c(x), _f32c(weight)
+        B, C, H, W = x.shape
+        K = w.shape[-1]
+        Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_dwconv_fwd(_ptr(x), _ptr(w), B, C, H, W, K, stride, _ptr(y), _stream_handle(x.device))
+        _lib.check(rc, "cabinet_dwconv_fwd")
+        fn_ctx.save_for_backward(x, w)
+        fn_ctx.stride = stride
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, w = fn_ctx.saved_tensors
+        g = _f32c(g)
+        B, C, H, W = x.shape
+        K, stride = w.shape[-1], fn_ctx.stride
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        ws, nbytes = _workspace(lib.cabinet_dwconv_bwd_workspace_bytes(B, C, H, W, K, stride), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_dwconv_bwd(_ptr(g), _ptr(x), _ptr(w), B, C, H, W, K, stride, _ptr(dx), _ptr(dw), _ptr(ws),
+                                        nbytes, _stream_handle(x.device))
+        _lib.check(rc, "cabinet_dwconv_bwd")
+        return dx, dw, None
+
+
+def dwconv(x, conv):
+    """Depthwise convolution of a device tensor with the weights of ``conv`` (an nn.Conv2d, see dwconv_supported)."""
+    if not x.is_cuda:
+        raise RuntimeError("dwconv: device tensors only")
+    return _DwConv.apply(x, conv.weight, conv.stride[0])

@@ -73,12 +73,13 @@ def _act(use_hs):
 
 class _FusedSequential(nn.Sequential):
     """nn.Sequential (same children, same state_dict keys) that, on device tensors, runs every
-    BatchNorm2d -> ReLU / HardSwish pair -- and every lone BatchNorm2d -- through the fused HIP op."""
+    BatchNorm2d -> ReLU / HardSwish pair -- and every lone BatchNorm2d -- through the fused HIP op, and the
+    depthwise convolutions through the HIP stencil kernels."""
 
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        from ..functional import bn_act
+        from ..functional import bn_act, dwconv, dwconv_supported
 
         layers = list(self)
         i = 0
@@ -92,6 +93,8 @@ class _FusedSequential(nn.Sequential):
                     x, i = bn_act(x, m, "hardswish"), i + 2
                 else:
                     x, i = bn_act(x, m, None), i + 1
+            elif isinstance(m, nn.Conv2d) and m.groups > 1 and dwconv_supported(m):
+                x, i = dwconv(x, m), i + 1  # depthwise stencil kernel (MIOpen only has its naive solver here)
             else:
                 x, i = m(x), i + 1
         return x

@@ -274,6 +274,21 @@ int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, con
                        float* dx, float* dweight, float* dbias,
                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Depthwise KxK convolution (groups == channels, no bias, dilation 1, padding K/2), NCHW fp32.
+ * Replaces the depthwise nn.Conv2d of the MBConv blocks, src/models/mobilenetv3.py:118-126,135-143
+ * (K in {3,5}, stride in {1,2}); weight is the Conv2d weight (C,1,K,K).
+ *   fwd : y (B,C,Ho,Wo), Ho = (H + 2*(K/2) - K)/stride + 1
+ *   bwd : dx (B,C,H,W) and dw (C,1,K,K) from dy, x, weight in one pass over dy; deterministic (no atomics)
+ * ------------------------------------------------------------------------- */
+int cabinet_dwconv_supported(int K, int stride);
+int cabinet_dwconv_fwd(const float* x, const float* weight, int B, int C, int H, int W, int K, int stride,
+                       float* y, cabinet_stream_t stream);
+size_t cabinet_dwconv_bwd_workspace_bytes(int B, int C, int H, int W, int K, int stride);
+int cabinet_dwconv_bwd(const float* dy, const float* x, const float* weight, int B, int C, int H, int W, int K,
+                       int stride, float* dx, float* dw, void* workspace, size_t workspace_bytes,
+                       cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
