@@ -579,12 +579,20 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
 }
 
 // ------------------------------------------------------------------------------- plain 1x1 convolution (no bias)
-size_t conv1x1_fwd_workspace(int Ci, int Co) { return fbytes((size_t)Ci * Co); }
-size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P) { return fbytes(dw_part_floats(B, Co, Ci, P)); }
+static int k16(int k) { return (k + 15) & ~15; }
+
+size_t conv1x1_fwd_workspace(int Ci, int Co) { return fbytes((size_t)k16(Ci) * Co); }
+size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P) {
+    return fbytes(dw_part_floats(B, Co, Ci, P)) + ((Co & 15) ? fbytes((size_t)k16(Co) * Ci) : 0);
+}
 
 hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int Co, int P, float* y, void* ws,
                            hipStream_t stream) {
-    float* wt = static_cast<float*>(ws);
+    float* wt = static_cast<float*>(ws);  // W^T, [align16(Ci)][Co], zero rows past Ci (K tail of the GEMM)
+    if (Ci & 15) {
+        hipError_t e = hipMemsetAsync(wt + (size_t)Ci * Co, 0, (size_t)(k16(Ci) - Ci) * Co * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+    }
     TrJobs jobs{};
     jobs.j[0] = {wgt, wt, Ci, Co, Ci, Co, 0, 0};
     stage_weights(jobs, 1, stream);
@@ -599,15 +607,26 @@ hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int 
 
 hipError_t conv1x1_bwd_run(const float* dy, const float* x, const float* wgt, int B, int Ci, int Co, int P, float* dx,
                            float* dw, void* ws, hipStream_t stream) {
-    if (dx) {  // dx = W^T dy: the (Co x Ci) weight is already the K-major A operand
+    float* part = static_cast<float*>(ws);
+    if (dx) {  // dx = W^T dy: the (Co x Ci) weight is already the K-major A operand (padded copy if Co % 16 != 0)
+        const float* at = wgt;
+        if (Co & 15) {
+            float* wpad = reinterpret_cast<float*>(static_cast<char*>(ws) + fbytes(dw_part_floats(B, Co, Ci, P)));
+            hipError_t e = hipMemsetAsync(wpad + (size_t)Co * Ci, 0, (size_t)(k16(Co) - Co) * Ci * sizeof(float), stream);
+            if (e != hipSuccess) return e;
+            TrJobs jobs{};
+            jobs.j[0] = {wgt, wpad, Ci, Co, Ci, Ci, 0, 1};
+            stage_weights(jobs, 1, stream);
+            at = wpad;
+        }
         GemmKArgs a{};
-        a.at = wgt, a.lda = Ci, a.M = Ci, a.K = Co;
+        a.at = at, a.lda = Ci, a.M = Ci, a.K = Co;
         a.src0 = a.src1 = dy, a.K0 = Co;
         a.dst0 = a.dst1 = dx, a.M0 = Ci;
         a.P = P;
         gemm_kmajor(a, B, stream);
     }
-    if (dw) return dw_product(dy, x, B, Co, Ci, P, static_cast<float*>(ws), dw, Ci, 0, stream);
+    if (dw) return dw_product(dy, x, B, Co, Ci, P, part, dw, Ci, 0, stream);
     return hipGetLastError();
 }
 

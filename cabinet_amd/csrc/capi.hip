@@ -472,8 +472,8 @@ int cabinet_cab_qkv_bwd(const float* dq, const float* dk, const float* dv, const
 // ------------------------------------------------------ bias-free 1x1 convolution
 static int check_conv1x1(int B, int Ci, int Co, int P, const char* who) {
     if (B <= 0 || Ci <= 0 || Co <= 0 || P <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
-    if ((Ci % 16) || (Co % 16))
-        return fail(CABINET_ERR_UNSUPPORTED, "%s: Ci=%d, Co=%d must be multiples of 16", who, Ci, Co);
+    if ((Ci % 4) || (Co % 4))
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: Ci=%d, Co=%d must be multiples of 4", who, Ci, Co);
     if (B > 65535) return fail(CABINET_ERR_UNSUPPORTED, "%s: B exceeds grid limits", who);
     return CABINET_OK;
 }
@@ -502,7 +502,7 @@ int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, 
     if (int rc = check_conv1x1(B, Ci, Co, P, "conv1x1_bwd")) return rc;
     if (!dy || !x || !w) return fail(CABINET_ERR_INVALID_ARG, "conv1x1_bwd: null tensor pointer");
     const size_t need = cabinet::conv1x1_bwd_workspace(B, Ci, Co, P);
-    if (dw && (!workspace || workspace_bytes < need))
+    if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "conv1x1_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     return hip_status(cabinet::conv1x1_bwd_run(dy, x, w, B, Ci, Co, P, dx, dw, workspace, static_cast<hipStream_t>(stream)),
                       "conv1x1_bwd launch");

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
                 ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         {
-            const int kk = tid >> 5, c4 = tid & 31, k = k0 + kk, p = p0 + c4 * 4;
+            const int kk = tid >> 5, c4 = tid & 31, k = min(k0 + kk, K - 1), p = p0 + c4 * 4;  // K tail: A rows are 0
             const float* row = (k < a.K0) ? a.src0 + ((size_t)b * a.K0 + k) * P
                                           : a.src1 + ((size_t)b * (K - a.K0) + (k - a.K0)) * P;
             if (INTERIOR || (vec_ok && p + 3 < P)) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
         *reinterpret_cast<f32x4*>(Bs + (size_t)buf * GK_BK * GK_NT + tid * 4) = rb;
     };
 
-    const int nchunks = K / GK_BK;
+    const int nchunks = (K + GK_BK - 1) / GK_BK;
     load_chunk(0);
     store_chunk(0);
     __syncthreads();

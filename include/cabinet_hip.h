@@ -239,7 +239,7 @@ int cabinet_cab_qkv_bwd(const float* dq, const float* dk, const float* dv, const
 
 /* ------------------------------------------------------------------------- *
  * Bias-free 1x1 convolution, y (B,Co,P) = W (Co,Ci) . x (B,Ci,P), on the exact-fp32 MFMA GEMMs.
- * Replaces src/models/cab.py:155 (project_out of the attention context).  Ci, Co multiples of 16.
+ * Replaces src/models/cab.py:155 (project_out of the attention context).  Ci, Co multiples of 4.
  * bwd: dx = W^T dy (skipped if dx == NULL), dw = sum_{b,p} dy (x) x (skipped if dw == NULL).
  * ------------------------------------------------------------------------- */
 size_t cabinet_conv1x1_fwd_workspace_bytes(int Ci, int Co);

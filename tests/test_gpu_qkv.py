@@ -83,7 +83,8 @@ def test_qkv_vs_oracle(B, C, Kc, Vc, H, W, sizes, training):
 
 
 @pytest.mark.parametrize("B,Ci,Co,shape", [(2, 128, 256, (16, 16)), (8, 128, 256, (32, 32)), (1, 48, 16, (5, 7)),
-                                           (3, 16, 32, (1, 1))])
+                                           (3, 16, 32, (1, 1)), (2, 24, 72, (16, 16)), (1, 72, 40, (9, 7)),
+                                           (2, 200, 80, (8, 8))])  # last three: channel counts not multiples of 16
 def test_conv1x1_vs_oracle(B, Ci, Co, shape):
     from cabinet_amd.functional import conv1x1
 
