@@ -72,6 +72,7 @@ hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int
                            float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
                            hipStream_t stream);
 size_t ohem_up_bwd_workspace(int B, int C, int H, int Wl);
+bool ohem_up_supported(int C, int Wl, int W);
 hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const float* loss_px, int B, int C, int Hl,
                            int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
                            hipStream_t stream);
@@ -282,6 +283,9 @@ static int check_ohem(int B, int C, int Hl, int Wl, int H, int W) {
         return fail(CABINET_ERR_INVALID_ARG, "ohem_up: non-positive dimension");
     if (C > 32) return fail(CABINET_ERR_UNSUPPORTED, "ohem_up: C=%d classes (max 32)", C);
     if (B > 65535 || H > 65535) return fail(CABINET_ERR_UNSUPPORTED, "ohem_up: B or H exceeds grid limits");
+    if (!cabinet::ohem_up_supported(C, Wl, W))
+        return fail(CABINET_ERR_UNSUPPORTED, "ohem_up: C=%d x Wl=%d (or the resize ratio %d/%d) exceeds the LDS row buffers",
+                    C, Wl, W, Wl);
     return CABINET_OK;
 }
 

@@ -16,7 +16,6 @@
 
 namespace cabinet {
 
-constexpr int OHEM_MAXC = 32;
 
 __device__ __forceinline__ void lin_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
     const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
@@ -25,62 +24,58 @@ __device__ __forceinline__ void lin_taps(int dst, float scale, int in_size, int&
     lam = src - (float)i0;
 }
 
-// logits of one output pixel: x[c] = bilinear sample of low[b][c] ; returns lse
-__device__ __forceinline__ float sample_logits(const float* __restrict__ low_b, int C, size_t plane, int o00, int o01,
-                                               int o10, int o11, float w00, float w01, float w10, float w11,
-                                               float (&x)[OHEM_MAXC]) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < OHEM_MAXC; ++c) {
-        if (c < C) {
-            const float* p = low_b + (size_t)c * plane;
-            x[c] = w00 * p[o00] + w01 * p[o01] + w10 * p[o10] + w11 * p[o11];
-            mx = fmaxf(mx, x[c]);
-        }
-    }
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < OHEM_MAXC; ++c)
-        if (c < C) se += expf(x[c] - mx);
-    return mx + logf(se);
-}
-
+// One workgroup per output row (b, oy).  The two source rows are lerped vertically into LDS once (coalesced
+// reads), so a pixel's C logits cost 2 LDS reads each instead of 4 scattered global loads.
+template <int CMAX>  // classes rounded up: the per-class loops are fully unrolled and predicated on c < C
 __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
                                                            int C, int Hl, int Wl, int H, int W, float rh, float rw,
                                                            float thresh, int ignore_lb, float* __restrict__ loss_px,
                                                            float* __restrict__ blk_sum, int* __restrict__ blk_cnt) {
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][Wl]
     __shared__ float s_f[4];
     __shared__ int s_i[2][4];
-    const int b = blockIdx.y;
-    const int pix = blockIdx.x * 256 + threadIdx.x, P = H * W;
+    const int b = blockIdx.y, oy = blockIdx.x, P = H * W;
+    const size_t plane = (size_t)Hl * Wl;
+    const float* low_b = low + (size_t)b * C * plane;
+    int y0, y1;
+    float ly;
+    lin_taps(oy, rh, Hl, y0, y1, ly);
+    for (int i = threadIdx.x; i < C * Wl; i += 256) {
+        const int c = i / Wl, xs = i - c * Wl;
+        const float* p = low_b + (size_t)c * plane;
+        v[i] = (1.f - ly) * p[y0 * Wl + xs] + ly * p[y1 * Wl + xs];
+    }
+    __syncthreads();
     float my_sum = 0.f;
     int my_valid = 0, my_above = 0;
-    if (pix < P) {
-        const int oy = pix / W, ox = pix - oy * W;
-        const long long lb = labels[(size_t)b * P + pix];
+    for (int ox = threadIdx.x; ox < W; ox += 256) {
+        const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
+        const long long lb = labels[pix];
         float loss = 0.f;
         if (lb != (long long)ignore_lb) {
-            int y0, y1, x0, x1;
-            float ly, lx;
-            lin_taps(oy, rh, Hl, y0, y1, ly);
+            int x0, x1;
+            float lx;
             lin_taps(ox, rw, Wl, x0, x1, lx);
-            float x[OHEM_MAXC];
-            const size_t plane = (size_t)Hl * Wl;
-            const float lse = sample_logits(low + (size_t)b * C * plane, C, plane, y0 * Wl + x0, y0 * Wl + x1,
-                                            y1 * Wl + x0, y1 * Wl + x1, (1.f - ly) * (1.f - lx), (1.f - ly) * lx,
-                                            ly * (1.f - lx), ly * lx, x);
-            float xl = 0.f;
+            float x[CMAX], mx = -INFINITY, xl = 0.f;
 #pragma unroll
-            for (int c = 0; c < OHEM_MAXC; ++c)
-                if (c < C && c == (int)lb) xl = x[c];
-            loss = lse - xl;
-            my_valid = 1;
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) {
+                    x[c] = (1.f - lx) * v[c * Wl + x0] + lx * v[c * Wl + x1];
+                    mx = fmaxf(mx, x[c]);
+                    if (c == (int)lb) xl = x[c];
+                }
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) se += expf(x[c] - mx);
+            loss = mx + logf(se) - xl;
+            my_valid += 1;
             if (loss > thresh) {
-                my_above = 1;
-                my_sum = loss;
+                my_above += 1;
+                my_sum += loss;
             }
         }
-        loss_px[(size_t)b * P + pix] = loss;
+        loss_px[pix] = loss;
     }
     // ordered block reduction
     my_sum = wave_sum(my_sum);
@@ -104,44 +99,94 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
 }
 
 // T[b][c][oy][xs] = sum_ox wx(ox, xs) * G_c(oy, ox),   G = coef * sel * (softmax - onehot)
-__global__ __launch_bounds__(128) void ohem_up_bwd_x_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
+// One workgroup per (segment of SX source columns, output row): G of the output pixels the segment touches is
+// computed ONCE into LDS (one pixel per thread and pass), then every (c, xs) gathers its <= ~2/rw+2 terms.
+template <int CMAX>
+__global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
                                                              const float* __restrict__ loss_px, int C, int Hl, int Wl,
                                                              int H, int W, float rh, float rw, float thresh,
-                                                             int ignore_lb, float coef, float* __restrict__ T) {
-    const int b = blockIdx.z, oy = blockIdx.y;
-    const int xs = blockIdx.x * 128 + threadIdx.x;
-    if (xs >= Wl) return;
-    const int P = H * W;
+                                                             int ignore_lb, float coef, int SX, int nox_max, int R,
+                                                             int gplane, float* __restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.z, oy = blockIdx.y, xs0 = blockIdx.x * SX, P = H * W;
+    const int nxs = min(SX, Wl - xs0);
+    // output pixels whose taps can touch [xs0, xs0 + nxs)
+    const int ox_lo = max(0, (int)floorf(((float)xs0 - 0.5f) / rw - 0.5f) - 1);
+    const int ox_hi = min(W - 1, (int)ceilf(((float)(xs0 + nxs - 1) + 1.5f) / rw - 0.5f) + 1);
+    const int nox = min(ox_hi - ox_lo + 1, nox_max);
+    const int vx0 = max(xs0 - 2, 0), nvx = min(xs0 + nxs + 2, Wl) - vx0;  // staged source columns
+    float* v = smem;                      // [C][SX + 4]
+    // G[c] is stored de-interleaved by R = round(W / Wl): pixel i sits at (i % R) * gplane + i / R.  The gather
+    // below walks i = lo(xs) + iter with lo(xs) advancing by R per lane, so in every iteration all lanes of a wave
+    // read the same phase at consecutive words (a plain [c][i] layout is a 16-way bank conflict there).
+    float* G = v + C * (SX + 4);          // [C][R * gplane]
+    const int gsize = R * gplane;
     const size_t plane = (size_t)Hl * Wl;
     const float* low_b = low + (size_t)b * C * plane;
     int y0, y1;
     float ly;
     lin_taps(oy, rh, Hl, y0, y1, ly);
-    const int ox_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1);
-    const int ox_hi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1);
-    float acc[OHEM_MAXC];
-#pragma unroll
-    for (int c = 0; c < OHEM_MAXC; ++c) acc[c] = 0.f;
-    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+    for (int i = threadIdx.x; i < C * nvx; i += 256) {
+        const int c = i / nvx, q = i - c * nvx;
+        const float* p = low_b + (size_t)c * plane;
+        v[c * (SX + 4) + q] = (1.f - ly) * p[y0 * Wl + vx0 + q] + ly * p[y1 * Wl + vx0 + q];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nox; i += 256) {
+        const int ox = ox_lo + i;
         int x0, x1;
         float lx;
         lin_taps(ox, rw, Wl, x0, x1, lx);
-        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
-        if (wx == 0.f) continue;
+        const int gi = (i % R) * gplane + i / R;
         const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
         const long long lb = labels[pix];
-        if (lb == (long long)ignore_lb || !(loss_px[pix] > thresh)) continue;  // not selected
-        float x[OHEM_MAXC];
-        const float lse = sample_logits(low_b, C, plane, y0 * Wl + x0, y0 * Wl + x1, y1 * Wl + x0, y1 * Wl + x1,
-                                        (1.f - ly) * (1.f - lx), (1.f - ly) * lx, ly * (1.f - lx), ly * lx, x);
-        const float wc = wx * coef;
+        const bool sel = lb != (long long)ignore_lb && loss_px[pix] > thresh;
+        // taps outside the staged window belong to a pixel no column of this segment receives from
+        const bool inwin = x0 >= vx0 && x1 < vx0 + nvx;
+        if (sel && inwin) {
+            float x[CMAX], mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < OHEM_MAXC; ++c)
-            if (c < C) acc[c] += wc * (expf(x[c] - lse) - (c == (int)lb ? 1.f : 0.f));
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) {
+                    x[c] = (1.f - lx) * v[c * (SX + 4) + x0 - vx0] + lx * v[c * (SX + 4) + x1 - vx0];
+                    mx = fmaxf(mx, x[c]);
+                }
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) {
+                    x[c] = expf(x[c] - mx);
+                    se += x[c];
+                }
+            const float inv = coef / se;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) G[c * gsize + gi] = x[c] * inv - (c == (int)lb ? coef : 0.f);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) G[c * gsize + gi] = 0.f;
+        }
     }
-#pragma unroll
-    for (int c = 0; c < OHEM_MAXC; ++c)
-        if (c < C) T[(((size_t)b * C + c) * H + oy) * Wl + xs] = acc[c];
+    __syncthreads();
+    for (int it = threadIdx.x; it < C * nxs; it += 256) {
+        const int c = it / nxs, xs = xs0 + (it - c * nxs);
+        const int lo = max(ox_lo, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1) - ox_lo;
+        const int hi = min(ox_hi, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1) - ox_lo;
+        float acc = 0.f;
+        int ph = lo % R, q = lo / R;  // de-interleaved position of pixel i, advanced incrementally
+        const float* Gc = G + c * gsize;
+        for (int i = lo; i <= min(hi, nox - 1); ++i) {
+            int x0, x1;
+            float lx;
+            lin_taps(ox_lo + i, rw, Wl, x0, x1, lx);
+            // (x1 == x0 at the clamped right edge: both taps are the same column, weight 1 in total)
+            const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+            acc = fmaf(wx, Gc[ph * gplane + q], acc);
+            if (++ph == R) ph = 0, ++q;
+        }
+        T[(((size_t)b * C + c) * H + oy) * Wl + xs] = acc;
+    }
 }
 
 // dlow[b][c][ys][xs] = sum_oy wy(oy, ys) * T[b][c][oy][xs]
@@ -163,24 +208,63 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_y_kernel(const float* __restr
     dlow[idx] = acc;
 }
 
-int ohem_blocks(int B, int H, int W) { return B * ceil_div(H * W, 256); }
+int ohem_blocks(int B, int H, int W) { (void)W; return B * H; }  // one partial per output row
 
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
                            float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(ohem_up_fwd_kernel, dim3(ceil_div(H * W, 256), B), dim3(256), 0, stream, low, labels, C, Hl, Wl,
-                       H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, loss_px, blk_sum, blk_cnt);
+#define OHEM_FWD(CM)                                                                                                   \
+    hipLaunchKernelGGL(ohem_up_fwd_kernel<CM>, dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float), stream, low, labels, \
+                       C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, loss_px, blk_sum,  \
+                       blk_cnt)
+    if (C <= 8) OHEM_FWD(8);
+    else if (C <= 16) OHEM_FWD(16);
+    else if (C <= 20) OHEM_FWD(20);
+    else OHEM_FWD(32);
+#undef OHEM_FWD
     return hipGetLastError();
 }
 
 size_t ohem_up_bwd_workspace(int B, int C, int H, int Wl) { return align_up((size_t)B * C * H * Wl * sizeof(float), 256); }
 
+// segment width (source columns per workgroup) and the bound on output pixels a segment touches
+static void ohem_segment(int C, int Wl, int W, int& SX, int& nox_max, int& R, int& gplane, size_t& lds) {
+    const float rw = (float)Wl / (float)W;
+    R = (W + Wl / 2) / Wl;
+    if (R < 1) R = 1;
+    for (SX = 64; SX >= 1; SX >>= 1) {
+        nox_max = (int)((float)(SX + 2) / rw) + 8;
+        gplane = ceil_div(nox_max, R);
+        gplane += (8 - gplane % 32 + 32) % 32;  // plane stride = 8 mod 32 banks: the phase-major writes stay 2-way
+        lds = ((size_t)C * (SX + 4) + (size_t)C * R * gplane) * sizeof(float);
+        if (lds <= 60 * 1024) return;
+    }
+    SX = 0;
+}
+
+bool ohem_up_supported(int C, int Wl, int W) {
+    int SX, nox, R, gplane;
+    size_t lds;
+    ohem_segment(C, Wl, W, SX, nox, R, gplane, lds);
+    return SX > 0 && (size_t)C * Wl * sizeof(float) <= 60 * 1024;
+}
+
 hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const float* loss_px, int B, int C, int Hl,
                            int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
                            hipStream_t stream) {
     float* T = static_cast<float*>(ws);
-    hipLaunchKernelGGL(ohem_up_bwd_x_kernel, dim3(ceil_div(Wl, 128), H, B), dim3(128), 0, stream, low, labels, loss_px, C,
-                       Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, coef, T);
+    int SX, nox_max, R, gplane;
+    size_t lds;
+    ohem_segment(C, Wl, W, SX, nox_max, R, gplane, lds);
+#define OHEM_BWD(CM)                                                                                                     \
+    hipLaunchKernelGGL(ohem_up_bwd_x_kernel<CM>, dim3(ceil_div(Wl, SX), H, B), dim3(256), lds, stream, low, labels, loss_px, \
+                       C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, coef, SX, nox_max,   \
+                       R, gplane, T)
+    if (C <= 8) OHEM_BWD(8);
+    else if (C <= 16) OHEM_BWD(16);
+    else if (C <= 20) OHEM_BWD(20);
+    else OHEM_BWD(32);
+#undef OHEM_BWD
     hipLaunchKernelGGL(ohem_up_bwd_y_kernel, dim3(ceil_div(B * C * Hl * Wl, 256)), dim3(256), 0, stream, T, B * C, Hl, Wl,
                        H, (float)Hl / (float)H, dlow);
     return hipGetLastError();

@@ -51,15 +51,30 @@ class OhemCELoss(nn.Module):
         into hand-written kernels on HIP tensors (``cabinet_ohem_up_fwd/bwd``): neither the (B,C,H,W) logits nor
         their log-softmax nor the per-pixel gradient are materialised.  The kernels implement the branch
         "at least n_min pixels above thresh"; class weights or the top-n_min branch take the composite path."""
+        prep = self._fused_launch(logits_low, labels, size)
+        return self._fused_finish(prep, None)
+
+    # The fused head runs in two phases so that a caller with several heads can issue all forward kernels first
+    # and pay ONE host read-back for the branch decisions (see ohem_upsampled_pair).
+    def _fused_launch(self, logits_low, labels, size):
         size = tuple(size) if size is not None else tuple(labels.shape[-2:])
         fused = logits_low.is_cuda and not isinstance(self.weight, torch.Tensor) and logits_low.shape[1] <= 32
-        if fused:
-            from .functional import _OhemUpSelected, _f32c, ohem_up_fwd_hip
+        if not fused:
+            return (logits_low, labels, size, None, None, None)
+        from .functional import _f32c, ohem_up_fwd_hip
 
-            low = _f32c(logits_low)
-            lab = labels.contiguous()
-            loss_px, stats = ohem_up_fwd_hip(low.detach(), lab, size, self.thresh, self.ignore_lb)
-            n_valid, n_above, _ = stats.tolist()  # the step's one host sync
+        low = _f32c(logits_low)
+        lab = labels.contiguous()
+        loss_px, stats = ohem_up_fwd_hip(low.detach(), lab, size, self.thresh, self.ignore_lb)
+        return (logits_low, labels, size, low, lab, (loss_px, stats))
+
+    def _fused_finish(self, prep, host_stats):
+        logits_low, labels, size, low, lab, fwd = prep
+        if fwd is not None:
+            from .functional import _OhemUpSelected
+
+            loss_px, stats = fwd
+            n_valid, n_above, _ = host_stats if host_stats is not None else stats.tolist()  # host sync
             n_valid, n_above = int(n_valid), int(n_above)
             if n_valid == 0:
                 return torch.zeros((), device=logits_low.device, requires_grad=True)
@@ -70,3 +85,15 @@ class OhemCELoss(nn.Module):
 
     def extra_repr(self):
         return f"thresh={self.thresh}, n_min={self.n_min}, ignore_lb={self.ignore_lb}"
+
+
+def ohem_upsampled_pair(crit_a, low_a, crit_b, low_b, labels, size):
+    """``crit_a.forward_upsampled(low_a, ...) + crit_b.forward_upsampled(low_b, ...)`` with both heads' forward
+    kernels issued before the single host read-back that decides their OHEM branches (the reference's step,
+    train.py:429-441, syncs once per head inside the sort-based loss)."""
+    pa = crit_a._fused_launch(low_a, labels, size)
+    pb = crit_b._fused_launch(low_b, labels, size)
+    host = [None, None]
+    if pa[5] is not None and pb[5] is not None:
+        host = torch.stack([pa[5][1], pb[5][1]]).tolist()
+    return crit_a._fused_finish(pa, host[0]) + crit_b._fused_finish(pb, host[1])

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import torch
 
-from .loss import OhemCELoss
+from .loss import OhemCELoss, ohem_upsampled_pair
 from .models.cabinet import CABiNet
 from .models.constants import DEFAULT_IGNORE_LABEL, DEFAULT_SCORE_THRESHOLD, MOBILENETV3_CFGS, OHEM_DIVISOR
 
@@ -65,7 +65,7 @@ class TrainStep:
             if fused:
                 low, low16 = self.net.forward_lowres(im)
                 size = im.shape[2:]
-                loss = self.crit_p.forward_upsampled(low, lb, size) + self.crit_16.forward_upsampled(low16, lb, size)
+                loss = ohem_upsampled_pair(self.crit_p, low, self.crit_16, low16, lb, size)
             else:
                 out, out16 = self.net(im)
                 loss = self.crit_p(out, lb) + self.crit_16(out16, lb)

@@ -14,6 +14,9 @@ TOL = 1e-3
     (2, 8, 16, 16, 128, 128, 0.0, 0.7, 2 * 128 * 128 // 16),     # x8, CABiNet's ratio
     (2, 19, 12, 20, 96, 160, 0.2, 0.7, 2 * 96 * 160 // 16),      # 19 classes, non-square, ignored pixels
     (1, 8, 9, 7, 61, 50, 0.1, 0.7, 100),                          # non-integer ratio, odd sizes
+    (1, 12, 20, 80, 160, 640, 0.05, 0.7, 160 * 640 // 16),        # two 64-column segments per row, 12 classes
+    (1, 27, 6, 6, 48, 48, 0.0, 0.7, 48 * 48 // 16),               # 27 classes (widest class bucket)
+    (1, 8, 32, 32, 16, 16, 0.0, 0.7, 16),                         # "upsample" that shrinks (ratio < 1)
     (1, 8, 8, 8, 64, 64, 0.0, 1.5, 64 * 64 // 16),                # higher threshold (fewer selected)
     (1, 8, 8, 8, 64, 64, 0.0, 50.0, 64 * 64 // 16),               # nothing above thresh -> composite top-k branch
     (1, 8, 8, 8, 64, 64, 1.0, 0.7, 10),                           # everything ignored -> 0 with grad

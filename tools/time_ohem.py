@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cabinet_amd.functional import ohem_up_fwd_hip, ohem_up_bwd_hip
 def t(fn, it=20):
