@@ -270,6 +270,52 @@ __global__ __launch_bounds__(BA_T) void bn_act_bwd_dx_kernel(const float* __rest
     ba_store(dx + (size_t)row * P, P, ch * BA_CHUNK, vg);
 }
 
+// ---- channel gate + activation (squeeze-excite tail, reference mobilenetv3.py:79-83 followed by :121/:141) ----
+// y = act(x * gate[b,c]);  backward: du = dy * act'(x*gate), dx = du * gate, dgate[b,c] = sum_p du * x
+__global__ __launch_bounds__(BA_T) void gate_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                             int P, int chunks, int act, float* __restrict__ y) {
+    const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;
+    const float gt = gate[row];
+    f32x4 v[BA_V];
+    ba_load(x + (size_t)row * P, P, ch * BA_CHUNK, v);
+#pragma unroll
+    for (int i = 0; i < BA_V; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = act_fwd(v[i][e] * gt, act);
+    ba_store(y + (size_t)row * P, P, ch * BA_CHUNK, v);
+}
+
+__global__ __launch_bounds__(BA_T) void gate_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gate, int P, int chunks, int act,
+                                                             float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks;
+    const float gt = gate[row];
+    f32x4 vx[BA_V], vg[BA_V];
+    ba_load(x + (size_t)row * P, P, ch * BA_CHUNK, vx);
+    ba_load(dy + (size_t)row * P, P, ch * BA_CHUNK, vg);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < BA_V; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float du = vg[i][e] * act_grad(vx[i][e] * gt, act);
+            s = fmaf(du, vx[i][e], s);
+            vg[i][e] = du * gt;
+        }
+    ba_store(dx + (size_t)row * P, P, ch * BA_CHUNK, vg);
+    s = ba_block_sum(s, red);
+    if (threadIdx.x == 0) part[(size_t)row * chunks + ch] = s;
+}
+
+__global__ void gate_act_dgate_kernel(const float* __restrict__ part, int rows, int chunks, float* __restrict__ dgate) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)row * chunks + c];
+    dgate[row] = s;
+}
+
 static int ba_chunks(int P) { return ceil_div(P, BA_CHUNK); }
 
 size_t bn_act_workspace(int B, int C, int P) {
@@ -302,6 +348,24 @@ hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, 
                        training, dweight, dbias, coef);
     hipLaunchKernelGGL(bn_act_bwd_dx_kernel, dim3(grid), dim3(BA_T), 0, stream, dy, x, save_mean, save_invstd, weight,
                        bias, coef, C, P, chunks, act, dx);
+    return hipGetLastError();
+}
+
+size_t gate_act_workspace(int rows, int P) { return align_up((size_t)rows * ba_chunks(P) * sizeof(float), 256); }
+
+hipError_t gate_act_fwd_run(const float* x, const float* gate, int rows, int P, int act, float* y, hipStream_t stream) {
+    const int chunks = ba_chunks(P);
+    hipLaunchKernelGGL(gate_act_fwd_kernel, dim3(rows * chunks), dim3(BA_T), 0, stream, x, gate, P, chunks, act, y);
+    return hipGetLastError();
+}
+
+hipError_t gate_act_bwd_run(const float* dy, const float* x, const float* gate, int rows, int P, int act, float* dx,
+                            float* dgate, void* ws, hipStream_t stream) {
+    const int chunks = ba_chunks(P);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(gate_act_bwd_kernel, dim3(rows * chunks), dim3(BA_T), 0, stream, dy, x, gate, P, chunks, act, dx,
+                       part);
+    hipLaunchKernelGGL(gate_act_dgate_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, stream, part, rows, chunks, dgate);
     return hipGetLastError();
 }
 

@@ -59,6 +59,10 @@ hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias
 hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, const float* bias,
                           const float* save_mean, const float* save_invstd, int B, int C, int P, int act, int training,
                           float* dx, float* dweight, float* dbias, void* ws, hipStream_t stream);
+size_t gate_act_workspace(int rows, int P);
+hipError_t gate_act_fwd_run(const float* x, const float* gate, int rows, int P, int act, float* y, hipStream_t stream);
+hipError_t gate_act_bwd_run(const float* dy, const float* x, const float* gate, int rows, int P, int act, float* dx,
+                            float* dgate, void* ws, hipStream_t stream);
 // dwconv.hip
 bool dwconv_supported(int K, int S);
 size_t dwconv_bwd_workspace(int B, int C, int H, int W, int K);
@@ -591,6 +595,31 @@ int cabinet_dwconv_bwd(const float* dy, const float* x, const float* weight, int
     return hip_status(cabinet::dwconv_bwd_run(dy, x, weight, B, C, H, W, K, stride, dx, dw, workspace,
                                               static_cast<hipStream_t>(stream)),
                       "dwconv_bwd launch");
+}
+
+// ------------------------------------------------------ channel gate + activation
+int cabinet_gate_act_fwd(const float* x, const float* gate, int B, int C, int P, int act, float* y,
+                         cabinet_stream_t stream) {
+    if (int rc = check_bn_act(B, C, P, act, "gate_act_fwd")) return rc;
+    if (!x || !gate || !y) return fail(CABINET_ERR_INVALID_ARG, "gate_act_fwd: null tensor pointer");
+    return hip_status(cabinet::gate_act_fwd_run(x, gate, B * C, P, act, y, static_cast<hipStream_t>(stream)),
+                      "gate_act_fwd launch");
+}
+
+size_t cabinet_gate_act_bwd_workspace_bytes(int B, int C, int P) {
+    return B > 0 && C > 0 && P > 0 ? cabinet::gate_act_workspace(B * C, P) : 0;
+}
+
+int cabinet_gate_act_bwd(const float* dy, const float* x, const float* gate, int B, int C, int P, int act, float* dx,
+                         float* dgate, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_bn_act(B, C, P, act, "gate_act_bwd")) return rc;
+    if (!dy || !x || !gate || !dx || !dgate) return fail(CABINET_ERR_INVALID_ARG, "gate_act_bwd: null tensor pointer");
+    const size_t need = cabinet::gate_act_workspace(B * C, P);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "gate_act_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::gate_act_bwd_run(dy, x, gate, B * C, P, act, dx, dgate, workspace,
+                                                static_cast<hipStream_t>(stream)),
+                      "gate_act_bwd launch");
 }
 
 }  // extern "C"

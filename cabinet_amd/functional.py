@@ -255,10 +255,37 @@ class _FfmUpFused(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+_NBT_PENDING = None  # list of num_batches_tracked buffers while batched_bn_counters() is open
+
+
+class batched_bn_counters:
+    """Within this context the ``num_batches_tracked += 1`` of every BatchNorm2d served by the HIP ops is deferred
+    and applied as ONE multi-tensor add on exit (the model has 59 BatchNorms: 59 one-element kernels per step
+    otherwise).  Values after the context are identical; nesting is a no-op."""
+
+    def __enter__(self):
+        global _NBT_PENDING
+        self.owner = _NBT_PENDING is None
+        if self.owner:
+            _NBT_PENDING = []
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT_PENDING
+        if self.owner:
+            pending, _NBT_PENDING = _NBT_PENDING, None
+            if pending:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
 def _bn_step(bn):
     if not (bn.affine and bn.track_running_stats):
         raise RuntimeError("ffm_fused: BatchNorm2d must be affine with running statistics")
     if bn.training:
+        if _NBT_PENDING is not None and bn.momentum is not None:
+            _NBT_PENDING.append(bn.num_batches_tracked)
+            return True, bn.momentum
         bn.num_batches_tracked.add_(1)
         return True, (bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked))
     return False, 0.0
@@ -693,3 +720,51 @@ def dwconv(x, conv):
     if not x.is_cuda:
         raise RuntimeError("dwconv: device tensors only")
     return _DwConv.apply(x, conv.weight, conv.stride[0])
+
+
+# --------------------------------------------------------------------------- channel gate + activation (SE tail)
+
+
+class _GateAct(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, gate, act):
+        lib = _lib.load()
+        x, gate = _f32c(x), _f32c(gate)
+        B, C = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_gate_act_fwd(_ptr(x), _ptr(gate), B, C, P, act, _ptr(y), _stream_handle(x.device))
+        _lib.check(rc, "cabinet_gate_act_fwd")
+        fn_ctx.save_for_backward(x, gate)
+        fn_ctx.act = act
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, gate = fn_ctx.saved_tensors
+        g = _f32c(g)
+        B, C = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        dx, dgate = torch.empty_like(x), torch.empty_like(gate)
+        ws, nbytes = _workspace(lib.cabinet_gate_act_bwd_workspace_bytes(B, C, P), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_gate_act_bwd(_ptr(g), _ptr(x), _ptr(gate), B, C, P, fn_ctx.act, _ptr(dx), _ptr(dgate),
+                                          _ptr(ws), nbytes, _stream_handle(x.device))
+        _lib.check(rc, "cabinet_gate_act_bwd")
+        return dx, dgate, None
+
+
+def gate_act(x, gate, act=None):
+    """act(x * gate[:, :, None, None]) for a device tensor x (B,C,H,W) and a (B,C) gate: the tail of SELayer.forward
+    (reference mobilenetv3.py:79-83) fused with the activation that follows it in the MBConv block."""
+    if not x.is_cuda:
+        raise RuntimeError("gate_act: device tensors only")
+    if act not in _ACT_CODES:
+        raise RuntimeError(f"gate_act: unknown activation {act!r}")
+    if gate.shape != x.shape[:2]:
+        raise RuntimeError(f"gate_act: gate {tuple(gate.shape)} does not match x {tuple(x.shape)}")
+    return _GateAct.apply(x, gate, _ACT_CODES[act])

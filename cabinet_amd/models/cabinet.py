@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import bn_act, ffm_fused, ffm_fused_upsampled
+from ..functional import batched_bn_counters, bn_act, ffm_fused, ffm_fused_upsampled
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -172,18 +172,16 @@ class CABiNet(nn.Module):
     def forward_lowres(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Both heads at H/8 x W/8, i.e. ``forward`` without its two final x8 bilinear upsamples (reference
         cabinet.py:240-245).  ``OhemCELoss.forward_upsampled`` fuses exactly those resizes into the loss."""
-        feat_sb = self.sb(x)
-        low, high = self.ab(self.mobile(x))
-        high_up = _resize(high, feat_sb.shape[2:])
-        final = self.conv_out(self.ffm.forward_upsampled(feat_sb, low))
+        with batched_bn_counters():  # one multi-tensor `num_batches_tracked += 1` for the model's 59 BatchNorms
+            feat_sb = self.sb(x)
+            low, high = self.ab(self.mobile(x))
+            high_up = _resize(high, feat_sb.shape[2:])
+            final = self.conv_out(self.ffm.forward_upsampled(feat_sb, low))
         return final, high_up
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        final, high_up = self.forward_lowres(x)   # resize of `low` fused into the FFM
         size = x.shape[2:]
-        feat_sb = self.sb(x)                      # (B,128,H/8,W/8)
-        low, high = self.ab(self.mobile(x))       # (B,256,H/32,W/32), (B,ncls,H/32,W/32)
-        high_up = _resize(high, feat_sb.shape[2:])
-        final = self.conv_out(self.ffm.forward_upsampled(feat_sb, low))  # resize of `low` fused into the FFM
         return _resize(final, size), _resize(high_up, size)
 
     def get_params(self):

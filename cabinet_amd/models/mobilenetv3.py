@@ -61,10 +61,13 @@ class SELayer(nn.Module):
         self.fc = nn.Sequential(nn.Linear(channel, squeezed), nn.ReLU(inplace=True),
                                 nn.Linear(squeezed, channel), HardSigmoid())
 
+    def gate(self, x):
+        n, c = x.shape[:2]
+        return self.fc(self.avg_pool(x).view(n, c))
+
     def forward(self, x):
         n, c = x.shape[:2]
-        gate = self.fc(self.avg_pool(x).view(n, c))
-        return x * gate.view(n, c, 1, 1)
+        return x * self.gate(x).view(n, c, 1, 1)
 
 
 def _act(use_hs):
@@ -79,7 +82,7 @@ class _FusedSequential(nn.Sequential):
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        from ..functional import bn_act, dwconv, dwconv_supported
+        from ..functional import bn_act, dwconv, dwconv_supported, gate_act
 
         layers = list(self)
         i = 0
@@ -93,6 +96,10 @@ class _FusedSequential(nn.Sequential):
                     x, i = bn_act(x, m, "hardswish"), i + 2
                 else:
                     x, i = bn_act(x, m, None), i + 1
+            elif isinstance(m, SELayer):  # channel gate fused with the activation behind it
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                act = "relu" if isinstance(nxt, nn.ReLU) else "hardswish" if isinstance(nxt, HardSwish) else None
+                x, i = gate_act(x, m.gate(x), act), i + (2 if act else 1)
             elif isinstance(m, nn.Conv2d) and m.groups > 1 and dwconv_supported(m):
                 x, i = dwconv(x, m), i + 1  # depthwise stencil kernel (MIOpen only has its naive solver here)
             else:

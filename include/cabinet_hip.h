@@ -289,6 +289,18 @@ int cabinet_dwconv_bwd(const float* dy, const float* x, const float* weight, int
                        int stride, float* dx, float* dw, void* workspace, size_t workspace_bytes,
                        cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Channel gate + activation: y = act(x * gate[b,c]) for x (B,C,P), gate (B,C); act as in cabinet_bn_act.
+ * Replaces the `x * y.view(n, c, 1, 1)` of SELayer.forward, src/models/mobilenetv3.py:79-83, fused with the
+ * ReLU / HardSwish that follows it in the MBConv block (mobilenetv3.py:121,141).
+ *   bwd: dx = dy * act'(x*gate) * gate,  dgate[b,c] = sum_p dy * act'(x*gate) * x   (x is the only saved tensor)
+ * ------------------------------------------------------------------------- */
+int cabinet_gate_act_fwd(const float* x, const float* gate, int B, int C, int P, int act, float* y,
+                         cabinet_stream_t stream);
+size_t cabinet_gate_act_bwd_workspace_bytes(int B, int C, int P);
+int cabinet_gate_act_bwd(const float* dy, const float* x, const float* gate, int B, int C, int P, int act,
+                         float* dx, float* dgate, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

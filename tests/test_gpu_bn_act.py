@@ -90,3 +90,40 @@ def test_bn_act_matches_stock_modules_and_is_deterministic():
         bn_act(x, bn, "hardswish").backward(torch.ones(2, 16, 40, 40, device="cuda"))
         runs.append((x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*runs))  # fixed reduction order, no atomics
+
+
+@pytest.mark.parametrize("act", [None, "relu", "hardswish"])
+@pytest.mark.parametrize("shape", [(2, 12, 16, 16), (1, 5, 7, 9), (2, 3, 100, 100), (3, 8, 1, 1)])
+def test_gate_act_vs_oracle(shape, act):
+    """act(x * gate) -- SELayer's product (mobilenetv3.py:79-83) + the activation behind it -- vs fp64 autograd."""
+    from cabinet_amd.functional import gate_act
+    from oracle.model_ref import _hswish
+
+    g0 = torch.Generator().manual_seed(8)
+    x = torch.randn(*shape, generator=g0) * 2
+    gate = torch.rand(shape[0], shape[1], generator=g0)
+    g = torch.randn(*shape, generator=g0)
+    xo, go = x.double().requires_grad_(True), gate.double().requires_grad_(True)
+    yo = {"relu": F.relu, "hardswish": _hswish, None: lambda t: t}[act](xo * go[:, :, None, None])
+    yo.backward(g.double())
+    xd, gd = x.cuda().requires_grad_(True), gate.cuda().requires_grad_(True)
+    y = gate_act(xd, gd, act)
+    y.backward(g.cuda())
+    assert_close(y, yo, TOL, "y")
+    assert_close(xd.grad, xo.grad, TOL, "dx")
+    assert_close(gd.grad, go.grad, TOL, "dgate")
+
+
+def test_batched_bn_counters_match_per_module_increments():
+    from cabinet_amd.functional import batched_bn_counters, bn_act
+
+    bns = [torch.nn.BatchNorm2d(4).cuda().train() for _ in range(3)]
+    x = torch.randn(2, 4, 5, 5, device="cuda")
+    with batched_bn_counters():
+        for bn in bns:
+            bn_act(x, bn, "relu")
+        bn_act(x, bns[0], None)
+        assert int(bns[0].num_batches_tracked) == 0  # deferred
+    assert [int(b.num_batches_tracked) for b in bns] == [2, 1, 1]
+    bn_act(x, bns[1], None)  # outside the context: immediate
+    assert int(bns[1].num_batches_tracked) == 2
