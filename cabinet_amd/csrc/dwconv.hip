@@ -12,6 +12,9 @@
 //   bwd : ONE kernel per input-space tile, sharing the staged dy tile between both gradients:
 //           dx[y][x]   = sum w[ky][kx] * dy[(y+p-ky)/S][(x+p-kx)/S]      (taps where the division is exact)
 //           dw[ky][kx] = sum_{b,y,x} x[y][x] * dy[(y+p-ky)/S][(x+p-kx)/S]  -> per-tile partials, ordered final sum
+//         stride 1 is the forward stencil with the flipped filter; stride 2 works on 2x2 input quads so that every
+//         tap is used exactly once per quad with compile-time offsets (these kernels are VALU-bound, not HBM-bound:
+//         the first, generic form spent ~100 instructions per pixel on parity masks and clamps)
 // No atomics anywhere: bitwise reproducible (MIOpen's naive backward is, too; its wrw GEMM path is not).
 #include "common.hpp"
 
@@ -75,12 +78,35 @@ __global__ __launch_bounds__(DW_T) void dwconv_fwd_kernel(const float* __restric
     }
 }
 
-// input-space tile: dx and the per-tile weight-gradient partials part[c][b*tiles + tile][K*K]
-template <int K, int S>
-__global__ __launch_bounds__(DW_T) void dwconv_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ wgt, DwShape s, int TW, int tiles_x,
-                                                           int tiles_y, float* __restrict__ dx,
-                                                           float* __restrict__ part) {
+// ---- backward: dx and the per-tile weight-gradient partials part[c][b*tiles + tile][K*K], one input-space tile ----
+// workgroup reduction of the K*K per-thread partial sums (fixed order); red is [KK][DW_T + 8] (row of 32 padded to 33)
+template <int KK>
+__device__ __forceinline__ void dw_reduce_partials(const float (&pw)[KK], float* red, float* __restrict__ out) {
+    constexpr int LD = DW_T + 8;
+    const int slot = threadIdx.x + (threadIdx.x >> 5);
+#pragma unroll
+    for (int t = 0; t < KK; ++t) red[t * LD + slot] = pw[t];
+    __syncthreads();
+    if (threadIdx.x < KK * 8) {
+        const int tap = threadIdx.x >> 3, seg = threadIdx.x & 7;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[tap * LD + seg * 33 + i];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        if (seg == 0) out[tap] = t;
+    }
+}
+
+// stride 1: with the flipped filter wf[a][b] = w[K-1-a][K-1-b] the input gradient is the SAME stencil as forward,
+// applied to dy (pad K/2), and dw[K-1-a][K-1-b] = sum x[y][x] * dy[y-p+a][x-p+b]: one staged dy tile (+halo),
+// a thread owns 4 vertically adjacent pixels, every LDS row it loads feeds up to K of them -- no masks.
+template <int K>
+__global__ __launch_bounds__(DW_T) void dwconv_bwd_s1_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ wgt, DwShape s, int TW, int tiles_x,
+                                                              int tiles_y, float* __restrict__ dx,
+                                                              float* __restrict__ part) {
     constexpr int PAD = K / 2, KK = K * K;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TH = DW_OUT / TW;
@@ -88,15 +114,83 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_kernel(const float* __restric
     const int tile = blockIdx.x % ntile, plane = blockIdx.x / ntile;
     const int b = plane / s.C, c = plane - b * s.C;
     const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
-    // dy rows/cols any pixel of the tile can touch: o = (i + PAD - k) / S, k in [0,K)
-    const int oy_lo = (y0 + PAD - (K - 1) + S - 1 + S * 1024) / S - 1024;  // ceil(./S), numerator may be negative
-    const int ox_lo = (x0 + PAD - (K - 1) + S - 1 + S * 1024) / S - 1024;
-    const int th = (y0 + TH - 1 + PAD) / S - oy_lo + 1, tw = (x0 + TW - 1 + PAD) / S - ox_lo + 1;
-    float* tile_dy = smem;            // [th][tw]
-    float* red = smem + th * tw;      // [KK][DW_T]
+    const int in_h = TH + K - 1, in_w = TW + K - 1;
+    float* tile_dy = smem;               // [in_h][in_w]
+    float* red = smem + in_h * in_w;     // [KK][DW_T + 8]
+    const float* dyp = dy + (size_t)plane * s.H * s.W;  // stride 1: dy has the input's size
+    for (int i = threadIdx.x; i < in_h * in_w; i += DW_T) {
+        const int r = i / in_w, q = i - r * in_w, oy = y0 - PAD + r, ox = x0 - PAD + q;
+        tile_dy[i] = (oy >= 0 && oy < s.H && ox >= 0 && ox < s.W) ? dyp[(size_t)oy * s.W + ox] : 0.f;
+    }
+    float wf[K][K];
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+        for (int bb = 0; bb < K; ++bb) wf[a][bb] = wgt[(c * K + (K - 1 - a)) * K + (K - 1 - bb)];
+    __syncthreads();
+    const int tx = threadIdx.x & (TW - 1), tq = threadIdx.x / TW;
+    const int xx = x0 + tx;
+    const float* xp = x + (size_t)plane * s.H * s.W;
+    float xv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = y0 + tq * 4 + j;
+        xv[j] = (yy < s.H && xx < s.W) ? xp[(size_t)yy * s.W + xx] : 0.f;
+    }
+    float pw[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) pw[t] = 0.f;
+    const float* base = tile_dy + (tq * 4) * in_w + tx;
+#pragma unroll
+    for (int r = 0; r < 3 + K; ++r) {
+        float v[K];
+#pragma unroll
+        for (int bb = 0; bb < K; ++bb) v[bb] = base[r * in_w + bb];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int a = r - j;  // compile-time after unrolling
+            if (a >= 0 && a < K) {
+#pragma unroll
+                for (int bb = 0; bb < K; ++bb) {
+                    acc[j] = fmaf(wf[a][bb], v[bb], acc[j]);
+                    pw[(K - 1 - a) * K + (K - 1 - bb)] = fmaf(xv[j], v[bb], pw[(K - 1 - a) * K + (K - 1 - bb)]);
+                }
+            }
+        }
+    }
+    float* dxp = dx + (size_t)plane * s.H * s.W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int yy = y0 + tq * 4 + j;
+        if (yy < s.H && xx < s.W) dxp[(size_t)yy * s.W + xx] = acc[j];
+    }
+    dw_reduce_partials<KK>(pw, red, part + ((size_t)c * (s.B * ntile) + (size_t)b * ntile + tile) * KK);
+}
+
+// stride 2: a thread owns the 2x2 input quad (2n+py, 2m+px).  A tap (ky,kx) reaches pixel parity
+// (py,px) = ((ky+p)&1, (kx+p)&1) only, from dy[n + (py+p-ky)/2][m + (px+p-kx)/2]: every tap is used exactly once per
+// quad, all offsets are compile-time, and the <= 3x3 dy neighbourhood is read from LDS once.
+template <int K>
+__global__ __launch_bounds__(DW_T) void dwconv_bwd_s2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ wgt, DwShape s, int TW, int tiles_x,
+                                                              int tiles_y, float* __restrict__ dx,
+                                                              float* __restrict__ part) {
+    constexpr int PAD = K / 2, KK = K * K;
+    // smallest / largest dy offset (py + PAD - ky) / 2 over the exact divisions: K=3 -> 0..1, K=5 -> -1..1
+    constexpr int OLO = (K == 3) ? 0 : -1, OHI = 1, NO = OHI - OLO + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TH = DW_OUT / TW, TWm = TW / 2, THn = TH / 2;
+    const int ntile = tiles_x * tiles_y;
+    const int tile = blockIdx.x % ntile, plane = blockIdx.x / ntile;
+    const int b = plane / s.C, c = plane - b * s.C;
+    const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;  // even
+    const int n0 = y0 / 2, m0 = x0 / 2;
+    const int th = THn + NO - 1, tw = TWm + NO - 1;
+    float* tile_dy = smem;          // [th][tw], origin (n0 + OLO, m0 + OLO)
+    float* red = smem + th * tw;    // [KK][DW_T + 8]
     const float* dyp = dy + (size_t)plane * s.Ho * s.Wo;
     for (int i = threadIdx.x; i < th * tw; i += DW_T) {
-        const int r = i / tw, q = i - r * tw, oy = oy_lo + r, ox = ox_lo + q;
+        const int r = i / tw, q = i - r * tw, oy = n0 + OLO + r, ox = m0 + OLO + q;
         tile_dy[i] = (oy >= 0 && oy < s.Ho && ox >= 0 && ox < s.Wo) ? dyp[(size_t)oy * s.Wo + ox] : 0.f;
     }
     float w[K][K];
@@ -105,63 +199,47 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_kernel(const float* __restric
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) w[ky][kx] = wgt[(c * K + ky) * K + kx];
     __syncthreads();
-    const int tx = threadIdx.x & (TW - 1), tq = threadIdx.x / TW;
-    const int xx = x0 + tx;
+    const int tm = threadIdx.x & (TWm - 1), tn = threadIdx.x / TWm;
+    float g[NO][NO];
+#pragma unroll
+    for (int a = 0; a < NO; ++a)
+#pragma unroll
+        for (int bb = 0; bb < NO; ++bb) g[a][bb] = tile_dy[(tn + a) * tw + tm + bb];
     const float* xp = x + (size_t)plane * s.H * s.W;
     float* dxp = dx + (size_t)plane * s.H * s.W;
-    float pw[K][K];
+    float pw[KK];
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky)
+    for (int t = 0; t < KK; ++t) pw[t] = 0.f;
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) pw[ky][kx] = 0.f;
-    // column taps of this lane: ox = (xx + PAD - kx) / S where exact; mask and LDS column per kx
-    int colq[K];
-    float colm[K];
+    for (int py = 0; py < 2; ++py) {
+        const int yy = y0 + 2 * tn + py;
+        float xv[2], acc[2] = {0.f, 0.f};
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx) {
-        const int t = xx + PAD - kx;
-        const bool ok = S == 1 || (t % S) == 0;  // t >= 0 inside the staged range whenever it matters
-        colq[kx] = ok ? (t >= 0 ? t / S : -1) - ox_lo : 0;
-        colm[kx] = (ok && colq[kx] >= 0 && colq[kx] < tw) ? 1.f : 0.f;
-        colq[kx] = min(max(colq[kx], 0), tw - 1);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int yy = y0 + tq * 4 + j;
-        const bool live = yy < s.H && xx < s.W;
-        const float xv = live ? xp[(size_t)yy * s.W + xx] : 0.f;
-        float acc = 0.f;
+        for (int px = 0; px < 2; ++px) {
+            const int xx = x0 + 2 * tm + px;
+            xv[px] = (yy < s.H && xx < s.W) ? xp[(size_t)yy * s.W + xx] : 0.f;
+        }
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
-            const int t = yy + PAD - ky;
-            if (S > 1 && (t % S) != 0) continue;  // uniform per wave row group: yy is the same for a whole row
-            const int r = (t >= 0 ? t / S : -1) - oy_lo;
-            if (r < 0 || r >= th) continue;
+            if (((py + PAD - ky) & 1) != 0) continue;           // compile-time
+            const int a = (py + PAD - ky) / 2 - OLO;            // row of g
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float g = tile_dy[r * tw + colq[kx]] * colm[kx];
-                acc = fmaf(w[ky][kx], g, acc);
-                pw[ky][kx] = fmaf(xv, g, pw[ky][kx]);
-            }
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    if (((px + PAD - kx) & 1) != 0) continue;
+                    const int bb = (px + PAD - kx) / 2 - OLO;
+                    acc[px] = fmaf(w[ky][kx], g[a][bb], acc[px]);
+                    pw[ky * K + kx] = fmaf(xv[px], g[a][bb], pw[ky * K + kx]);
+                }
         }
-        if (live) dxp[(size_t)yy * s.W + xx] = acc;
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int xx = x0 + 2 * tm + px;
+            if (yy < s.H && xx < s.W) dxp[(size_t)yy * s.W + xx] = acc[px];
+        }
     }
-    // workgroup reduction of the K*K partial sums, fixed order
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) red[(ky * K + kx) * DW_T + threadIdx.x] = pw[ky][kx];
-    __syncthreads();
-    if (threadIdx.x < KK * 8) {
-        const int tap = threadIdx.x >> 3, seg = threadIdx.x & 7;
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) t += red[tap * DW_T + seg * 32 + i];
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        if (seg == 0) part[((size_t)c * (s.B * ntile) + (size_t)b * ntile + tile) * KK + tap] = t;
-    }
+    dw_reduce_partials<KK>(pw, red, part + ((size_t)c * (s.B * ntile) + (size_t)b * ntile + tile) * KK);
 }
 
 // dw[c][tap] = sum over the B*ntile partials (double accumulation, fixed order)
@@ -205,11 +283,16 @@ static hipError_t bwd_launch(const float* dy, const float* x, const float* w, co
                              void* ws, hipStream_t stream) {
     const int TW = dw_tile_w(s.W), TH = DW_OUT / TW;
     const int tiles_x = ceil_div(s.W, TW), tiles_y = ceil_div(s.H, TH);
-    const int th = (TH + K - 1) / S + 2, tw = (TW + K - 1) / S + 2;  // upper bound of the staged dy tile
-    const size_t lds = ((size_t)th * tw + (size_t)K * K * DW_T) * sizeof(float);
+    const size_t tile_floats = S == 1 ? (size_t)(TH + K - 1) * (TW + K - 1) : (size_t)(TH / 2 + 2) * (TW / 2 + 2);
+    const size_t lds = (tile_floats + (size_t)K * K * (DW_T + 8)) * sizeof(float);
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL((dwconv_bwd_kernel<K, S>), dim3((unsigned)((size_t)s.B * s.C * tiles_x * tiles_y)), dim3(DW_T), lds,
-                       stream, dy, x, w, s, TW, tiles_x, tiles_y, dx, part);
+    const dim3 grid((unsigned)((size_t)s.B * s.C * tiles_x * tiles_y));
+    if (S == 1)
+        hipLaunchKernelGGL((dwconv_bwd_s1_kernel<K>), grid, dim3(DW_T), lds, stream, dy, x, w, s, TW, tiles_x, tiles_y, dx,
+                           part);
+    else
+        hipLaunchKernelGGL((dwconv_bwd_s2_kernel<K>), grid, dim3(DW_T), lds, stream, dy, x, w, s, TW, tiles_x, tiles_y, dx,
+                           part);
     hipLaunchKernelGGL(dwconv_dw_finalize_kernel, dim3(s.C * K * K), dim3(256), 0, stream, part, s.B * tiles_x * tiles_y,
                        K * K, dw);
     return hipGetLastError();
