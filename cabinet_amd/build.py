@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libcabinet_hip.so")
 ARCH = "gfx950"
 
 SOURCES = ["capi.hip", "cab_attn_fwd.hip", "cab_attn_bwd.hip", "ffm.hip", "ohem.hip", "cab_local.hip", "cab_qkv.hip", "bn_act.hip", "dwconv.hip"]
-HEADERS = ["common.hpp", "cab_local.hpp", "cab_qkv.hpp", "blocks.hpp", os.path.join("..", "..", "include", "cabinet_hip.h")]
+HEADERS = ["common.hpp", "cab_local.hpp", "cab_qkv.hpp", "blocks.hpp", "act.hpp", os.path.join("..", "..", "include", "cabinet_hip.h")]
 
 
 def _hipcc():

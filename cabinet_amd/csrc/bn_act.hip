@@ -15,6 +15,7 @@
 // Nothing but x, mean and invstd is kept for backward (no pre-activation or mask tensor).  One workgroup streams
 // one 8192-element chunk of one (b,c) plane with 128-bit loads; partial results are combined in a fixed order
 // (no atomics): bitwise reproducible.
+#include "act.hpp"
 #include "common.hpp"
 
 namespace cabinet {
@@ -22,24 +23,6 @@ namespace cabinet {
 constexpr int BA_T = 256;
 constexpr int BA_V = 8;                     // float4 per thread and chunk
 constexpr int BA_CHUNK = BA_T * 4 * BA_V;   // 8192 elements
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2 };
-
-__device__ __forceinline__ float act_fwd(float u, int act) {
-    if (act == ACT_RELU) return fmaxf(u, 0.f);
-    if (act == ACT_HSWISH) return u * fminf(fmaxf(u + 3.f, 0.f), 6.f) / 6.f;  // mobilenetv3.py:48-50,63-65
-    return u;
-}
-__device__ __forceinline__ float act_grad(float u, int act) {
-    if (act == ACT_RELU) return u > 0.f ? 1.f : 0.f;
-    if (act == ACT_HSWISH) {
-        // d/du [u * relu6(u+3)/6] with relu6' = 1 on the open interval (0,6), as ATen's hardtanh backward
-        const float t = u + 3.f;
-        const float inner = (t > 0.f && t < 6.f) ? u / 6.f : 0.f;
-        return fminf(fmaxf(t, 0.f), 6.f) / 6.f + inner;
-    }
-    return 1.f;
-}
 
 __device__ __forceinline__ float ba_block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -322,17 +305,36 @@ size_t bn_act_workspace(int B, int C, int P) {
     return align_up((size_t)2 * C * B * ba_chunks(P) * sizeof(float), 256) + align_up((size_t)2 * C * sizeof(float), 256);
 }
 
-hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias, float* running_mean,
-                          float* running_var, int B, int C, int P, int act, int training, float momentum, float eps,
-                          float* y, float* save_mean, float* save_invstd, void* ws, hipStream_t stream) {
+hipError_t bn_stats_run(const float* x, float* running_mean, float* running_var, int B, int C, int P, int training,
+                        float momentum, float eps, float* save_mean, float* save_invstd, void* ws, hipStream_t stream) {
     const int chunks = ba_chunks(P), grid = B * C * chunks;
     float* part = static_cast<float*>(ws);
     if (training)
         hipLaunchKernelGGL(bn_act_stats_kernel, dim3(grid), dim3(BA_T), 0, stream, x, part, B, C, P, chunks);
     hipLaunchKernelGGL(bn_act_finalize_kernel, dim3(C), dim3(BA_T), 0, stream, part, B, C, P, chunks, training, momentum,
                        eps, running_mean, running_var, save_mean, save_invstd);
+    return hipGetLastError();
+}
+
+hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias, float* running_mean,
+                          float* running_var, int B, int C, int P, int act, int training, float momentum, float eps,
+                          float* y, float* save_mean, float* save_invstd, void* ws, hipStream_t stream) {
+    const int chunks = ba_chunks(P), grid = B * C * chunks;
+    (void)bn_stats_run(x, running_mean, running_var, B, C, P, training, momentum, eps, save_mean, save_invstd, ws, stream);
     hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid), dim3(BA_T), 0, stream, x, save_mean, save_invstd, weight, bias, C,
                        P, chunks, act, y);
+    return hipGetLastError();
+}
+
+hipError_t bn_bwd_tail_run(const float* part, int nt, const float* dy, const float* x, const float* weight,
+                           const float* bias, const float* save_mean, const float* save_invstd, int B, int C, int P,
+                           int act, int training, float* dx, float* dweight, float* dbias, float* coef,
+                           hipStream_t stream) {
+    const int chunks = ba_chunks(P), grid = B * C * chunks;
+    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3(C), dim3(BA_T), 0, stream, part, nt, C, (double)B * (double)P,
+                       training, dweight, dbias, coef);
+    hipLaunchKernelGGL(bn_act_bwd_dx_kernel, dim3(grid), dim3(BA_T), 0, stream, dy, x, save_mean, save_invstd, weight,
+                       bias, coef, C, P, chunks, act, dx);
     return hipGetLastError();
 }
 
@@ -344,11 +346,8 @@ hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, 
     float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + align_up((size_t)2 * C * nt * sizeof(float), 256));
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid), dim3(BA_T), 0, stream, dy, x, save_mean, save_invstd, weight,
                        bias, B, C, P, chunks, act, part);
-    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3(C), dim3(BA_T), 0, stream, part, nt, C, (double)B * (double)P,
-                       training, dweight, dbias, coef);
-    hipLaunchKernelGGL(bn_act_bwd_dx_kernel, dim3(grid), dim3(BA_T), 0, stream, dy, x, save_mean, save_invstd, weight,
-                       bias, coef, C, P, chunks, act, dx);
-    return hipGetLastError();
+    return bn_bwd_tail_run(part, nt, dy, x, weight, bias, save_mean, save_invstd, B, C, P, act, training, dx, dweight,
+                           dbias, coef, stream);
 }
 
 size_t gate_act_workspace(int rows, int P) { return align_up((size_t)rows * ba_chunks(P) * sizeof(float), 256); }

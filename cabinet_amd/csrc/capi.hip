@@ -70,6 +70,16 @@ hipError_t dwconv_fwd_run(const float* x, const float* w, int B, int C, int H, i
                           hipStream_t stream);
 hipError_t dwconv_bwd_run(const float* dy, const float* x, const float* w, int B, int C, int H, int W, int K, int S,
                           float* dx, float* dw, void* ws, hipStream_t stream);
+size_t bn_dwconv_fwd_workspace(int B, int C, int H, int W);
+size_t bn_dwconv_bwd_workspace(int B, int C, int H, int W, int K);
+hipError_t bn_dwconv_fwd_run(const float* z, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                             const float* w, int B, int C, int H, int W, int K, int S, int act, int training,
+                             float momentum, float eps, float* y, float* save_mean, float* save_invstd, void* ws,
+                             hipStream_t stream);
+hipError_t bn_dwconv_bwd_run(const float* dy, const float* z, const float* bn_w, const float* bn_b,
+                             const float* save_mean, const float* save_invstd, const float* w, int B, int C, int H,
+                             int W, int K, int S, int act, int training, float* dz, float* dbn_w, float* dbn_b,
+                             float* dw, void* ws, hipStream_t stream);
 // ohem.hip
 int ohem_blocks(int B, int H, int W);
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
@@ -620,6 +630,52 @@ int cabinet_gate_act_bwd(const float* dy, const float* x, const float* gate, int
     return hip_status(cabinet::gate_act_bwd_run(dy, x, gate, B * C, P, act, dx, dgate, workspace,
                                                 static_cast<hipStream_t>(stream)),
                       "gate_act_bwd launch");
+}
+
+// ------------------------------------------------------ BatchNorm (+act) -> depthwise convolution
+size_t cabinet_bn_dwconv_fwd_workspace_bytes(int B, int C, int H, int W) {
+    return B > 0 && C > 0 && H > 0 && W > 0 ? cabinet::bn_dwconv_fwd_workspace(B, C, H, W) : 0;
+}
+
+int cabinet_bn_dwconv_fwd(const float* z, const float* bn_weight, const float* bn_bias, float* running_mean,
+                          float* running_var, const float* conv_weight, int B, int C, int H, int W, int K, int stride,
+                          int act, int training, float momentum, float eps, float* y, float* save_mean,
+                          float* save_invstd, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_dwconv(B, C, H, W, K, stride, "bn_dwconv_fwd")) return rc;
+    if (int rc = check_bn_act(B, C, H * W, act, "bn_dwconv_fwd")) return rc;
+    if (!z || !bn_weight || !bn_bias || !running_mean || !running_var || !conv_weight || !y || !save_mean || !save_invstd)
+        return fail(CABINET_ERR_INVALID_ARG, "bn_dwconv_fwd: null tensor pointer");
+    const size_t need = cabinet::bn_dwconv_fwd_workspace(B, C, H, W);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "bn_dwconv_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::bn_dwconv_fwd_run(z, bn_weight, bn_bias, running_mean, running_var, conv_weight, B, C, H, W,
+                                                 K, stride, act, training, momentum, eps, y, save_mean, save_invstd,
+                                                 workspace, static_cast<hipStream_t>(stream)),
+                      "bn_dwconv_fwd launch");
+}
+
+size_t cabinet_bn_dwconv_bwd_workspace_bytes(int B, int C, int H, int W, int K, int stride) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || !cabinet::dwconv_supported(K, stride)) return 0;
+    return cabinet::bn_dwconv_bwd_workspace(B, C, H, W, K);
+}
+
+int cabinet_bn_dwconv_bwd(const float* dy, const float* z, const float* bn_weight, const float* bn_bias,
+                          const float* save_mean, const float* save_invstd, const float* conv_weight, int B, int C,
+                          int H, int W, int K, int stride, int act, int training, float* dz, float* dbn_weight,
+                          float* dbn_bias, float* dconv_weight, void* workspace, size_t workspace_bytes,
+                          cabinet_stream_t stream) {
+    if (int rc = check_dwconv(B, C, H, W, K, stride, "bn_dwconv_bwd")) return rc;
+    if (int rc = check_bn_act(B, C, H * W, act, "bn_dwconv_bwd")) return rc;
+    if (!dy || !z || !bn_weight || !bn_bias || !save_mean || !save_invstd || !conv_weight || !dz || !dbn_weight ||
+        !dbn_bias || !dconv_weight)
+        return fail(CABINET_ERR_INVALID_ARG, "bn_dwconv_bwd: null tensor pointer");
+    const size_t need = cabinet::bn_dwconv_bwd_workspace(B, C, H, W, K);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "bn_dwconv_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::bn_dwconv_bwd_run(dy, z, bn_weight, bn_bias, save_mean, save_invstd, conv_weight, B, C, H,
+                                                 W, K, stride, act, training, dz, dbn_weight, dbn_bias, dconv_weight,
+                                                 workspace, static_cast<hipStream_t>(stream)),
+                      "bn_dwconv_bwd launch");
 }
 
 }  // extern "C"

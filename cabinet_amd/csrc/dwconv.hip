@@ -16,6 +16,7 @@
 //         tap is used exactly once per quad with compile-time offsets (these kernels are VALU-bound, not HBM-bound:
 //         the first, generic form spent ~100 instructions per pixel on parity masks and clamps)
 // No atomics anywhere: bitwise reproducible (MIOpen's naive backward is, too; its wrw GEMM path is not).
+#include "act.hpp"
 #include "common.hpp"
 
 namespace cabinet {
@@ -31,7 +32,7 @@ static int dw_tile_w(int w) { return w > 32 ? 64 : w > 16 ? 32 : w > 8 ? 16 : 8;
 
 template <int K, int S>
 __global__ __launch_bounds__(DW_T) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                           DwShape s, int TW, int tiles_x, int tiles_y,
+                                                           DwShape s, int TW, int tiles_x, int tiles_y, BnFold f,
                                                            float* __restrict__ y) {
     constexpr int PAD = K / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -42,9 +43,19 @@ __global__ __launch_bounds__(DW_T) void dwconv_fwd_kernel(const float* __restric
     const int in_h = (TH - 1) * S + K, in_w = (TW - 1) * S + K;
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
     const float* xp = x + (size_t)plane * s.H * s.W;
-    for (int i = threadIdx.x; i < in_h * in_w; i += DW_T) {
-        const int r = i / in_w, q = i - r * in_w, iy = iy0 + r, ix = ix0 + q;
-        smem[i] = (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W) ? xp[(size_t)iy * s.W + ix] : 0.f;
+    if (f.mean) {  // the input is act(bn(z)): evaluated while staging; the zero padding is that of the activated map
+        const float mu = f.mean[c], inv = f.invstd[c], gam = f.weight[c], bet = f.bias[c];
+        for (int i = threadIdx.x; i < in_h * in_w; i += DW_T) {
+            const int r = i / in_w, q = i - r * in_w, iy = iy0 + r, ix = ix0 + q;
+            smem[i] = (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W)
+                          ? act_fwd(fmaf((xp[(size_t)iy * s.W + ix] - mu) * inv, gam, bet), f.act)
+                          : 0.f;
+        }
+    } else {
+        for (int i = threadIdx.x; i < in_h * in_w; i += DW_T) {
+            const int r = i / in_w, q = i - r * in_w, iy = iy0 + r, ix = ix0 + q;
+            smem[i] = (iy >= 0 && iy < s.H && ix >= 0 && ix < s.W) ? xp[(size_t)iy * s.W + ix] : 0.f;
+        }
     }
     float w[K][K];
 #pragma unroll
@@ -99,16 +110,29 @@ __device__ __forceinline__ void dw_reduce_partials(const float (&pw)[KK], float*
     }
 }
 
+// With a folded BatchNorm the backward kernels also (i) rebuild their x operand a = act(bn(z)) from z and (ii) turn
+// the input gradient da they produce into the BatchNorm-backward partial sums of this tile,
+// sum du and sum du * xhat with du = da * act'(u): the BatchNorm's own reduce pass over (da, z) disappears.
+__device__ __forceinline__ float block_sum_dw(float v, float* red4) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+    __syncthreads();
+    return t;
+}
+
 // stride 1: with the flipped filter wf[a][b] = w[K-1-a][K-1-b] the input gradient is the SAME stencil as forward,
 // applied to dy (pad K/2), and dw[K-1-a][K-1-b] = sum x[y][x] * dy[y-p+a][x-p+b]: one staged dy tile (+halo),
 // a thread owns 4 vertically adjacent pixels, every LDS row it loads feeds up to K of them -- no masks.
 template <int K>
 __global__ __launch_bounds__(DW_T) void dwconv_bwd_s1_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ wgt, DwShape s, int TW, int tiles_x,
-                                                              int tiles_y, float* __restrict__ dx,
-                                                              float* __restrict__ part) {
+                                                              int tiles_y, BnFold f, float* __restrict__ dx,
+                                                              float* __restrict__ part, float* __restrict__ bnpart) {
     constexpr int PAD = K / 2, KK = K * K;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red4[4];
     const int TH = DW_OUT / TW;
     const int ntile = tiles_x * tiles_y;
     const int tile = blockIdx.x % ntile, plane = blockIdx.x / ntile;
@@ -132,10 +156,21 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s1_kernel(const float* __rest
     const int xx = x0 + tx;
     const float* xp = x + (size_t)plane * s.H * s.W;
     float xv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float xh[4], dact[4];  // folded BatchNorm: xhat and act'(u) of the thread's pixels
+    float mu = 0.f, inv = 1.f, gam = 1.f, bet = 0.f;
+    if (f.mean) mu = f.mean[c], inv = f.invstd[c], gam = f.weight[c], bet = f.bias[c];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int yy = y0 + tq * 4 + j;
-        xv[j] = (yy < s.H && xx < s.W) ? xp[(size_t)yy * s.W + xx] : 0.f;
+        const bool live = yy < s.H && xx < s.W;
+        xv[j] = live ? xp[(size_t)yy * s.W + xx] : 0.f;
+        xh[j] = 0.f, dact[j] = 0.f;
+        if (f.mean) {
+            xh[j] = (xv[j] - mu) * inv;
+            const float u = fmaf(xh[j], gam, bet);
+            xv[j] = live ? act_fwd(u, f.act) : 0.f;
+            dact[j] = live ? act_grad(u, f.act) : 0.f;
+        }
     }
     float pw[KK];
 #pragma unroll
@@ -164,6 +199,21 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s1_kernel(const float* __rest
         const int yy = y0 + tq * 4 + j;
         if (yy < s.H && xx < s.W) dxp[(size_t)yy * s.W + xx] = acc[j];
     }
+    if (f.mean) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float du = acc[j] * dact[j];
+            s1 += du, s2 = fmaf(du, xh[j], s2);
+        }
+        s1 = block_sum_dw(s1, red4);
+        s2 = block_sum_dw(s2, red4);
+        if (threadIdx.x == 0) {
+            const int nt = s.B * ntile;
+            bnpart[(size_t)c * nt + b * ntile + tile] = s1;
+            bnpart[((size_t)s.C + c) * nt + b * ntile + tile] = s2;
+        }
+    }
     dw_reduce_partials<KK>(pw, red, part + ((size_t)c * (s.B * ntile) + (size_t)b * ntile + tile) * KK);
 }
 
@@ -173,9 +223,10 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s1_kernel(const float* __rest
 template <int K>
 __global__ __launch_bounds__(DW_T) void dwconv_bwd_s2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ wgt, DwShape s, int TW, int tiles_x,
-                                                              int tiles_y, float* __restrict__ dx,
-                                                              float* __restrict__ part) {
+                                                              int tiles_y, BnFold f, float* __restrict__ dx,
+                                                              float* __restrict__ part, float* __restrict__ bnpart) {
     constexpr int PAD = K / 2, KK = K * K;
+    __shared__ float red4[4];
     // smallest / largest dy offset (py + PAD - ky) / 2 over the exact divisions: K=3 -> 0..1, K=5 -> -1..1
     constexpr int OLO = (K == 3) ? 0 : -1, OHI = 1, NO = OHI - OLO + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,14 +261,23 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s2_kernel(const float* __rest
     float pw[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) pw[t] = 0.f;
+    float mu = 0.f, inv = 1.f, gam = 1.f, bet = 0.f, s1 = 0.f, s2 = 0.f;
+    if (f.mean) mu = f.mean[c], inv = f.invstd[c], gam = f.weight[c], bet = f.bias[c];
 #pragma unroll
     for (int py = 0; py < 2; ++py) {
         const int yy = y0 + 2 * tn + py;
-        float xv[2], acc[2] = {0.f, 0.f};
+        float xv[2], xh[2] = {0.f, 0.f}, dact[2] = {0.f, 0.f}, acc[2] = {0.f, 0.f};
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
             const int xx = x0 + 2 * tm + px;
-            xv[px] = (yy < s.H && xx < s.W) ? xp[(size_t)yy * s.W + xx] : 0.f;
+            const bool live = yy < s.H && xx < s.W;
+            xv[px] = live ? xp[(size_t)yy * s.W + xx] : 0.f;
+            if (f.mean) {
+                xh[px] = (xv[px] - mu) * inv;
+                const float u = fmaf(xh[px], gam, bet);
+                xv[px] = live ? act_fwd(u, f.act) : 0.f;
+                dact[px] = live ? act_grad(u, f.act) : 0.f;
+            }
         }
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
@@ -237,6 +297,17 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s2_kernel(const float* __rest
         for (int px = 0; px < 2; ++px) {
             const int xx = x0 + 2 * tm + px;
             if (yy < s.H && xx < s.W) dxp[(size_t)yy * s.W + xx] = acc[px];
+            const float du = acc[px] * dact[px];
+            s1 += du, s2 = fmaf(du, xh[px], s2);
+        }
+    }
+    if (f.mean) {
+        s1 = block_sum_dw(s1, red4);
+        s2 = block_sum_dw(s2, red4);
+        if (threadIdx.x == 0) {
+            const int nt = s.B * ntile;
+            bnpart[(size_t)c * nt + b * ntile + tile] = s1;
+            bnpart[((size_t)s.C + c) * nt + b * ntile + tile] = s2;
         }
     }
     dw_reduce_partials<KK>(pw, red, part + ((size_t)c * (s.B * ntile) + (size_t)b * ntile + tile) * KK);
@@ -268,54 +339,126 @@ size_t dwconv_bwd_workspace(int B, int C, int H, int W, int K) {
     return align_up((size_t)C * B * ceil_div(W, TW) * ceil_div(H, TH) * K * K * sizeof(float), 256);
 }
 
+static int bwd_tiles(int H, int W) {
+    const int TW = dw_tile_w(W), TH = DW_OUT / TW;
+    return ceil_div(W, TW) * ceil_div(H, TH);
+}
+
 template <int K, int S>
-static hipError_t fwd_launch(const float* x, const float* w, const DwShape& s, float* y, hipStream_t stream) {
+static hipError_t fwd_launch(const float* x, const float* w, const DwShape& s, const BnFold& f, float* y,
+                             hipStream_t stream) {
     const int TW = dw_tile_w(s.Wo), TH = DW_OUT / TW;
     const int tiles_x = ceil_div(s.Wo, TW), tiles_y = ceil_div(s.Ho, TH);
     const size_t lds = (size_t)((TH - 1) * S + K) * ((TW - 1) * S + K) * sizeof(float);
     hipLaunchKernelGGL((dwconv_fwd_kernel<K, S>), dim3((unsigned)((size_t)s.B * s.C * tiles_x * tiles_y)), dim3(DW_T), lds,
-                       stream, x, w, s, TW, tiles_x, tiles_y, y);
+                       stream, x, w, s, TW, tiles_x, tiles_y, f, y);
     return hipGetLastError();
 }
 
 template <int K, int S>
-static hipError_t bwd_launch(const float* dy, const float* x, const float* w, const DwShape& s, float* dx, float* dw,
-                             void* ws, hipStream_t stream) {
+static hipError_t bwd_launch(const float* dy, const float* x, const float* w, const DwShape& s, const BnFold& f,
+                             float* dx, float* dw, float* part, float* bnpart, hipStream_t stream) {
     const int TW = dw_tile_w(s.W), TH = DW_OUT / TW;
     const int tiles_x = ceil_div(s.W, TW), tiles_y = ceil_div(s.H, TH);
     const size_t tile_floats = S == 1 ? (size_t)(TH + K - 1) * (TW + K - 1) : (size_t)(TH / 2 + 2) * (TW / 2 + 2);
     const size_t lds = (tile_floats + (size_t)K * K * (DW_T + 8)) * sizeof(float);
-    float* part = static_cast<float*>(ws);
     const dim3 grid((unsigned)((size_t)s.B * s.C * tiles_x * tiles_y));
     if (S == 1)
-        hipLaunchKernelGGL((dwconv_bwd_s1_kernel<K>), grid, dim3(DW_T), lds, stream, dy, x, w, s, TW, tiles_x, tiles_y, dx,
-                           part);
+        hipLaunchKernelGGL((dwconv_bwd_s1_kernel<K>), grid, dim3(DW_T), lds, stream, dy, x, w, s, TW, tiles_x, tiles_y, f,
+                           dx, part, bnpart);
     else
-        hipLaunchKernelGGL((dwconv_bwd_s2_kernel<K>), grid, dim3(DW_T), lds, stream, dy, x, w, s, TW, tiles_x, tiles_y, dx,
-                           part);
+        hipLaunchKernelGGL((dwconv_bwd_s2_kernel<K>), grid, dim3(DW_T), lds, stream, dy, x, w, s, TW, tiles_x, tiles_y, f,
+                           dx, part, bnpart);
     hipLaunchKernelGGL(dwconv_dw_finalize_kernel, dim3(s.C * K * K), dim3(256), 0, stream, part, s.B * tiles_x * tiles_y,
                        K * K, dw);
     return hipGetLastError();
+}
+
+static hipError_t fwd_dispatch(const float* x, const float* w, const DwShape& s, int K, int S, const BnFold& f, float* y,
+                               hipStream_t stream) {
+    if (K == 3 && S == 1) return fwd_launch<3, 1>(x, w, s, f, y, stream);
+    if (K == 3 && S == 2) return fwd_launch<3, 2>(x, w, s, f, y, stream);
+    if (K == 5 && S == 1) return fwd_launch<5, 1>(x, w, s, f, y, stream);
+    return fwd_launch<5, 2>(x, w, s, f, y, stream);
+}
+
+static hipError_t bwd_dispatch(const float* dy, const float* x, const float* w, const DwShape& s, int K, int S,
+                               const BnFold& f, float* dx, float* dw, float* part, float* bnpart, hipStream_t stream) {
+    if (K == 3 && S == 1) return bwd_launch<3, 1>(dy, x, w, s, f, dx, dw, part, bnpart, stream);
+    if (K == 3 && S == 2) return bwd_launch<3, 2>(dy, x, w, s, f, dx, dw, part, bnpart, stream);
+    if (K == 5 && S == 1) return bwd_launch<5, 1>(dy, x, w, s, f, dx, dw, part, bnpart, stream);
+    return bwd_launch<5, 2>(dy, x, w, s, f, dx, dw, part, bnpart, stream);
 }
 
 hipError_t dwconv_fwd_run(const float* x, const float* w, int B, int C, int H, int W, int K, int S, float* y,
                           hipStream_t stream) {
     DwShape s{B, C, H, W, 0, 0};
     out_size(H, W, K, S, s.Ho, s.Wo);
-    if (K == 3 && S == 1) return fwd_launch<3, 1>(x, w, s, y, stream);
-    if (K == 3 && S == 2) return fwd_launch<3, 2>(x, w, s, y, stream);
-    if (K == 5 && S == 1) return fwd_launch<5, 1>(x, w, s, y, stream);
-    return fwd_launch<5, 2>(x, w, s, y, stream);
+    return fwd_dispatch(x, w, s, K, S, BnFold{nullptr, nullptr, nullptr, nullptr, 0}, y, stream);
 }
 
 hipError_t dwconv_bwd_run(const float* dy, const float* x, const float* w, int B, int C, int H, int W, int K, int S,
                           float* dx, float* dw, void* ws, hipStream_t stream) {
     DwShape s{B, C, H, W, 0, 0};
     out_size(H, W, K, S, s.Ho, s.Wo);
-    if (K == 3 && S == 1) return bwd_launch<3, 1>(dy, x, w, s, dx, dw, ws, stream);
-    if (K == 3 && S == 2) return bwd_launch<3, 2>(dy, x, w, s, dx, dw, ws, stream);
-    if (K == 5 && S == 1) return bwd_launch<5, 1>(dy, x, w, s, dx, dw, ws, stream);
-    return bwd_launch<5, 2>(dy, x, w, s, dx, dw, ws, stream);
+    return bwd_dispatch(dy, x, w, s, K, S, BnFold{nullptr, nullptr, nullptr, nullptr, 0}, dx, dw, static_cast<float*>(ws),
+                        nullptr, stream);
+}
+
+// ---- BatchNorm2d (+activation) -> depthwise convolution as one operator (reference mobilenetv3.py:135-143:
+// `BatchNorm2d(hidden), act, depthwise Conv2d`): the normalised, activated tensor is never written or re-read.
+//   fwd : BN statistics of z (one read), then the convolution reads z again and normalises while staging
+//   bwd : the convolution's backward rebuilds a = act(bn(z)) from z, writes da and the BN-backward partial sums;
+//         the BN-backward dx pass (da, z -> dz) finishes.  6 passes over the (B,C,H,W) tensor instead of 10.
+struct BnDwWs {
+    size_t bn, part, bnpart, coef, da, total;
+};
+static BnDwWs bn_dw_layout(int B, int C, int H, int W, int K) {
+    BnDwWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const int nt = B * bwd_tiles(H, W);
+    w.bn = take(bn_act_workspace(B, C, H * W));
+    w.part = take((size_t)C * nt * K * K * sizeof(float));
+    w.bnpart = take((size_t)2 * C * nt * sizeof(float));
+    w.coef = take((size_t)2 * C * sizeof(float));
+    w.da = take((size_t)B * C * H * W * sizeof(float));
+    w.total = off;
+    return w;
+}
+size_t bn_dwconv_fwd_workspace(int B, int C, int H, int W) { return bn_act_workspace(B, C, H * W); }
+size_t bn_dwconv_bwd_workspace(int B, int C, int H, int W, int K) { return bn_dw_layout(B, C, H, W, K).total; }
+
+hipError_t bn_dwconv_fwd_run(const float* z, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                             const float* w, int B, int C, int H, int W, int K, int S, int act, int training,
+                             float momentum, float eps, float* y, float* save_mean, float* save_invstd, void* ws,
+                             hipStream_t stream) {
+    hipError_t e = bn_stats_run(z, run_mean, run_var, B, C, H * W, training, momentum, eps, save_mean, save_invstd, ws,
+                                stream);
+    if (e != hipSuccess) return e;
+    DwShape s{B, C, H, W, 0, 0};
+    out_size(H, W, K, S, s.Ho, s.Wo);
+    return fwd_dispatch(z, w, s, K, S, BnFold{save_mean, save_invstd, bn_w, bn_b, act}, y, stream);
+}
+
+hipError_t bn_dwconv_bwd_run(const float* dy, const float* z, const float* bn_w, const float* bn_b,
+                             const float* save_mean, const float* save_invstd, const float* w, int B, int C, int H,
+                             int W, int K, int S, int act, int training, float* dz, float* dbn_w, float* dbn_b,
+                             float* dw, void* ws, hipStream_t stream) {
+    const BnDwWs L = bn_dw_layout(B, C, H, W, K);
+    char* base = static_cast<char*>(ws);
+    auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
+    DwShape s{B, C, H, W, 0, 0};
+    out_size(H, W, K, S, s.Ho, s.Wo);
+    hipError_t e = bwd_dispatch(dy, z, w, s, K, S, BnFold{save_mean, save_invstd, bn_w, bn_b, act}, at(L.da), dw,
+                                at(L.part), at(L.bnpart), stream);
+    if (e != hipSuccess) return e;
+    return bn_bwd_tail_run(at(L.bnpart), B * bwd_tiles(H, W), at(L.da), z, bn_w, bn_b, save_mean, save_invstd, B, C,
+                           H * W, act, training, dz, dbn_w, dbn_b, at(L.coef), stream);
 }
 
 }  // namespace cabinet

@@ -768,3 +768,59 @@ def gate_act(x, gate, act=None):
     if gate.shape != x.shape[:2]:
         raise RuntimeError(f"gate_act: gate {tuple(gate.shape)} does not match x {tuple(x.shape)}")
     return _GateAct.apply(x, gate, _ACT_CODES[act])
+
+
+# --------------------------------------------------------------------------- BatchNorm (+act) -> depthwise conv, fused
+
+
+class _BnActDwConv(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, z, bn_w, bn_b, run_mean, run_var, conv_w, act, stride, training, momentum, eps):
+        lib = _lib.load()
+        z, bn_w, bn_b, cw = _f32c(z), _f32c(bn_w), _f32c(bn_b), _f32c(conv_w)
+        B, C, H, W = z.shape
+        K = cw.shape[-1]
+        Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=z.device)
+        mean = torch.empty(C, dtype=torch.float32, device=z.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=z.device)
+        ws, nbytes = _workspace(lib.cabinet_bn_dwconv_fwd_workspace_bytes(B, C, H, W), z.device)
+        with torch.cuda.device(z.device):
+            rc = lib.cabinet_bn_dwconv_fwd(_ptr(z), _ptr(bn_w), _ptr(bn_b), _ptr(run_mean), _ptr(run_var), _ptr(cw), B, C,
+                                           H, W, K, stride, act, int(training), float(momentum), float(eps), _ptr(y),
+                                           _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream_handle(z.device))
+        _lib.check(rc, "cabinet_bn_dwconv_fwd")
+        fn_ctx.save_for_backward(z, bn_w, bn_b, cw, mean, invstd)
+        fn_ctx.meta = (act, stride, bool(training))
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        z, bn_w, bn_b, cw, mean, invstd = fn_ctx.saved_tensors
+        act, stride, training = fn_ctx.meta
+        g = _f32c(g)
+        B, C, H, W = z.shape
+        K = cw.shape[-1]
+        dz, dbw, dbb, dcw = torch.empty_like(z), torch.empty_like(bn_w), torch.empty_like(bn_b), torch.empty_like(cw)
+        ws, nbytes = _workspace(lib.cabinet_bn_dwconv_bwd_workspace_bytes(B, C, H, W, K, stride), z.device)
+        with torch.cuda.device(z.device):
+            rc = lib.cabinet_bn_dwconv_bwd(_ptr(g), _ptr(z), _ptr(bn_w), _ptr(bn_b), _ptr(mean), _ptr(invstd), _ptr(cw), B,
+                                           C, H, W, K, stride, act, int(training), _ptr(dz), _ptr(dbw), _ptr(dbb),
+                                           _ptr(dcw), _ptr(ws), nbytes, _stream_handle(z.device))
+        _lib.check(rc, "cabinet_bn_dwconv_bwd")
+        return dz, dbw, dbb, None, None, dcw, None, None, None, None, None
+
+
+def bn_act_dwconv(z, bn, act, conv):
+    """conv(act(bn(z))) for a depthwise ``conv`` (see dwconv_supported) on a device tensor, without materialising the
+    normalised tensor (reference mobilenetv3.py:135-143)."""
+    if not z.is_cuda:
+        raise RuntimeError("bn_act_dwconv: device tensors only")
+    if act not in _ACT_CODES:
+        raise RuntimeError(f"bn_act_dwconv: unknown activation {act!r}")
+    training, momentum = _bn_step(bn)
+    return _BnActDwConv.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, _ACT_CODES[act],
+                              conv.stride[0], training, momentum, bn.eps)

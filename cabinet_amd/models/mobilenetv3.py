@@ -82,7 +82,7 @@ class _FusedSequential(nn.Sequential):
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        from ..functional import bn_act, dwconv, dwconv_supported, gate_act
+        from ..functional import bn_act, bn_act_dwconv, dwconv, dwconv_supported, gate_act
 
         layers = list(self)
         i = 0
@@ -90,7 +90,12 @@ class _FusedSequential(nn.Sequential):
             m = layers[i]
             if isinstance(m, nn.BatchNorm2d):
                 nxt = layers[i + 1] if i + 1 < len(layers) else None
-                if isinstance(nxt, nn.ReLU):
+                act = "relu" if isinstance(nxt, nn.ReLU) else "hardswish" if isinstance(nxt, HardSwish) else None
+                nxt2 = layers[i + 2] if act and i + 2 < len(layers) else None
+                if isinstance(nxt2, nn.Conv2d) and nxt2.groups > 1 and dwconv_supported(nxt2):
+                    # BN + activation folded into the depthwise convolution's loader: the activated map never exists
+                    x, i = bn_act_dwconv(x, m, act, nxt2), i + 3
+                elif isinstance(nxt, nn.ReLU):
                     x, i = bn_act(x, m, "relu"), i + 2
                 elif isinstance(nxt, HardSwish):
                     x, i = bn_act(x, m, "hardswish"), i + 2

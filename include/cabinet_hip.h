@@ -301,6 +301,28 @@ size_t cabinet_gate_act_bwd_workspace_bytes(int B, int C, int P);
 int cabinet_gate_act_bwd(const float* dy, const float* x, const float* gate, int B, int C, int P, int act,
                          float* dx, float* dgate, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * BatchNorm2d (+activation) followed by a depthwise convolution, as one operator.
+ * Replaces `nn.BatchNorm2d(hidden), act, depthwise nn.Conv2d` of the MBConv block, src/models/mobilenetv3.py:135-143:
+ * the normalised, activated (B,C,H,W) tensor is neither written nor re-read -- the convolution normalises while it
+ * stages its input tile, and its backward emits the BatchNorm-backward partial sums.
+ *   z: the BatchNorm input (B,C,H,W); bn_* / running_* / save_* / act / training / momentum / eps as cabinet_bn_act;
+ *   conv_weight (C,1,K,K), K, stride as cabinet_dwconv.   y (B,C,Ho,Wo).
+ *   bwd: dy (B,C,Ho,Wo) -> dz (B,C,H,W), dbn_weight, dbn_bias (C), dconv_weight (C,1,K,K).  Deterministic.
+ * ------------------------------------------------------------------------- */
+size_t cabinet_bn_dwconv_fwd_workspace_bytes(int B, int C, int H, int W);
+int cabinet_bn_dwconv_fwd(const float* z, const float* bn_weight, const float* bn_bias,
+                          float* running_mean, float* running_var, const float* conv_weight,
+                          int B, int C, int H, int W, int K, int stride, int act, int training,
+                          float momentum, float eps, float* y, float* save_mean, float* save_invstd,
+                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+size_t cabinet_bn_dwconv_bwd_workspace_bytes(int B, int C, int H, int W, int K, int stride);
+int cabinet_bn_dwconv_bwd(const float* dy, const float* z, const float* bn_weight, const float* bn_bias,
+                          const float* save_mean, const float* save_invstd, const float* conv_weight,
+                          int B, int C, int H, int W, int K, int stride, int act, int training,
+                          float* dz, float* dbn_weight, float* dbn_bias, float* dconv_weight,
+                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
