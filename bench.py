@@ -92,6 +92,18 @@ _PMC_KEYS = {  # bench kernel group -> rocprofv3 kernel names whose HBM traffic 
 }
 
 
+_PMC_GROUP_KEYS = {  # bench kernel group -> (group of profiles/r01_pmc_groups.json, kernels summed, one launch each)
+    "bn_act_fwd": ("bn_act", ["cabinet::bn_act_stats_kernel", "cabinet::bn_act_finalize_kernel",
+                              "cabinet::bn_act_apply_kernel"]),
+    "bn_act_bwd": ("bn_act", ["cabinet::bn_act_bwd_reduce_kernel", "cabinet::bn_act_bwd_finalize_kernel",
+                              "cabinet::bn_act_bwd_dx_kernel"]),
+    "ohem_up_fwd": ("ohem", ["cabinet::ohem_up_fwd_kernel<8>"]),
+    "ohem_up_bwd": ("ohem", ["cabinet::ohem_up_bwd_x_kernel<8>", "cabinet::ohem_up_bwd_y_kernel"]),
+    "cab_local_fwd": ("cab", ["cabinet::cab_local_fwd_kernel"]),
+    "cab_local_bwd": ("cab", ["cabinet::cab_local_bwd_kernel"]),
+}
+
+
 def measured_traffic(group, batch, size):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_counters.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 calibration in that file).
@@ -101,6 +113,18 @@ def measured_traffic(group, batch, size):
         return None
     pmc = json.load(open(path))
     total = 0.0
+    if group in _PMC_GROUP_KEYS:
+        gpath = os.path.join(ROOT, "profiles", "r01_pmc_groups.json")
+        if not os.path.exists(gpath):
+            return None
+        gname, kernels = _PMC_GROUP_KEYS[group]
+        g = json.load(open(gpath)).get(gname, {})
+        for name in kernels:
+            c = g.get(name)
+            if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                return None
+            total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        return round(total)
     if not _PMC_KEYS.get(group):
         return None
     for name in _PMC_KEYS[group]:

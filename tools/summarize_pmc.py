@@ -32,4 +32,12 @@ def main(root):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    m = main(sys.argv[1])
+    if len(sys.argv) > 2:  # also write / update a JSON file: {kernel name up to "(": {counter: per-launch average}}
+        import json
+
+        out = json.load(open(sys.argv[2])) if os.path.exists(sys.argv[2]) else {}
+        for kern, cs in m.items():
+            out.setdefault(kern.split("(")[0].replace("void ", ""), {}).update({c: v for c, (v, n) in cs.items()})
+        json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+        print("updated", sys.argv[2])
