@@ -58,6 +58,9 @@ SIGNATURES = {
     "cabinet_bn_dwconv_fwd": (_INT, [_PTR] * 6 + [_INT] * 8 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_bn_dwconv_bwd_workspace_bytes": (_SZ, [_INT] * 6),
     "cabinet_bn_dwconv_bwd": (_INT, [_PTR] * 7 + [_INT] * 8 + [_PTR] * 4 + [_PTR, _SZ, _PTR]),
+    "cabinet_stem_conv_fwd": (_INT, [_PTR] * 2 + [_INT] * 3 + [_PTR] + [_PTR]),
+    "cabinet_stem_conv_wrw_workspace_bytes": (_SZ, [_INT] * 3),
+    "cabinet_stem_conv_wrw": (_INT, [_PTR] * 2 + [_INT] * 3 + [_PTR] + [_PTR, _SZ, _PTR]),
     "cabinet_dwconv_supported": (_INT, [_INT] * 2),
     "cabinet_dwconv_fwd": (_INT, [_PTR] * 2 + [_INT] * 6 + [_PTR] + [_PTR]),
     "cabinet_dwconv_bwd_workspace_bytes": (_SZ, [_INT] * 6),

@@ -80,6 +80,11 @@ hipError_t bn_dwconv_bwd_run(const float* dy, const float* z, const float* bn_w,
                              const float* save_mean, const float* save_invstd, const float* w, int B, int C, int H,
                              int W, int K, int S, int act, int training, float* dz, float* dbn_w, float* dbn_b,
                              float* dw, void* ws, hipStream_t stream);
+// stem_conv.hip
+size_t stem_conv_wrw_workspace(int B, int H, int W);
+hipError_t stem_conv_fwd_run(const float* x, const float* w, int B, int H, int W, float* y, hipStream_t stream);
+hipError_t stem_conv_wrw_run(const float* dy, const float* x, int B, int H, int W, float* dw, void* ws,
+                             hipStream_t stream);
 // ohem.hip
 int ohem_blocks(int B, int H, int W);
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
@@ -676,6 +681,35 @@ int cabinet_bn_dwconv_bwd(const float* dy, const float* z, const float* bn_weigh
                                                  W, K, stride, act, training, dz, dbn_weight, dbn_bias, dconv_weight,
                                                  workspace, static_cast<hipStream_t>(stream)),
                       "bn_dwconv_bwd launch");
+}
+
+// ------------------------------------------------------ 7x7 stride-2 stem convolution
+static int check_stem(int B, int H, int W, const char* who) {
+    if (B <= 0 || H <= 0 || W <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if ((long long)B * ((H + 1) / 2) > 2147483647LL / 4) return fail(CABINET_ERR_UNSUPPORTED, "%s: grid too large", who);
+    return CABINET_OK;
+}
+
+int cabinet_stem_conv_fwd(const float* x, const float* weight, int B, int H, int W, float* y, cabinet_stream_t stream) {
+    if (int rc = check_stem(B, H, W, "stem_conv_fwd")) return rc;
+    if (!x || !weight || !y) return fail(CABINET_ERR_INVALID_ARG, "stem_conv_fwd: null tensor pointer");
+    return hip_status(cabinet::stem_conv_fwd_run(x, weight, B, H, W, y, static_cast<hipStream_t>(stream)),
+                      "stem_conv_fwd launch");
+}
+
+size_t cabinet_stem_conv_wrw_workspace_bytes(int B, int H, int W) {
+    return B > 0 && H > 0 && W > 0 ? cabinet::stem_conv_wrw_workspace(B, H, W) : 0;
+}
+
+int cabinet_stem_conv_wrw(const float* dy, const float* x, int B, int H, int W, float* dw, void* workspace,
+                          size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_stem(B, H, W, "stem_conv_wrw")) return rc;
+    if (!dy || !x || !dw) return fail(CABINET_ERR_INVALID_ARG, "stem_conv_wrw: null tensor pointer");
+    const size_t need = cabinet::stem_conv_wrw_workspace(B, H, W);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "stem_conv_wrw: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::stem_conv_wrw_run(dy, x, B, H, W, dw, workspace, static_cast<hipStream_t>(stream)),
+                      "stem_conv_wrw launch");
 }
 
 }  // extern "C"

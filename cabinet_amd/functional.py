@@ -824,3 +824,54 @@ def bn_act_dwconv(z, bn, act, conv):
     training, momentum = _bn_step(bn)
     return _BnActDwConv.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, _ACT_CODES[act],
                               conv.stride[0], training, momentum, bn.eps)
+
+
+# --------------------------------------------------------------------------- 7x7 stride-2 stem convolution (K9)
+
+
+def stem_conv_supported(conv):
+    """True for the spatial branch's first convolution (reference cabinet.py:111): 3 -> 64, 7x7, stride 2, pad 3."""
+    return (conv.in_channels == 3 and conv.out_channels == 64 and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.padding_mode == "zeros")
+
+
+class _StemConv(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, weight):
+        lib = _lib.load()
+        x, w = _f32c(x), _f32c(weight)
+        B, _, H, W = x.shape
+        y = torch.empty((B, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_stem_conv_fwd(_ptr(x), _ptr(w), B, H, W, _ptr(y), _stream_handle(x.device))
+        _lib.check(rc, "cabinet_stem_conv_fwd")
+        fn_ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, w = fn_ctx.saved_tensors
+        g = _f32c(g)
+        B, _, H, W = x.shape
+        dx = None
+        if fn_ctx.needs_input_grad[0]:  # not the training step (the input is the image); served by ATen when asked for
+            dx = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        dw = torch.empty_like(w)
+        ws, nbytes = _workspace(lib.cabinet_stem_conv_wrw_workspace_bytes(B, H, W), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_stem_conv_wrw(_ptr(g), _ptr(x), B, H, W, _ptr(dw), _ptr(ws), nbytes,
+                                           _stream_handle(x.device))
+        _lib.check(rc, "cabinet_stem_conv_wrw")
+        return dx, dw
+
+
+def stem_conv(x, conv):
+    """The spatial branch's 7x7/2 stem convolution on a device tensor (see stem_conv_supported)."""
+    if not x.is_cuda:
+        raise RuntimeError("stem_conv: device tensors only")
+    return _StemConv.apply(x, conv.weight)

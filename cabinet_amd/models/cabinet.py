@@ -19,7 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import batched_bn_counters, bn_act, ffm_fused, ffm_fused_upsampled
+from ..functional import (batched_bn_counters, bn_act, ffm_fused, ffm_fused_upsampled, stem_conv,
+                          stem_conv_supported)
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -43,7 +44,10 @@ class ConvBNReLU(nn.Module):
         self.init_weight()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.conv(x)
+        if x.is_cuda and x.shape[1] == 3 and stem_conv_supported(self.conv):
+            x = stem_conv(x, self.conv)  # K9: the 7x7/2 image stem without NHWC round trips
+        else:
+            x = self.conv(x)
         if x.is_cuda:  # K7: BatchNorm + ReLU in one streaming pass pair instead of two library launches
             return bn_act(x, self.bn, "relu")
         return self.relu(self.bn(x))

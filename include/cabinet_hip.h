@@ -323,6 +323,17 @@ int cabinet_bn_dwconv_bwd(const float* dy, const float* z, const float* bn_weigh
                           float* dz, float* dbn_weight, float* dbn_bias, float* dconv_weight,
                           void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * The 7x7 stride-2 padding-3 stem convolution of the spatial branch: x (B,3,H,W) -> y (B,64,Ho,Wo), no bias.
+ * Replaces the nn.Conv2d inside ConvBNReLU(3, 64, kernel_size=7, stride=2, padding=3), src/models/cabinet.py:111
+ * (forward cabinet.py:42).  weight (64,3,7,7).  The input is the image: only the weight gradient exists.
+ *   wrw : dw (64,3,7,7) = sum over images and pixels of dy (x) patches; ordered slab sum, deterministic.
+ * ------------------------------------------------------------------------- */
+int cabinet_stem_conv_fwd(const float* x, const float* weight, int B, int H, int W, float* y, cabinet_stream_t stream);
+size_t cabinet_stem_conv_wrw_workspace_bytes(int B, int H, int W);
+int cabinet_stem_conv_wrw(const float* dy, const float* x, int B, int H, int W, float* dw,
+                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
