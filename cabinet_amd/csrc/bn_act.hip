@@ -24,14 +24,6 @@ constexpr int BA_T = 256;
 constexpr int BA_V = 8;                     // float4 per thread and chunk
 constexpr int BA_CHUNK = BA_T * 4 * BA_V;   // 8192 elements
 
-__device__ __forceinline__ float ba_block_sum(float v, float* red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float t = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    return t;
-}
 
 // chunk of a plane -> registers (zeros past the end); returns the number of valid elements of the chunk
 __device__ __forceinline__ int ba_load(const float* __restrict__ row, int P, int lo, f32x4 (&v)[BA_V]) {
@@ -85,14 +77,14 @@ __global__ __launch_bounds__(BA_T) void bn_act_stats_kernel(const float* __restr
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < BA_V; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = ba_block_sum(s, red) / (float)cnt;
+    const float mean = block_sum_256(s, red) / (float)cnt;
     float m2 = 0.f;
 #pragma unroll
     for (int i = 0; i < BA_V; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (ba_valid(P, ch * BA_CHUNK, i, e)) m2 += (v[i][e] - mean) * (v[i][e] - mean);
-    m2 = ba_block_sum(m2, red);
+    m2 = block_sum_256(m2, red);
     if (threadIdx.x == 0) {
         const int nt = B * chunks, tile = b * chunks + ch;
         part[(size_t)c * nt + tile] = mean;
@@ -191,8 +183,8 @@ __global__ __launch_bounds__(BA_T) void bn_act_bwd_reduce_kernel(const float* __
             const float du = vg[i][e] * act_grad(fmaf(xh, gam, bet), act);
             s1 += du, s2 += du * xh;
         }
-    s1 = ba_block_sum(s1, red);
-    s2 = ba_block_sum(s2, red);
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red);
     if (threadIdx.x == 0) {
         const int nt = B * chunks, tile = b * chunks + ch;
         part[(size_t)c * nt + tile] = s1;
@@ -287,7 +279,7 @@ __global__ __launch_bounds__(BA_T) void gate_act_bwd_kernel(const float* __restr
             vg[i][e] = du * gt;
         }
     ba_store(dx + (size_t)row * P, P, ch * BA_CHUNK, vg);
-    s = ba_block_sum(s, red);
+    s = block_sum_256(s, red);
     if (threadIdx.x == 0) part[(size_t)row * chunks + ch] = s;
 }
 

@@ -47,22 +47,7 @@ static PyrGeom make_geom(const QkvShape& q) {
 __device__ __forceinline__ int bin_start(int r, int n, int s) { return (r * n) / s; }            // floor(r*n/s)
 __device__ __forceinline__ int bin_end(int r, int n, int s) { return ((r + 1) * n + s - 1) / s; }  // ceil((r+1)*n/s)
 
-// one axis of F.interpolate(mode="bilinear", align_corners=False)
-__device__ __forceinline__ void lerp_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
-    const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
-    i0 = min((int)src, in_size - 1);
-    i1 = min(i0 + 1, in_size - 1);
-    lam = src - (float)i0;
-}
 
-__device__ __forceinline__ float block_sum256(float v, float* red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float t = (red[0] + red[1]) + (red[2] + red[3]);
-    __syncthreads();
-    return t;
-}
 
 // ------------------------------------------------------------------------------- weight staging
 struct TrJob {
@@ -198,8 +183,8 @@ __global__ __launch_bounds__(256) void pyramid_add_kernel(const float* __restric
             const int s = g.s[i];
             int y0, y1, x0, x1;
             float ly, lx;
-            lerp_taps(oy, (float)s / (float)g.H, s, y0, y1, ly);
-            lerp_taps(ox, (float)s / (float)g.W, s, x0, x1, lx);
+            bilinear_taps(oy, (float)s / (float)g.H, s, y0, y1, ly);
+            bilinear_taps(ox, (float)s / (float)g.W, s, x0, x1, lx);
             const float* ti = t + g.off[i];
             acc += (1.f - ly) * ((1.f - lx) * ti[y0 * s + x0] + lx * ti[y0 * s + x1]) +
                    ly * ((1.f - lx) * ti[y1 * s + x0] + lx * ti[y1 * s + x1]);
@@ -232,7 +217,7 @@ __global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __res
         const int xs = cb - g.coff[i];
         int x0, x1;
         float lx;
-        lerp_taps(ox, (float)g.s[i] / (float)g.W, g.s[i], x0, x1, lx);
+        bilinear_taps(ox, (float)g.s[i] / (float)g.W, g.s[i], x0, x1, lx);
         wx[it] = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
     }
     for (int it = tid; it < g.NCB * g.H; it += 256) {
@@ -242,7 +227,7 @@ __global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __res
         const int ys = cb - g.coff[i];
         int y0, y1;
         float ly;
-        lerp_taps(oy, (float)g.s[i] / (float)g.H, g.s[i], y0, y1, ly);
+        bilinear_taps(oy, (float)g.s[i] / (float)g.H, g.s[i], y0, y1, ly);
         wy[it] = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
     }
     __syncthreads();
@@ -348,8 +333,8 @@ __global__ __launch_bounds__(256) void qkv_plane_bwd_kernel(const float* __restr
         dout[p] = dy;
         s1 += dy, s2 += dy * xh;
     }
-    s1 = block_sum256(s1, red);
-    s2 = block_sum256(s2, red);
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red);
     if (tid == 0) {
         bnpart[(size_t)m * B + b] = s1;
         bnpart[((size_t)2 * Kc + m) * B + b] = s2;

@@ -33,6 +33,25 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// sum over a 256-thread workgroup (4 waves), result in every thread; fixed order; red: 4 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
+}
+
+// one axis of F.interpolate(mode="bilinear", align_corners=False): source taps and the weight of the upper tap
+// (src = (dst + 0.5) * in/out - 0.5 clamped at 0, i1 = min(i0 + 1, in - 1))
+__device__ __forceinline__ void bilinear_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
+    const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
+    i0 = min((int)src, in_size - 1);
+    i1 = min(i0 + 1, in_size - 1);
+    lam = src - (float)i0;
+}
+
 // ---- buffer loads: wave-uniform descriptor + per-lane byte offset + SCALAR byte offset, so a strided
 // walk over NCHW rows costs one SALU multiply per load and no vector address arithmetic ----
 typedef __amdgpu_buffer_rsrc_t buf_rsrc;

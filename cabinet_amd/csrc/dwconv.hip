@@ -110,17 +110,9 @@ __device__ __forceinline__ void dw_reduce_partials(const float (&pw)[KK], float*
     }
 }
 
-// With a folded BatchNorm the backward kernels also (i) rebuild their x operand a = act(bn(z)) from z and (ii) turn
-// the input gradient da they produce into the BatchNorm-backward partial sums of this tile,
+// With a folded BatchNorm (BnFold, act.hpp) the backward kernels also (i) rebuild their x operand a = act(bn(z)) from z
+// and (ii) turn the input gradient da they produce into the BatchNorm-backward partial sums of this tile,
 // sum du and sum du * xhat with du = da * act'(u): the BatchNorm's own reduce pass over (da, z) disappears.
-__device__ __forceinline__ float block_sum_dw(float v, float* red4) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float t = (red4[0] + red4[1]) + (red4[2] + red4[3]);
-    __syncthreads();
-    return t;
-}
 
 // stride 1: with the flipped filter wf[a][b] = w[K-1-a][K-1-b] the input gradient is the SAME stencil as forward,
 // applied to dy (pad K/2), and dw[K-1-a][K-1-b] = sum x[y][x] * dy[y-p+a][x-p+b]: one staged dy tile (+halo),
@@ -206,8 +198,8 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s1_kernel(const float* __rest
             const float du = acc[j] * dact[j];
             s1 += du, s2 = fmaf(du, xh[j], s2);
         }
-        s1 = block_sum_dw(s1, red4);
-        s2 = block_sum_dw(s2, red4);
+        s1 = block_sum_256(s1, red4);
+        s2 = block_sum_256(s2, red4);
         if (threadIdx.x == 0) {
             const int nt = s.B * ntile;
             bnpart[(size_t)c * nt + b * ntile + tile] = s1;
@@ -302,8 +294,8 @@ __global__ __launch_bounds__(DW_T) void dwconv_bwd_s2_kernel(const float* __rest
         }
     }
     if (f.mean) {
-        s1 = block_sum_dw(s1, red4);
-        s2 = block_sum_dw(s2, red4);
+        s1 = block_sum_256(s1, red4);
+        s2 = block_sum_256(s2, red4);
         if (threadIdx.x == 0) {
             const int nt = s.B * ntile;
             bnpart[(size_t)c * nt + b * ntile + tile] = s1;

@@ -31,13 +31,6 @@ struct FfmShape {
 // G1 / G2:  D[m][p] = sum_k At[k][m] * Bm[k][p]   per image
 // =====================================================================================
 
-// one axis of F.interpolate(mode="bilinear", align_corners=False): source taps and weight of the upper tap
-__device__ __forceinline__ void bilinear_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
-    const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
-    i0 = min((int)src, in_size - 1);
-    i1 = min(i0 + 1, in_size - 1);
-    lam = src - (float)i0;
-}
 
 constexpr int GK_BK = 16;   // k-chunk
 constexpr int GK_NT = 128;  // pixels per tile (2 waves x 2 blocks x 32)
@@ -428,14 +421,6 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
         if (ox < rows && oy0 + j < cols) out[(size_t)(oy0 + j) * rows + ox] = tile[threadIdx.x][j];
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    return t;
-}
 
 // per (b,c) row of z: sum and sum of squares over the P pixels -> stat_part[2][C][B]
 // (a streaming pass over z, which is still Infinity-Cache resident right after the GEMM wrote it; this

@@ -17,12 +17,6 @@
 namespace cabinet {
 
 
-__device__ __forceinline__ void lin_taps(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
-    const float src = fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
-    i0 = min((int)src, in_size - 1);
-    i1 = min(i0 + 1, in_size - 1);
-    lam = src - (float)i0;
-}
 
 // One workgroup per output row (b, oy).  The two source rows are lerped vertically into LDS once (coalesced
 // reads), so a pixel's C logits cost 2 LDS reads each instead of 4 scattered global loads.
@@ -39,7 +33,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
     const float* low_b = low + (size_t)b * C * plane;
     int y0, y1;
     float ly;
-    lin_taps(oy, rh, Hl, y0, y1, ly);
+    bilinear_taps(oy, rh, Hl, y0, y1, ly);
     for (int i = threadIdx.x; i < C * Wl; i += 256) {
         const int c = i / Wl, xs = i - c * Wl;
         const float* p = low_b + (size_t)c * plane;
@@ -55,7 +49,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
         if (lb != (long long)ignore_lb) {
             int x0, x1;
             float lx;
-            lin_taps(ox, rw, Wl, x0, x1, lx);
+            bilinear_taps(ox, rw, Wl, x0, x1, lx);
             float x[CMAX], mx = -INFINITY, xl = 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
@@ -125,7 +119,7 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restr
     const float* low_b = low + (size_t)b * C * plane;
     int y0, y1;
     float ly;
-    lin_taps(oy, rh, Hl, y0, y1, ly);
+    bilinear_taps(oy, rh, Hl, y0, y1, ly);
     for (int i = threadIdx.x; i < C * nvx; i += 256) {
         const int c = i / nvx, q = i - c * nvx;
         const float* p = low_b + (size_t)c * plane;
@@ -136,7 +130,7 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restr
         const int ox = ox_lo + i;
         int x0, x1;
         float lx;
-        lin_taps(ox, rw, Wl, x0, x1, lx);
+        bilinear_taps(ox, rw, Wl, x0, x1, lx);
         const int gi = (i % R) * gplane + i / R;
         const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
         const long long lb = labels[pix];
@@ -179,7 +173,7 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restr
         for (int i = lo; i <= min(hi, nox - 1); ++i) {
             int x0, x1;
             float lx;
-            lin_taps(ox_lo + i, rw, Wl, x0, x1, lx);
+            bilinear_taps(ox_lo + i, rw, Wl, x0, x1, lx);
             // (x1 == x0 at the clamped right edge: both taps are the same column, weight 1 in total)
             const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
             acc = fmaf(wx, Gc[ph * gplane + q], acc);
@@ -202,7 +196,7 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_y_kernel(const float* __restr
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         int y0, y1;
         float ly;
-        lin_taps(oy, rh, Hl, y0, y1, ly);
+        bilinear_taps(oy, rh, Hl, y0, y1, ly);
         acc += ((y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f)) * src[(size_t)oy * Wl];
     }
     dlow[idx] = acc;
