@@ -61,6 +61,10 @@ SIGNATURES = {
     "cabinet_stem_conv_fwd": (_INT, [_PTR] * 2 + [_INT] * 3 + [_PTR] + [_PTR]),
     "cabinet_stem_conv_wrw_workspace_bytes": (_SZ, [_INT] * 3),
     "cabinet_stem_conv_wrw": (_INT, [_PTR] * 2 + [_INT] * 3 + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_pwconv_supported": (_INT, [_INT] * 3),
+    "cabinet_pwconv_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR]),
+    "cabinet_pwconv_bwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_pwconv_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
     "cabinet_dwconv_supported": (_INT, [_INT] * 2),
     "cabinet_dwconv_fwd": (_INT, [_PTR] * 2 + [_INT] * 6 + [_PTR] + [_PTR]),
     "cabinet_dwconv_bwd_workspace_bytes": (_SZ, [_INT] * 6),

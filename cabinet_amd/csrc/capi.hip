@@ -85,6 +85,12 @@ size_t stem_conv_wrw_workspace(int B, int H, int W);
 hipError_t stem_conv_fwd_run(const float* x, const float* w, int B, int H, int W, float* y, hipStream_t stream);
 hipError_t stem_conv_wrw_run(const float* dy, const float* x, int B, int H, int W, float* dw, void* ws,
                              hipStream_t stream);
+// pwconv.hip
+bool pwconv_supported(int Ci, int Co, int P);
+size_t pwconv_bwd_workspace(int B, int Ci, int Co, int P);
+hipError_t pwconv_fwd_run(const float* x, const float* w, int B, int Ci, int Co, int P, float* y, hipStream_t stream);
+hipError_t pwconv_bwd_run(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P, float* dx,
+                          float* dw, void* ws, hipStream_t stream);
 // ohem.hip
 int ohem_blocks(int B, int H, int W);
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
@@ -710,6 +716,41 @@ int cabinet_stem_conv_wrw(const float* dy, const float* x, int B, int H, int W, 
         return fail(CABINET_ERR_WORKSPACE, "stem_conv_wrw: workspace %zu < %zu bytes", workspace_bytes, need);
     return hip_status(cabinet::stem_conv_wrw_run(dy, x, B, H, W, dw, workspace, static_cast<hipStream_t>(stream)),
                       "stem_conv_wrw launch");
+}
+
+// ------------------------------------------------------ thin pointwise convolution
+static int check_pwconv(int B, int Ci, int Co, int P, const char* who) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || P <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if (!cabinet::pwconv_supported(Ci, Co, P))
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: Ci=%d, Co=%d (multiples of 8, <= 120, block product <= 8)", who, Ci, Co);
+    return CABINET_OK;
+}
+
+int cabinet_pwconv_supported(int Ci, int Co, int P) {
+    return Ci > 0 && Co > 0 && P > 0 && cabinet::pwconv_supported(Ci, Co, P) ? 1 : 0;
+}
+
+int cabinet_pwconv_fwd(const float* x, const float* w, int B, int Ci, int Co, int P, float* y, cabinet_stream_t stream) {
+    if (int rc = check_pwconv(B, Ci, Co, P, "pwconv_fwd")) return rc;
+    if (!x || !w || !y) return fail(CABINET_ERR_INVALID_ARG, "pwconv_fwd: null tensor pointer");
+    return hip_status(cabinet::pwconv_fwd_run(x, w, B, Ci, Co, P, y, static_cast<hipStream_t>(stream)),
+                      "pwconv_fwd launch");
+}
+
+size_t cabinet_pwconv_bwd_workspace_bytes(int B, int Ci, int Co, int P) {
+    if (B <= 0 || Ci <= 0 || Co <= 0 || P <= 0 || !cabinet::pwconv_supported(Ci, Co, P)) return 0;
+    return cabinet::pwconv_bwd_workspace(B, Ci, Co, P);
+}
+
+int cabinet_pwconv_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P, float* dx,
+                       float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_pwconv(B, Ci, Co, P, "pwconv_bwd")) return rc;
+    if (!dy || !x || !w) return fail(CABINET_ERR_INVALID_ARG, "pwconv_bwd: null tensor pointer");
+    const size_t need = cabinet::pwconv_bwd_workspace(B, Ci, Co, P);
+    if (dw && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "pwconv_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::pwconv_bwd_run(dy, x, w, B, Ci, Co, P, dx, dw, workspace, static_cast<hipStream_t>(stream)),
+                      "pwconv_bwd launch");
 }
 
 }  // extern "C"

@@ -875,3 +875,61 @@ def stem_conv(x, conv):
     if not x.is_cuda:
         raise RuntimeError("stem_conv: device tensors only")
     return _StemConv.apply(x, conv.weight)
+
+
+# --------------------------------------------------------------------------- thin pointwise convolution (K10)
+
+
+def pwconv_supported(conv, x):
+    """True for the bias-free stride-1 1x1 convolutions the streaming kernels cover (thin channel counts on large
+    planes, reference mobilenetv3.py:128-131,144-151); others stay with MIOpen, which is as fast there."""
+    if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.bias is None and conv.dilation == (1, 1)):
+        return False
+    P = x.shape[2] * x.shape[3]
+    # measured on MI355X (tools/time_pwconv*.py): the streaming kernels win where the layer is HBM-bound -- planes of
+    # >= 256 x 256 pixels with <= 96 channels either side (2.5x forward / input gradient, 1.3x weight gradient)
+    return (P >= 65536 and conv.in_channels <= 96 and conv.out_channels <= 96
+            and bool(_lib.load().cabinet_pwconv_supported(conv.in_channels, conv.out_channels, P)))
+
+
+class _PwConv(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, weight):
+        lib = _lib.load()
+        x = _f32c(x)
+        Co, Ci = weight.shape[0], weight.shape[1]
+        w2 = _f32c(weight).view(Co, Ci)
+        B, P = x.shape[0], x.shape[2] * x.shape[3]
+        y = torch.empty((B, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_pwconv_fwd(_ptr(x), _ptr(w2), B, Ci, Co, P, _ptr(y), _stream_handle(x.device))
+        _lib.check(rc, "cabinet_pwconv_fwd")
+        fn_ctx.save_for_backward(x, w2)
+        fn_ctx.w_shape = weight.shape
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, w2 = fn_ctx.saved_tensors
+        g = _f32c(g)
+        Co, Ci = w2.shape
+        B, P = x.shape[0], x.shape[2] * x.shape[3]
+        dx = torch.empty_like(x) if fn_ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w2) if fn_ctx.needs_input_grad[1] else None
+        ws, nbytes = _workspace(lib.cabinet_pwconv_bwd_workspace_bytes(B, Ci, Co, P), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_pwconv_bwd(_ptr(g), _ptr(x), _ptr(w2), B, Ci, Co, P, _ptr(dx), _ptr(dw), _ptr(ws), nbytes,
+                                        _stream_handle(x.device))
+        _lib.check(rc, "cabinet_pwconv_bwd")
+        return dx, (dw.view(fn_ctx.w_shape) if dw is not None else None)
+
+
+def pwconv(x, conv):
+    """Thin pointwise convolution of a device tensor with the weights of ``conv`` (see pwconv_supported)."""
+    if not x.is_cuda:
+        raise RuntimeError("pwconv: device tensors only")
+    return _PwConv.apply(x, conv.weight)

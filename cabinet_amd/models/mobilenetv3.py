@@ -82,7 +82,8 @@ class _FusedSequential(nn.Sequential):
     def forward(self, x):
         if not x.is_cuda:
             return super().forward(x)
-        from ..functional import bn_act, bn_act_dwconv, dwconv, dwconv_supported, gate_act
+        from ..functional import (bn_act, bn_act_dwconv, dwconv, dwconv_supported, gate_act, pwconv,
+                                  pwconv_supported)
 
         layers = list(self)
         i = 0
@@ -105,6 +106,8 @@ class _FusedSequential(nn.Sequential):
                 nxt = layers[i + 1] if i + 1 < len(layers) else None
                 act = "relu" if isinstance(nxt, nn.ReLU) else "hardswish" if isinstance(nxt, HardSwish) else None
                 x, i = gate_act(x, m.gate(x), act), i + (2 if act else 1)
+            elif isinstance(m, nn.Conv2d) and m.groups == 1 and pwconv_supported(m, x):
+                x, i = pwconv(x, m), i + 1  # thin 1x1 conv on a large plane: streaming MFMA kernel, no NHWC copies
             elif isinstance(m, nn.Conv2d) and m.groups > 1 and dwconv_supported(m):
                 x, i = dwconv(x, m), i + 1  # depthwise stencil kernel (MIOpen only has its naive solver here)
             else:

@@ -334,6 +334,19 @@ size_t cabinet_stem_conv_wrw_workspace_bytes(int B, int H, int W);
 int cabinet_stem_conv_wrw(const float* dy, const float* x, int B, int H, int W, float* dw,
                           void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Thin pointwise (1x1, bias-free, stride 1) convolution on large planes, streaming form:
+ * y (B,Co,P) = W (Co,Ci) . x (B,Ci,P).  Replaces the nn.Conv2d(kernel_size=1) of the first MBConv blocks,
+ * src/models/mobilenetv3.py:128-131,144-151, where the product is HBM-bound (Ci, Co <= 120).
+ * Supported: Ci, Co multiples of 8, <= 120, ceil(Ci/32)*ceil(Co/32) <= 8 (cabinet_pwconv_supported).
+ *   bwd: dx = W^T dy (skipped if NULL), dw = sum_{b,p} dy (x) x (skipped if NULL); ordered slab sum, deterministic.
+ * ------------------------------------------------------------------------- */
+int cabinet_pwconv_supported(int Ci, int Co, int P);
+int cabinet_pwconv_fwd(const float* x, const float* w, int B, int Ci, int Co, int P, float* y, cabinet_stream_t stream);
+size_t cabinet_pwconv_bwd_workspace_bytes(int B, int Ci, int Co, int P);
+int cabinet_pwconv_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P,
+                       float* dx, float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
