@@ -233,6 +233,51 @@ def kernel_rooflines(batch, size, iters):
     del xb, gb, xg, yb
     torch.cuda.empty_cache()
 
+    # ---- K8: depthwise 3x3 stride-2 convolution of features.2 (64 ch, size/2 -> size/4) with its BatchNorm + HardSwish
+    # folded in; algorithmic bytes: fwd read z twice (statistics, convolution) + write y; bwd read dy, z (convolution),
+    # read da, z + write dz (BatchNorm dx) + write da
+    import torch.nn as nn
+
+    conv = nn.Conv2d(Cb, Cb, 3, 2, 1, groups=Cb, bias=False).to(dev)
+    bn = nn.BatchNorm2d(Cb).to(dev).train()
+    zb = torch.randn(B, Cb, hb, hb, generator=g).to(dev).requires_grad_(True)
+    yb = Fh.bn_act_dwconv(zb, bn, "hardswish", conv)
+    gy = torch.randn(yb.shape, generator=g).to(dev)
+    nz, ny = 4.0 * zb.numel(), 4.0 * yb.numel()
+    ms = time_kernel(lambda: Fh.bn_act_dwconv(zb.detach(), bn, "hardswish", conv), iters)
+    entry("bn_dwconv_fwd (K8: BN stats + 3x3/2 depthwise conv with BN+HardSwish folded in)", ms, 28.0 * yb.numel(),
+          2 * nz + ny, "hbm")
+    ms = time_kernel(lambda: torch.autograd.grad(yb, (zb, conv.weight, bn.weight), gy, retain_graph=True), iters)
+    entry("bn_dwconv_bwd (K8: dx + dw + BN partial sums, then BN dx)", ms, 60.0 * yb.numel(), ny + 5 * nz, "hbm")
+    del zb, yb, gy
+    torch.cuda.empty_cache()
+
+    # ---- K9: 7x7/2 stem convolution (3 -> 64) at the image size; 2*B*Ho*Wo*64*147 FLOP each way
+    stem = nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(dev)
+    img = torch.randn(B, 3, size, size, generator=g).to(dev)
+    ys = Fh.stem_conv(img, stem)
+    gs = torch.randn(ys.shape, generator=g).to(dev)
+    fl_s = 2.0 * ys.numel() * 147
+    ms = time_kernel(lambda: Fh.stem_conv(img, stem), iters)
+    entry("stem_conv_fwd (K9: 7x7/2, patch gather from LDS)", ms, fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
+    ms = time_kernel(lambda: torch.autograd.grad(ys, stem.weight, gs, retain_graph=True), iters)
+    entry("stem_conv_wrw (K9: contraction over pixels, ordered slabs)", ms, fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
+    del img, ys, gs
+    torch.cuda.empty_cache()
+
+    # ---- K10: thin pointwise convolution 16 -> 64 on the size/2 plane (features.2 expansion)
+    pw = nn.Conv2d(16, 64, 1, bias=False).to(dev)
+    xp = torch.randn(B, 16, hb, hb, generator=g).to(dev).requires_grad_(True)
+    yp = Fh.pwconv(xp, pw)
+    gp = torch.randn(yp.shape, generator=g).to(dev)
+    nx, nyp = 4.0 * xp.numel(), 4.0 * yp.numel()
+    ms = time_kernel(lambda: Fh.pwconv(xp.detach(), pw), iters)
+    entry("pwconv_fwd (K10: streaming 1x1 conv 16->64)", ms, 2.0 * yp.numel() * 16, nx + nyp, "hbm")
+    ms = time_kernel(lambda: torch.autograd.grad(yp, (xp, pw.weight), gp, retain_graph=True), iters)
+    entry("pwconv_bwd (K10: dx stream + wgrad slabs)", ms, 4.0 * yp.numel() * 16, 2 * nyp + 2 * nx, "hbm")
+    del xp, yp, gp
+    torch.cuda.empty_cache()
+
     # ---- f3: OHEM-CE fused with the final x8 upsample (per head)
     ncls = 8
     lowl = torch.randn(B, ncls, size // 8, size // 8, generator=g).to(dev)
