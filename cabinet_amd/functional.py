@@ -1,11 +1,17 @@
 """Autograd operators of the hot path, backed by libcabinet_hip.so on HIP tensors.
 
-``cab_attention``  replaces reference src/models/cab.py:149-154
-``ffm_fused``      replaces reference src/models/cabinet.py:142-153
+``cab_attention``   replaces reference src/models/cab.py:149-154          (K1 / K2)
+``cab_qkv``         cab.py:137-146 (projections, BN, PSP)                 (K6)     ``conv1x1``  cab.py:155
+``cab_local``       cab.py:182-184 and :213-216                           (K5)
+``ffm_fused``       src/models/cabinet.py:142-153                         (K3 / K4; ``ffm_fused_upsampled`` + :228-230)
+``bn_act``          cabinet.py:42-44 and every BatchNorm2d(+act) pair     (K7)     ``gate_act``  mobilenetv3.py:79-83
+``dwconv`` / ``bn_act_dwconv``   mobilenetv3.py:118-126,135-143           (K8)
+``stem_conv``       cabinet.py:111                                        (K9)     ``pwconv``   mobilenetv3.py:128-131
+OHEM head           src/utils/loss.py:51-80 + cabinet.py:240-245          (``ohem_up_*``, used by cabinet_amd.loss)
 
 Device tensors ALWAYS go through the hand-written HIP kernels (RuntimeError if the
 library is absent or rejects the shape -- never a silent PyTorch fallback).  Host (CPU)
-tensors take the composite ATen path below so the modules stay usable for
+tensors take the composite ATen path of the modules so they stay usable for
 checkpoint surgery, EMA copies and CPU unit tests, exactly like any nn.Module.
 """
 

@@ -5,8 +5,10 @@ Drop-in for ``from src.models.cabinet import CABiNet``: same constructor signatu
 sub-module names and ``state_dict`` keys.  On HIP tensors ``FeatureFusionModule.forward``
 (reference cabinet.py:142-153) runs as the fused gfx950 pipeline behind
 :func:`cabinet_amd.functional.ffm_fused` and the CAB attention core as one fused
-kernel (see ``cab.py``); backbone, spatial branch and heads stay on stock PyTorch-ROCm
-as BASELINE.json's north_star prescribes.
+kernel (see ``cab.py``); ``ConvBNReLU`` runs its BatchNorm + ReLU through the fused streaming op
+(and the spatial branch's 7x7/2 stem through its own MFMA kernel).  The dense 3x3 and wide 1x1
+convolutions of backbone, spatial branch and heads stay on stock PyTorch-ROCm (MIOpen), as
+BASELINE.json's north_star prescribes.
 """
 
 from __future__ import annotations

@@ -9,8 +9,9 @@ import torch.nn.functional as F
 from cabinet_amd import _lib
 from cabinet_amd.functional import _ptr, _stream_handle, _workspace
 
-LAYERS = [(16, 16, 512), (16, 64, 512), (64, 24, 256), (24, 72, 256), (72, 40, 128), (40, 240, 128), (80, 480, 64),
-          (672, 112, 64), (160, 960, 32)]
+LAYERS = [(72, 40, 128), (40, 120, 128), (120, 40, 128), (40, 240, 128), (240, 80, 64), (80, 200, 64), (200, 80, 64),
+          (80, 184, 64), (184, 80, 64), (80, 480, 64), (480, 112, 64), (112, 672, 64), (672, 112, 64), (672, 160, 32),
+          (160, 960, 32), (960, 160, 32)]
 
 
 def timeit(fn, iters=10):
@@ -41,11 +42,13 @@ for ci, co, h in LAYERS:
     f = timeit(lambda: lib.cabinet_conv1x1_fwd(_ptr(x), _ptr(w), B, ci, co, P, _ptr(y), _ptr(ws), nb, st))
     d = timeit(lambda: lib.cabinet_conv1x1_bwd(_ptr(g), _ptr(x), _ptr(w), B, ci, co, P, _ptr(dx), None, _ptr(ws), nb, st))
     q = timeit(lambda: lib.cabinet_conv1x1_bwd(_ptr(g), _ptr(x), _ptr(w), B, ci, co, P, None, _ptr(dw), _ptr(ws), nb, st))
-    xs = x.clone().requires_grad_(True)
-    w4 = w.view(co, ci, 1, 1).clone().requires_grad_(True)
-    sf = timeit(lambda: F.conv2d(xs, w4))
-    ys = F.conv2d(xs, w4)
-    sb = timeit(lambda: torch.autograd.grad(ys, (xs, w4), g, retain_graph=True))
+    w4 = w.view(co, ci, 1, 1)
+    cb = torch.ops.aten.convolution_backward
+    sf = timeit(lambda: F.conv2d(x, w4))
+    sdx = timeit(lambda: cb(g, x, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False]))
+    sdw = timeit(lambda: cb(g, x, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+    sb = sdx + sdw
     mb = 4.0 * B * P / 1e6
-    print(f"{ci:4d}->{co:4d} @{h:3d}: ours fwd {f:7.1f} dx {d:7.1f} dw {q:7.1f} | stock fwd {sf:7.1f} bwd {sb:7.1f} us | "
-          f"ideal@5TB/s fwd {mb * (ci + co) / 5:6.1f} dx {mb * (ci + co) / 5:6.1f} dw {mb * (ci + co) / 5:6.1f}")
+    gf = 2.0 * B * P * ci * co / 1e9
+    print(f"{ci:4d}->{co:4d} @{h:3d}: ours fwd {f:6.1f} dx {d:6.1f} dw {q:6.1f} | stock fwd {sf:6.1f} dx {sdx:6.1f} dw {sdw:6.1f} us | "
+          f"HBM@5TB/s {mb * (ci + co) / 5:5.1f} us, MFMA@100TF {gf * 10:5.1f} us per product")
