@@ -169,6 +169,25 @@ class TestOhemCELoss:
         loss.backward()
         assert torch.isfinite(logits.grad).all()
 
+    def test_host_tensors_take_the_composite_path_of_the_fused_head(self):
+        """forward_upsampled / ohem_upsampled_pair on CPU tensors == interpolate + forward (reference cabinet.py:240-245
+        followed by loss.py:38-80); TrainStep(fused_loss=True) on the host therefore equals the reference recipe."""
+        from cabinet_amd.loss import ohem_upsampled_pair
+
+        torch.manual_seed(3)
+        low_a = torch.randn(2, 5, 8, 8, requires_grad=True)
+        low_b = torch.randn(2, 5, 8, 8, requires_grad=True)
+        labels = torch.randint(0, 5, (2, 32, 32))
+        crit_a, crit_b = OhemCELoss(0.7, 64, 255), OhemCELoss(0.7, 64, 255)
+        up = lambda t: torch.nn.functional.interpolate(t, size=(32, 32), mode="bilinear", align_corners=False)  # noqa: E731
+        want = crit_a(up(low_a), labels) + crit_b(up(low_b), labels)
+        got = ohem_upsampled_pair(crit_a, low_a, crit_b, low_b, labels, (32, 32))
+        assert torch.allclose(got, want, atol=1e-6)
+        single = crit_a.forward_upsampled(low_a, labels, (32, 32)) + crit_b.forward_upsampled(low_b, labels)
+        assert torch.allclose(single, want, atol=1e-6)
+        got.backward()
+        assert low_a.grad is not None and torch.isfinite(low_a.grad).all()
+
     def test_class_weights_and_no_criteria_submodule(self):
         w = torch.ones(19)
         w[0] = 2.0
