@@ -85,26 +85,25 @@ class _FusedSequential(nn.Sequential):
         from ..functional import (bn_act, bn_act_dwconv, dwconv, dwconv_supported, gate_act, pwconv,
                                   pwconv_supported)
 
-        layers = list(self)
+        layers = [m for m in self if not isinstance(m, nn.Identity)]  # placeholders of the non-SE blocks: no-ops
+
+        def act_of(m):
+            return "relu" if isinstance(m, nn.ReLU) else "hardswish" if isinstance(m, HardSwish) else None
+
         i = 0
         while i < len(layers):
             m = layers[i]
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
             if isinstance(m, nn.BatchNorm2d):
-                nxt = layers[i + 1] if i + 1 < len(layers) else None
-                act = "relu" if isinstance(nxt, nn.ReLU) else "hardswish" if isinstance(nxt, HardSwish) else None
+                act = act_of(nxt)
                 nxt2 = layers[i + 2] if act and i + 2 < len(layers) else None
                 if isinstance(nxt2, nn.Conv2d) and nxt2.groups > 1 and dwconv_supported(nxt2):
                     # BN + activation folded into the depthwise convolution's loader: the activated map never exists
                     x, i = bn_act_dwconv(x, m, act, nxt2), i + 3
-                elif isinstance(nxt, nn.ReLU):
-                    x, i = bn_act(x, m, "relu"), i + 2
-                elif isinstance(nxt, HardSwish):
-                    x, i = bn_act(x, m, "hardswish"), i + 2
                 else:
-                    x, i = bn_act(x, m, None), i + 1
+                    x, i = bn_act(x, m, act), i + (2 if act else 1)
             elif isinstance(m, SELayer):  # channel gate fused with the activation behind it
-                nxt = layers[i + 1] if i + 1 < len(layers) else None
-                act = "relu" if isinstance(nxt, nn.ReLU) else "hardswish" if isinstance(nxt, HardSwish) else None
+                act = act_of(nxt)
                 x, i = gate_act(x, m.gate(x), act), i + (2 if act else 1)
             elif isinstance(m, nn.Conv2d) and m.groups == 1 and pwconv_supported(m, x):
                 x, i = pwconv(x, m), i + 1  # thin 1x1 conv on a large plane: streaming MFMA kernel, no NHWC copies
