@@ -49,7 +49,7 @@ SIGNATURES = {
     "cabinet_conv1x1_bwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_conv1x1_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
     "cabinet_bn_act_workspace_bytes": (_SZ, [_INT] * 3),
-    "cabinet_bn_act_fwd": (_INT, [_PTR] * 5 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
+    "cabinet_bn_act_fwd": (_INT, [_PTR] * 6 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_bn_act_bwd": (_INT, [_PTR] * 6 + [_INT] * 5 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_gate_act_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR]),
     "cabinet_gate_act_bwd_workspace_bytes": (_SZ, [_INT] * 3),

@@ -148,8 +148,9 @@ __global__ __launch_bounds__(BA_T) void bn_act_finalize_kernel(const float* __re
 __global__ __launch_bounds__(BA_T) void bn_act_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ weight,
-                                                             const float* __restrict__ bias, int C, int P, int chunks,
-                                                             int act, float* __restrict__ y) {
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ residual, int C, int P,
+                                                             int chunks, int act, float* __restrict__ y) {
     const int row = blockIdx.x / chunks, ch = blockIdx.x - row * chunks, c = row % C;
     const float mu = mean[c], inv = invstd[c], gam = weight[c], bet = bias[c];
     f32x4 v[BA_V];
@@ -158,6 +159,12 @@ __global__ __launch_bounds__(BA_T) void bn_act_apply_kernel(const float* __restr
     for (int i = 0; i < BA_V; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] = act_fwd(fmaf((v[i][e] - mu) * inv, gam, bet), act);
+    if (residual) {  // the identity shortcut of an MBConv block (mobilenetv3.py:158), added in the same pass
+        f32x4 r[BA_V];
+        ba_load(residual + (size_t)row * P, P, ch * BA_CHUNK, r);
+#pragma unroll
+        for (int i = 0; i < BA_V; ++i) v[i] += r[i];
+    }
     ba_store(y + (size_t)row * P, P, ch * BA_CHUNK, v);
 }
 
@@ -309,12 +316,13 @@ hipError_t bn_stats_run(const float* x, float* running_mean, float* running_var,
 }
 
 hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias, float* running_mean,
-                          float* running_var, int B, int C, int P, int act, int training, float momentum, float eps,
-                          float* y, float* save_mean, float* save_invstd, void* ws, hipStream_t stream) {
+                          float* running_var, const float* residual, int B, int C, int P, int act, int training,
+                          float momentum, float eps, float* y, float* save_mean, float* save_invstd, void* ws,
+                          hipStream_t stream) {
     const int chunks = ba_chunks(P), grid = B * C * chunks;
     (void)bn_stats_run(x, running_mean, running_var, B, C, P, training, momentum, eps, save_mean, save_invstd, ws, stream);
-    hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid), dim3(BA_T), 0, stream, x, save_mean, save_invstd, weight, bias, C,
-                       P, chunks, act, y);
+    hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid), dim3(BA_T), 0, stream, x, save_mean, save_invstd, weight, bias,
+                       residual, C, P, chunks, act, y);
     return hipGetLastError();
 }
 

@@ -54,8 +54,9 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
 // bn_act.hip
 size_t bn_act_workspace(int B, int C, int P);
 hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias, float* running_mean,
-                          float* running_var, int B, int C, int P, int act, int training, float momentum, float eps,
-                          float* y, float* save_mean, float* save_invstd, void* ws, hipStream_t stream);
+                          float* running_var, const float* residual, int B, int C, int P, int act, int training,
+                          float momentum, float eps, float* y, float* save_mean, float* save_invstd, void* ws,
+                          hipStream_t stream);
 hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, const float* bias,
                           const float* save_mean, const float* save_invstd, int B, int C, int P, int act, int training,
                           float* dx, float* dweight, float* dbias, void* ws, hipStream_t stream);
@@ -551,7 +552,7 @@ size_t cabinet_bn_act_workspace_bytes(int B, int C, int P) {
 }
 
 int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
-                       int B, int C, int P, int act, int training, float momentum, float eps, float* y,
+                       const float* residual, int B, int C, int P, int act, int training, float momentum, float eps, float* y,
                        float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
                        cabinet_stream_t stream) {
     if (int rc = check_bn_act(B, C, P, act, "bn_act_fwd")) return rc;
@@ -560,7 +561,7 @@ int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias, f
     const size_t need = cabinet::bn_act_workspace(B, C, P);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "bn_act_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
-    return hip_status(cabinet::bn_act_fwd_run(x, weight, bias, running_mean, running_var, B, C, P, act, training,
+    return hip_status(cabinet::bn_act_fwd_run(x, weight, bias, running_mean, running_var, residual, B, C, P, act, training,
                                               momentum, eps, y, save_mean, save_invstd, workspace,
                                               static_cast<hipStream_t>(stream)),
                       "bn_act_fwd launch");

@@ -627,9 +627,10 @@ _ACT_CODES = {None: 0, "none": 0, "relu": 1, "hardswish": 2}
 class _BnAct(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(fn_ctx, x, weight, bias, run_mean, run_var, act, training, momentum, eps):
+    def forward(fn_ctx, x, weight, bias, run_mean, run_var, act, training, momentum, eps, residual=None):
         lib = _lib.load()
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        residual = _f32c(residual) if residual is not None else None
         B, C = x.shape[0], x.shape[1]
         P = x[0, 0].numel()
         y = torch.empty_like(x)
@@ -637,7 +638,7 @@ class _BnAct(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws, nbytes = _workspace(lib.cabinet_bn_act_workspace_bytes(B, C, P), x.device)
         with torch.cuda.device(x.device):
-            rc = lib.cabinet_bn_act_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(run_mean), _ptr(run_var), B, C, P, act,
+            rc = lib.cabinet_bn_act_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(run_mean), _ptr(run_var), _ptr(residual), B, C, P, act,
                                         int(training), float(momentum), float(eps), _ptr(y), _ptr(mean), _ptr(invstd),
                                         _ptr(ws), nbytes, _stream_handle(x.device))
         _lib.check(rc, "cabinet_bn_act_fwd")
@@ -660,20 +661,23 @@ class _BnAct(torch.autograd.Function):
                                         fn_ctx.act, int(fn_ctx.training), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
                                         nbytes, _stream_handle(x.device))
         _lib.check(rc, "cabinet_bn_act_bwd")
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, (g if fn_ctx.needs_input_grad[9] else None)
 
 
-def bn_act(x, bn, act=None):
-    """act(bn(x)) for a device tensor; ``bn`` is the nn.BatchNorm2d owning parameters and running buffers
-    (updated in place in training mode), ``act`` one of None / "relu" / "hardswish"
-    (reference cabinet.py:42-44, mobilenetv3.py:86-99)."""
+def bn_act(x, bn, act=None, residual=None):
+    """act(bn(x)) [+ residual] for a device tensor; ``bn`` is the nn.BatchNorm2d owning parameters and running
+    buffers (updated in place in training mode), ``act`` one of None / "relu" / "hardswish"
+    (reference cabinet.py:42-44, mobilenetv3.py:86-99); ``residual`` is the MBConv identity shortcut
+    (mobilenetv3.py:158), added in the same pass."""
     if not x.is_cuda:
         raise RuntimeError("bn_act: device tensors only (host tensors take the composite ATen path)")
     if act not in _ACT_CODES:
         raise RuntimeError(f"bn_act: unknown activation {act!r}")
     training, momentum = _bn_step(bn)
+    if residual is not None and residual.shape != x.shape:
+        raise RuntimeError(f"bn_act: residual {tuple(residual.shape)} does not match x {tuple(x.shape)}")
     return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _ACT_CODES[act], training, momentum,
-                        bn.eps)
+                        bn.eps, residual)
 
 
 # --------------------------------------------------------------------------- depthwise convolution (K8)

@@ -79,9 +79,10 @@ class _FusedSequential(nn.Sequential):
     BatchNorm2d -> ReLU / HardSwish pair -- and every lone BatchNorm2d -- through the fused HIP op, and the
     depthwise convolutions through the HIP stencil kernels."""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         if not x.is_cuda:
-            return super().forward(x)
+            y = super().forward(x)
+            return y if residual is None else residual + y
         from ..functional import (bn_act, bn_act_dwconv, dwconv, dwconv_supported, gate_act, pwconv,
                                   pwconv_supported)
 
@@ -101,7 +102,10 @@ class _FusedSequential(nn.Sequential):
                     # BN + activation folded into the depthwise convolution's loader: the activated map never exists
                     x, i = bn_act_dwconv(x, m, act, nxt2), i + 3
                 else:
-                    x, i = bn_act(x, m, act), i + (2 if act else 1)
+                    last = i + (2 if act else 1) >= len(layers)  # the block's closing BatchNorm takes the shortcut
+                    x, i = bn_act(x, m, act, residual if last else None), i + (2 if act else 1)
+                    if last:
+                        residual = None
             elif isinstance(m, SELayer):  # channel gate fused with the activation behind it
                 act = act_of(nxt)
                 x, i = gate_act(x, m.gate(x), act), i + (2 if act else 1)
@@ -111,7 +115,7 @@ class _FusedSequential(nn.Sequential):
                 x, i = dwconv(x, m), i + 1  # depthwise stencil kernel (MIOpen only has its naive solver here)
             else:
                 x, i = m(x), i + 1
-        return x
+        return x if residual is None else residual + x
 
 
 def conv_3x3_bn(inp, oup, stride):
@@ -147,8 +151,9 @@ class InvertedResidual(nn.Module):
         self.conv = _FusedSequential(*layers)
 
     def forward(self, x):
-        y = self.conv(x)
-        return x + y if self.identity else y
+        if self.identity:
+            return self.conv(x, residual=x)  # x + conv(x); on device the add rides on the closing BatchNorm's pass
+        return self.conv(x)
 
 
 class MobileNetV3(nn.Module):

@@ -254,7 +254,9 @@ int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, 
  * Replaces the bn -> relu tail of ConvBNReLU.forward, src/models/cabinet.py:42-44, and the same
  * BatchNorm2d -> ReLU / HardSwish pairs at cabinet.py:59-63,67-68 and src/models/mobilenetv3.py:86-99,118-152
  * (HardSwish: x * relu6(x + 3) / 6, mobilenetv3.py:48-50,63-65).
- *   act: 0 = none, 1 = ReLU, 2 = HardSwish.   y = act(weight * xhat + bias), xhat = (x - mean) * invstd
+ *   act: 0 = none, 1 = ReLU, 2 = HardSwish.   y = act(weight * xhat + bias) [+ residual], xhat = (x - mean) * invstd
+ *   (residual: the identity shortcut `x + self.conv(x)` of an MBConv block, mobilenetv3.py:158, added in the same
+ *   pass; its gradient is dy itself, so backward is unchanged)
  *   training != 0: batch statistics (biased variance; unbiased into running_var; running buffers updated with
  *   `momentum`), save_mean / save_invstd (C) receive them; training == 0: running statistics.
  *   bwd needs only x, save_mean, save_invstd (the pre-activation is recomputed):
@@ -264,7 +266,7 @@ int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, 
  * ------------------------------------------------------------------------- */
 size_t cabinet_bn_act_workspace_bytes(int B, int C, int P);
 int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias,
-                       float* running_mean, float* running_var,
+                       float* running_mean, float* running_var, const float* residual /* nullable, (B,C,P) */,
                        int B, int C, int P, int act, int training, float momentum, float eps,
                        float* y, float* save_mean, float* save_invstd,
                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);

@@ -127,3 +127,26 @@ def test_batched_bn_counters_match_per_module_increments():
     assert [int(b.num_batches_tracked) for b in bns] == [2, 1, 1]
     bn_act(x, bns[1], None)  # outside the context: immediate
     assert int(bns[1].num_batches_tracked) == 2
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_with_residual_shortcut(training):
+    """y = bn(x) + r in one pass (the MBConv identity shortcut, mobilenetv3.py:158) vs fp64 autograd; dr == dy."""
+    from cabinet_amd.functional import bn_act
+
+    g0 = torch.Generator().manual_seed(6)
+    shape = (2, 24, 33, 31)
+    bn = torch.nn.BatchNorm2d(24)
+    x, r, g = (torch.randn(*shape, generator=g0) for _ in range(3))
+    xo, ro = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    w, b = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    yo = F.batch_norm(xo, bn.running_mean.double().clone(), bn.running_var.double().clone(), w, b, training, 0.1, 1e-5) + ro
+    yo.backward(g.double())
+    bn = bn.cuda().train(training)
+    xd, rd = x.cuda().requires_grad_(True), r.cuda().requires_grad_(True)
+    y = bn_act(xd, bn, None, rd)
+    y.backward(g.cuda())
+    assert_close(y, yo, TOL, "y")
+    assert_close(xd.grad, xo.grad, TOL, "dx")
+    assert_close(rd.grad, ro.grad, 0.0, "dresidual", atol=0)
+    assert_close(bn.weight.grad, w.grad, TOL, "dweight")
