@@ -154,6 +154,17 @@ def kernel_rooflines(batch, size, iters):
     ctx, lse = Fh.attn_fwd_hip(q, k, v, scale)
     out = []
 
+    notes = {
+        "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
+        "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
+        "cab_qkv_fwd": "11 dependent launches of <= 10 us of work each: launch-latency bound",
+        "cab_qkv_bwd": "~20 dependent launches of <= 10 us of work each: launch-latency bound",
+        "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
+        "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
+        "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
+        "bn_dwconv_bwd": "the depthwise stencil backward is VALU bound; the BatchNorm dx pass is HBM bound",
+    }
+
     def entry(name, ms, flops, bytes_, bound):
         tf = flops / (ms * 1e-3) / 1e12
         gbs = bytes_ / (ms * 1e-3) / 1e9
@@ -164,6 +175,8 @@ def kernel_rooflines(batch, size, iters):
             r = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                      frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None)
         r["traffic"] = measured_traffic(name.split(" ")[0], batch, size)
+        if name.split(" ")[0] in notes:
+            r["note"] = notes[name.split(" ")[0]]
         r.update(kernel=name, ms_per_launch=round(ms, 4), algorithmic_gflop=round(flops / 1e9, 3),
                  algorithmic_mbytes=round(bytes_ / 1e6, 1), tflops=round(tf, 2), gbytes_per_s=round(gbs, 1))
         out.append(r)
