@@ -433,6 +433,14 @@ def main():
                        f"({cb['seconds']:.1f} s) of fwd + 2x OhemCE + bwd"),
             "seconds_per_step": round(cb["seconds_per_step"], 3),
         }
+    # RCCL (NCCL_DEBUG=VERSION on these boxes) writes its version banner to C stdout, which is only flushed at exit:
+    # every rank pushes it out now, so that rank 0's JSON line is the LAST line of the job's stdout
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if ddp:
+        torch.distributed.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if ddp:
