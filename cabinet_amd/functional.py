@@ -661,7 +661,10 @@ class _BnAct(torch.autograd.Function):
                                         fn_ctx.act, int(fn_ctx.training), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
                                         nbytes, _stream_handle(x.device))
         _lib.check(rc, "cabinet_bn_act_bwd")
-        return dx, dw, db, None, None, None, None, None, None, (g if fn_ctx.needs_input_grad[9] else None)
+        grads = (dx, dw, db, None, None, None, None, None, None)
+        if len(fn_ctx.needs_input_grad) > 9:  # called with the optional residual operand: d(residual) = dy
+            grads += (g if fn_ctx.needs_input_grad[9] else None,)
+        return grads
 
 
 def bn_act(x, bn, act=None, residual=None):
