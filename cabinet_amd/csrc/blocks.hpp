@@ -33,11 +33,11 @@ hipError_t dw_product(const float* dzv, const float* xs, int B, int Co, int Cx, 
                       int ldo, int col_off, hipStream_t stream);
 size_t dw_part_floats(int B, int Co, int Cx, int P);
 
-// per (b,c) row of z (B,C,P): sum and sum of squares -> stat_part[2][C][B]
-void bn_rowstats(const float* z, float* stat_part, int B, int C, int P, hipStream_t stream);
+// per (b,c) row of z (B,C,P): sum and sum of squares -> stat_part[2][C][B] (double)
+void bn_rowstats(const float* z, double* stat_part, int B, int C, int P, hipStream_t stream);
 // one workgroup per channel, nch channels starting at the given pointers (C = channel count of the stat_part
 // layout): training -> mean / invstd from the partials (+ running-stat update), eval -> running statistics
-void bn_finalize(const float* stat_part, int ntiles, int C, int nch, long long count, int training, float momentum, float eps,
+void bn_finalize(const double* stat_part, int ntiles, int C, int nch, long long count, int training, float momentum, float eps,
                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, hipStream_t stream);
 
 }  // namespace cabinet

@@ -5,7 +5,16 @@
 //   dP    = g^T v                          dS[i][j] = P[i][j] (dP[i][j] - D_i)
 //   dq    = scale * dS k                   dk[c][j] = scale * sum_i dS[i][j] q[c][i]
 //
-// Two kernels, no atomics, bitwise deterministic:
+// Conditioning of dq.  sum_j dS[i][j] = 0 exactly, so dq_i = scale * sum_j dS[i][j] (k_j - c) for ANY vector c.  With the
+// flash-style D_i (from g and the stored ctx) the rounding error of D_i enters dq as -dD_i * sum_j P[i][j] k_j ~ -dD_i * mean(k):
+// small per element (~5e-6 relative) but COHERENT over queries and channels, so it adds up in everything contracted
+// over positions downstream (dW_q, d(beta_q): 4e-3 relative in a model whose keys have a large common component and
+// near-uniform attention, while the elementwise dq error was 3e-6).  K2a therefore feeds the dq product with CENTRED keys
+// k_j - mean_j(k_j) (subtracted where the K tile is laid down as the product's LDS image; S keeps the raw keys, so P is
+// bit-identical): the same algebraic value with the coherent term and the large common-mode partial sums removed
+// (dq error vs fp64 5e-6 -> 4e-7, below the autograd formulation's 1e-6).  mean_j(k_j) comes from a tiny pre-kernel.
+//
+// Two main kernels, no atomics, bitwise deterministic:
 //   K2a  dq   : workgroup = 32 queries, 4 waves split the keys     (+ writes D_i)
 //   K2b  dk,dv: workgroup = 32 keys,    4 waves split the queries
 // Each recomputes S and dP for its tiles (2n^2(4Kc+3Vc) executed vs 2n^2(3Kc+2Vc)
@@ -31,12 +40,30 @@ __device__ __forceinline__ void stage_chunk(float* tb, const float* __restrict__
     for (int s = 0; s < 16; ++s) tb[(2 * s + h) * TSTR + li] = src[(size_t)(2 * s) * row_stride];
 }
 
+// kmean[b][c] = mean_j k[b][c][j]; one wave per row.  (Any vector near the mean serves the identity above; fp32 is ample.)
+__global__ __launch_bounds__(256) void attn_key_mean_kernel(const float* __restrict__ k, float* __restrict__ kmean, int rows, int n) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = k + (size_t)row * n;
+    float a = 0.f;
+    for (int j = lane; j < n; j += 64) a += p[j];
+    a = wave_sum(a);
+    if (lane == 0) kmean[row] = a / (float)n;
+}
+
+// stage_chunk with a per-channel constant subtracted (the mean key of the chunk's 32 channels, in LDS)
+__device__ __forceinline__ void stage_chunk_centred(float* tb, const float* __restrict__ src, size_t row_stride, int li,
+                                                    int h, const float* __restrict__ cmean) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) tb[(2 * s + h) * TSTR + li] = src[(size_t)(2 * s) * row_stride] - cmean[2 * s + h];
+}
+
 // ------------------------------------------------------------------------------------ K2a: dq
 template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dq_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ ctx, const float* __restrict__ lse,
-    float* __restrict__ dq, float* __restrict__ delta, int n, float scale) {
+    const float* __restrict__ kmean, float* __restrict__ dq, float* __restrict__ delta, int n, float scale) {
     constexpr int KB = KC / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qt = smem;                 // [KC][32]  q * scale*log2e   (B operand of S^T)
@@ -46,6 +73,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_kernel(
     float* s_part = red + KC * 32;    // [8][32]   partial D_i
     float* s_delta = s_part + 256;    // [32]
     float* s_lse = s_delta + 32;      // [32]
+    float* s_kbar = s_lse + 32;       // [KC]  mean key
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, i0 = blockIdx.x * 32;
@@ -64,6 +92,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_kernel(
             acc += gv * ctx[v_base + (size_t)c * n + ig];
         }
         s_part[part * 32 + i] = acc;
+        for (int c = threadIdx.x; c < KC; c += 256) s_kbar[c] = kmean[b * KC + c];
     }
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -108,7 +137,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_kernel(
 #pragma unroll
         for (int cb = 0; cb < KB; ++cb) {
             float* tc = tb + (cb & 1) * TCHUNK;
-            stage_chunk(tc, kp + (size_t)(cb * 32) * n, n, li, h);
+            stage_chunk_centred(tc, kp + (size_t)(cb * 32) * n, n, li, h, s_kbar + cb * 32);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[cb] = mfma32(tc[li * TSTR + acc_row(r) + 4 * h], s[r], acc[cb]);
@@ -293,7 +322,8 @@ template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ ctx, const float* __restrict__ lse,
-    float* __restrict__ dq, float* __restrict__ delta, int n, float scale, int B, int nsplit) {
+    const float* __restrict__ kmean, float* __restrict__ dq, float* __restrict__ delta, int n, float scale, int B,
+    int nsplit) {
     constexpr int KB = KC / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* qt = smem;                   // [KC][32]  q * scale*log2e   (B operand of S^T)
@@ -303,6 +333,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
     float* s_part = red + KC * 32;      // [8][32]
     float* s_delta = s_part + 256;      // [32]
     float* s_lse = s_delta + 32;        // [32]
+    float* s_kbar = s_lse + 32;         // [KC]  mean key
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     // small grids (few query tiles) split the KEY range over nsplit workgroups per query tile; partial dq
@@ -339,6 +370,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
             acc += gv * ctx[v_base + (size_t)c * n + ig];
         }
         s_part[part * 32 + i] = acc;
+        for (int c = threadIdx.x; c < KC; c += 256) s_kbar[c] = kmean[b * KC + c];
     }
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dq_fast_kernel(
         for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
         // S^T chain; behind each MFMA the K row pair it used is laid down in the transposed image
         chain_regA_ldsB<KC / 2>(s, kv, [&](int c2) { return qt[(2 * c2 + h) * 32 + li]; },
-                                [&](int c2) { kim[simg(2 * c2 + h, li)] = kv[c2]; });
+                                [&](int c2) { kim[simg(2 * c2 + h, li)] = kv[c2] - s_kbar[2 * c2 + h]; });
         // dP^T chain; the K registers are free now: refill them with the next tile behind the MFMAs
         chain_regA_ldsB<VC / 2>(dp, vv, [&](int c2) { return gt[(2 * c2 + h) * 32 + li]; }, [&](int c2) {
 #pragma unroll
@@ -558,7 +590,9 @@ template <int KC, int VC>
 static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k, const float* v,
                                   const float* ctx, const float* lse, float scale, int B, int n, float* dq,
                                   float* dk, float* dv, float* delta, hipStream_t stream) {
-    const size_t lds_dq = (size_t)((KC + VC) * 32 + 4 * KC * 32 + KC * 32 + 256 + 64) * sizeof(float);
+    float* kmean = delta + align_up((size_t)B * n, 64);
+    hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
+    const size_t lds_dq = (size_t)((KC + VC) * 32 + 4 * KC * 32 + KC * 32 + 256 + 64 + KC) * sizeof(float);
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 4 * (KC + VC) * 32) * sizeof(float);
     auto k_dq = cab_attn_bwd_dq_fast_kernel<KC, VC>;
     auto k_kv = cab_attn_bwd_dkdv_fast_kernel<KC, VC>;
@@ -575,14 +609,14 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
     const int nsplit = bwd_nsplit(B, n);
     dim3 grid(((n + 31) / 32) * B * nsplit);
     if (nsplit == 1) {
-        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, dq, delta, n, scale, B, 1);
+        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale, B, 1);
         hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale, B, 1);
     } else {
         // partial slabs live behind D_i in the workspace: [nsplit][B][KC][n] then [nsplit][B][VC][n]
-        float* part_k = delta + align_up((size_t)B * n, 64);
+        float* part_k = kmean + align_up((size_t)B * KC, 64);
         float* part_v = part_k + (size_t)nsplit * B * KC * n;
         const size_t cq = (size_t)B * KC * n, cv = (size_t)B * VC * n;
-        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, part_k, delta, n, scale, B, nsplit);
+        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, part_k, delta, n, scale, B, nsplit);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dq, cq, nsplit);
         hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, part_k, part_v, n, scale, B, nsplit);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dk, cq, nsplit);
@@ -595,7 +629,9 @@ template <int KC, int VC>
 static hipError_t launch_bwd(const float* g, const float* q, const float* k, const float* v, const float* ctx,
                              const float* lse, float scale, int B, int n, float* dq, float* dk, float* dv,
                              float* delta, hipStream_t stream) {
-    const size_t lds_dq = (size_t)((KC + VC) * 32 + 8 * TCHUNK + KC * 32 + 256 + 64) * sizeof(float);
+    float* kmean = delta + align_up((size_t)B * n, 64);
+    hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
+    const size_t lds_dq = (size_t)((KC + VC) * 32 + 8 * TCHUNK + KC * 32 + 256 + 64 + KC) * sizeof(float);
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 8 * TCHUNK + (KC + VC) * 32) * sizeof(float);
     auto k_dq = cab_attn_bwd_dq_kernel<KC, VC>;
     auto k_kv = cab_attn_bwd_dkdv_kernel<KC, VC>;
@@ -610,13 +646,13 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
         attr_done = true;
     }
     dim3 grid((n + 31) / 32, 1, B);
-    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, dq, delta, n, scale);
+    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale);
     hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale);
     return hipGetLastError();
 }
 
 size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
-    size_t bytes = align_up((size_t)B * n, 64) * sizeof(float);  // D_i
+    size_t bytes = (align_up((size_t)B * n, 64) + align_up((size_t)B * Kc, 64)) * sizeof(float);  // D_i, mean key
     const int nsplit = (Kc <= 128 && Kc + Vc <= 256) ? bwd_nsplit(B, n) : 1;
     if (nsplit > 1) bytes += (size_t)nsplit * B * (Kc + Vc) * n * sizeof(float);  // partial dq|dk and dv slabs
     return align_up(bytes, 256);

@@ -407,7 +407,7 @@ static FwdWs fwd_layout(const QkvShape& s) {
     w.at2v = take((size_t)s.Vc * s.Vc);
     w.atpk = take((size_t)s.ns * s.Kc * s.Kc);
     w.atpv = take((size_t)s.ns * s.Vc * s.Vc);
-    w.stat = take((size_t)2 * 2 * s.Kc * s.B);
+    w.stat = take((size_t)2 * 2 * 2 * s.Kc * s.B);  // doubles
     w.tk = take((size_t)s.B * s.Kc * g.NBp);
     w.tv = take((size_t)s.B * s.Vc * g.NBp);
     w.total = off;
@@ -440,10 +440,11 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
         a.P = P;
         gemm_kmajor(a, s.B, stream);
     }
-    if (training) bn_rowstats(sv.zqk, at(L.stat), s.B, 2 * s.Kc, P, stream);
-    bn_finalize(at(L.stat), s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps, w.bnq_rm, w.bnq_rv,
+    double* stat = reinterpret_cast<double*>(base + L.stat);
+    if (training) bn_rowstats(sv.zqk, stat, s.B, 2 * s.Kc, P, stream);
+    bn_finalize(stat, s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps, w.bnq_rm, w.bnq_rv,
                 sv.mean, sv.invstd, stream);
-    bn_finalize(at(L.stat) + (size_t)s.Kc * s.B, s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps,
+    bn_finalize(stat + (size_t)s.Kc * s.B, s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps,
                 w.bnk_rm, w.bnk_rv, sv.mean + s.Kc, sv.invstd + s.Kc, stream);
     hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
                        sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);

@@ -33,6 +33,13 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// sum of the 16 accumulator registers of one lane (pairwise)
+__device__ __forceinline__ float row_sum16(const f32x16& s) {
+    const float a = (s[0] + s[1]) + (s[2] + s[3]), b = (s[4] + s[5]) + (s[6] + s[7]);
+    const float c = (s[8] + s[9]) + (s[10] + s[11]), d = (s[12] + s[13]) + (s[14] + s[15]);
+    return (a + b) + (c + d);
+}
+
 // sum over a 256-thread workgroup (4 waves), result in every thread; fixed order; red: 4 floats of LDS
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);

@@ -422,35 +422,52 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 }
 
 
-// per (b,c) row of z: sum and sum of squares over the P pixels -> stat_part[2][C][B]
+// per (b,c) row of z: sum and sum of squares over the P pixels -> stat_part[2][C][B] (double)
 // (a streaming pass over z, which is still Infinity-Cache resident right after the GEMM wrote it; this
-// replaced an in-epilogue cross-lane reduction that cost ~60 us per launch in wave shuffles)
-__global__ __launch_bounds__(256) void bn_rowstats_kernel(const float* __restrict__ z, float* __restrict__ stat_part,
+// replaced an in-epilogue cross-lane reduction that cost ~60 us per launch in wave shuffles).
+// Accumulated in DOUBLE end to end: var = E[z^2] - mean^2 cancels by (mean/std)^2, so fp32 row sums lost 1e-7 * that
+// ratio (1e-3 of the variance for a channel with mean = 100 std); with double sums the one-pass form is exact to fp32
+// output precision for any ratio a float tensor can hold.  The pass stays HBM / Infinity-Cache bound (3 f64 ops per value).
+__global__ __launch_bounds__(256) void bn_rowstats_kernel(const float* __restrict__ z, double* __restrict__ stat_part,
                                                            int B, int C, int P) {
-    __shared__ float s_red[4];
+    __shared__ double s_red[2][4];
     const int row = blockIdx.x, b = row / C, c = row - b * C;
     const float* zr = z + (size_t)row * P;
-    float s1 = 0.f, s2 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
     if ((P & 3) == 0) {
         for (int p = threadIdx.x * 4; p < P; p += 1024) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(zr + p);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s1 += v[e], s2 += v[e] * v[e];
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)v[e];
+                s1 += d, s2 = fma(d, d, s2);
+            }
         }
     } else {
-        for (int p = threadIdx.x; p < P; p += 256) s1 += zr[p], s2 += zr[p] * zr[p];
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const double d = (double)zr[p];
+            s1 += d, s2 = fma(d, d, s2);
+        }
     }
-    s1 = block_sum_256(s1, s_red);
-    s2 = block_sum_256(s2, s_red);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[0][threadIdx.x >> 6] = s1;
+        s_red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        stat_part[(size_t)c * B + b] = s1;
-        stat_part[((size_t)C + c) * B + b] = s2;
+        stat_part[(size_t)c * B + b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+        stat_part[((size_t)C + c) * B + b] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
     }
 }
 
 // BN statistics, one workgroup per channel: training -> reduce the per-tile partials (double),
 // update the running buffers; eval -> running statistics.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stat_part, int ntiles, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stat_part, int ntiles, int C,
                                                            long long count, int training, float momentum, float eps,
                                                            float* __restrict__ running_mean,
                                                            float* __restrict__ running_var,
@@ -466,11 +483,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         return;
     }
     double s1 = 0.0, s2 = 0.0;
-    const float* p1 = stat_part + (size_t)c * ntiles;
-    const float* p2 = stat_part + ((size_t)C + c) * ntiles;
+    const double* p1 = stat_part + (size_t)c * ntiles;
+    const double* p2 = stat_part + ((size_t)C + c) * ntiles;
     for (int t = threadIdx.x; t < ntiles; t += 256) {
-        s1 += (double)p1[t];
-        s2 += (double)p2[t];
+        s1 += p1[t];
+        s2 += p2[t];
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -496,10 +513,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-void bn_rowstats(const float* z, float* stat_part, int B, int C, int P, hipStream_t stream) {
+void bn_rowstats(const float* z, double* stat_part, int B, int C, int P, hipStream_t stream) {
     hipLaunchKernelGGL(bn_rowstats_kernel, dim3(B * C), dim3(256), 0, stream, z, stat_part, B, C, P);
 }
-void bn_finalize(const float* stat_part, int ntiles, int C, int nch, long long count, int training, float momentum, float eps,
+void bn_finalize(const double* stat_part, int ntiles, int C, int nch, long long count, int training, float momentum, float eps,
                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, hipStream_t stream) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(nch), dim3(256), 0, stream, stat_part, ntiles, C, count, training,
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
@@ -772,7 +789,7 @@ __global__ __launch_bounds__(256) void ffm_dz_kernel(const float* __restrict__ g
 // dW_c = U^T(dz) . low^T, again at low resolution.  GEMM FLOPs drop from 3 x 2*B*P*Cin*Co to
 // 3 x 2*B*P*Cs*Co + 3 x 2*B*Pl*Cc*Co  (25.8 -> 9.7 GFLOP per product at config 3).
 static size_t wt_bytes(const FfmShape& s) { return align_up((size_t)(s.Cs + s.Cc) * s.Co * sizeof(float), 256); }
-static size_t stat_bytes(const FfmShape& s) { return align_up((size_t)s.B * 2 * s.Co * sizeof(float), 256); }
+static size_t stat_bytes(const FfmShape& s) { return align_up((size_t)s.B * 2 * s.Co * sizeof(double), 256); }
 static size_t low_bytes(const FfmShape& s, int Hl, int Wl) {
     return align_up((size_t)s.B * s.Co * Hl * Wl * sizeof(float), 256);
 }
@@ -783,7 +800,7 @@ size_t ffm_up_fwd_workspace(const FfmShape& s, int Hl, int Wl) {
 }
 
 // everything after z exists: BN statistics, pooling, SE gate, gated output
-static void ffm_fwd_tail(const FfmShape& s, float* stat_part, const float* bn_w, const float* bn_b,
+static void ffm_fwd_tail(const FfmShape& s, double* stat_part, const float* bn_w, const float* bn_b,
                          float* run_mean, float* run_var, const float* w1, const float* w2, int training,
                          float momentum, float eps, float* out, const float* z, float* save_mean,
                          float* save_invstd, float* pooled, float* gate, hipStream_t stream) {
@@ -808,7 +825,7 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
                        hipStream_t stream) {
     const int P = s.H * s.W, Cin = s.Cs + s.Cc;
     float* wt = static_cast<float*>(ws);
-    float* stat_part = reinterpret_cast<float*>(static_cast<char*>(ws) + wt_bytes(s));
+    double* stat_part = reinterpret_cast<double*>(static_cast<char*>(ws) + wt_bytes(s));
     // W_blk (Co x Cin) -> Wt (Cin x Co): the K-major A operand of G1
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
                        s.Co, Cin);
@@ -831,7 +848,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
     const int P = s.H * s.W, Pl = Hl * Wl, Cin = s.Cs + s.Cc;
     char* base = static_cast<char*>(ws);
     float* wt = reinterpret_cast<float*>(base);
-    float* stat_part = reinterpret_cast<float*>(base + wt_bytes(s));
+    double* stat_part = reinterpret_cast<double*>(base + wt_bytes(s));
     float* ylow = reinterpret_cast<float*>(base + wt_bytes(s) + stat_bytes(s));
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
                        s.Co, Cin);

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
             for (int c = 0; c < CMAX; ++c)
                 if (c < C) se += expf(x[c] - mx);
             loss = mx + logf(se) - xl;
-            my_valid += 1;
+            // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): poison this
+            // block's valid count so the caller's one host read sees it (a row holds far fewer than 2^20 pixels)
+            my_valid += (lb < 0 || lb >= (long long)C) ? -(1 << 20) : 1;
             if (loss > thresh) {
                 my_above += 1;
                 my_sum += loss;
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
     if (threadIdx.x == 0) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
         blk_sum[blk] = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
-        blk_cnt[2 * blk] = s_i[0][0] + s_i[0][1] + s_i[0][2] + s_i[0][3];
+        const int nv = s_i[0][0] + s_i[0][1] + s_i[0][2] + s_i[0][3];
+        blk_cnt[2 * blk] = nv < 0 ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
         blk_cnt[2 * blk + 1] = s_i[1][0] + s_i[1][1] + s_i[1][2] + s_i[1][3];
     }
 }

@@ -63,6 +63,13 @@ class OhemCELoss(nn.Module):
             return (logits_low, labels, size, None, None, None)
         from .functional import _f32c, ohem_up_fwd_hip
 
+        # the kernels read `const long long*` labels of exactly (B,H,W): anything else is the caller's error, as it is
+        # for F.cross_entropy ("expected scalar type Long"), never a silent reinterpretation of the bytes
+        if labels.dtype != torch.int64:
+            raise RuntimeError(f"OhemCELoss.forward_upsampled: labels must be int64 (torch.long), got {labels.dtype}")
+        if tuple(labels.shape) != (logits_low.shape[0],) + size or labels.device != logits_low.device:
+            raise RuntimeError(f"OhemCELoss.forward_upsampled: labels {tuple(labels.shape)} on {labels.device} do not "
+                               f"match logits batch {logits_low.shape[0]} x size {size} on {logits_low.device}")
         low = _f32c(logits_low)
         lab = labels.contiguous()
         loss_px, stats = ohem_up_fwd_hip(low.detach(), lab, size, self.thresh, self.ignore_lb)
@@ -76,6 +83,9 @@ class OhemCELoss(nn.Module):
             loss_px, stats = fwd
             n_valid, n_above, _ = host_stats if host_stats is not None else stats.tolist()  # host sync
             n_valid, n_above = int(n_valid), int(n_above)
+            if n_valid < 0:  # the forward kernel poisons the count when it meets a label outside [0, C) that is not ignore_lb
+                raise RuntimeError(f"OhemCELoss.forward_upsampled: label out of range [0, {logits_low.shape[1]}) "
+                                   f"(and != ignore_lb {self.ignore_lb}); F.cross_entropy asserts on the same input")
             if n_valid == 0:
                 return torch.zeros((), device=logits_low.device, requires_grad=True)
             if n_above >= min(self.n_min, n_valid):
@@ -85,6 +95,25 @@ class OhemCELoss(nn.Module):
 
     def extra_repr(self):
         return f"thresh={self.thresh}, n_min={self.n_min}, ignore_lb={self.ignore_lb}"
+
+
+class SoftmaxFocalLoss(nn.Module):
+    """Focal loss on softmax probabilities with optional per-class weights -- mirror of reference
+    ``src/utils/loss.py:86-128`` (API parity of ``src.utils.loss``; not on the timed path: train.py builds OhemCELoss)."""
+
+    def __init__(self, gamma, weight=None, ignore_lb=255):
+        super().__init__()
+        self.gamma = gamma
+        self.ignore_lb = ignore_lb
+        if weight is not None and not isinstance(weight, torch.Tensor):
+            weight = torch.tensor(weight, dtype=torch.float32)
+        self.register_buffer("weight", weight)
+
+    def forward(self, logits, labels):
+        log_prob = F.log_softmax(logits, dim=1)
+        focal = (1 - log_prob.exp()) ** self.gamma * log_prob
+        w = self.weight if isinstance(self.weight, torch.Tensor) else None
+        return F.nll_loss(focal, labels, weight=w, ignore_index=self.ignore_lb)
 
 
 def ohem_upsampled_pair(crit_a, low_a, crit_b, low_b, labels, size):

@@ -152,7 +152,9 @@ int cabinet_ffm_up_bwd(const float* dout, const float* fsp, const float* low, co
  *         i < cabinet_ohem_up_blocks(B,H,W); the caller reduces them (and decides the branch)
  *   bwd : dlogits_low (B,C,Hl,Wl) = coef * U^T[ sel * (softmax - onehot) ],  sel = valid & (loss_px > thresh),
  *         coef = upstream_grad / #selected.  Deterministic (no atomics).   C <= 32.
- * labels are int64 (torch.long), (B,H,W).
+ * labels are int64 (torch.long), (B,H,W), each either ignore_lb or in [0, C).  A label outside that set is the
+ * caller's error (F.cross_entropy asserts on it); the forward kernel reports it by writing blk_cnt[2*i] = -2^30 for
+ * every workgroup that met one, so the reduced #valid is negative (valid as long as B*H*W < 2^30, W < 2^20).
  * ------------------------------------------------------------------------- */
 int cabinet_ohem_up_blocks(int B, int H, int W);
 int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels,

@@ -1,1 +1,1 @@
-from cabinet_amd.loss import OhemCELoss  # noqa: F401
+from cabinet_amd.loss import OhemCELoss, SoftmaxFocalLoss  # noqa: F401

@@ -211,3 +211,36 @@ class TestOhemCELoss:
                 a.backward()
                 b.backward()
                 assert torch.allclose(la.grad, lb_.grad, rtol=1e-5, atol=1e-9), (thresh, n_min)
+
+
+class TestSoftmaxFocalLoss:
+    """reference tests/unit/test_loss.py:109-158 restated, plus vectors produced by the reference itself
+    (tests/golden/g4_focal.npz, written by tests/golden/make_golden_loss.py)."""
+
+    def test_forward_backward_contract(self):
+        from src.utils.loss import SoftmaxFocalLoss
+
+        for gamma in (0.0, 1.0, 2.0, 5.0):
+            logits = torch.randn(2, 19, 32, 32, requires_grad=True)
+            loss = SoftmaxFocalLoss(gamma=gamma, weight=torch.ones(19), ignore_lb=255)(logits, torch.randint(0, 19, (2, 32, 32)))
+            loss.backward()
+            assert loss.ndim == 0 and float(loss) >= 0 and torch.isfinite(logits.grad).all()
+
+    def test_matches_reference_vectors(self):
+        import os
+
+        import numpy as np
+
+        from conftest import GOLDEN
+        from src.utils.loss import SoftmaxFocalLoss
+
+        g = np.load(os.path.join(GOLDEN, "g4_focal.npz"))
+        logits, labels, weight = (torch.from_numpy(g[k]) for k in ("logits", "labels", "weight"))
+        for gi, gamma in enumerate(g["gammas"]):
+            for tag, w in (("plain", None), ("weighted", weight)):
+                x = logits.clone().requires_grad_(True)
+                loss = SoftmaxFocalLoss(float(gamma), weight=w, ignore_lb=255)(x, labels)
+                loss.backward()
+                assert abs(float(loss) - float(g[f"{tag}.{gi}.loss"])) <= 1e-6 * max(1.0, abs(float(loss)))
+                want = torch.from_numpy(g[f"{tag}.{gi}.dlogits"])
+                assert float((x.grad - want).norm()) <= 1e-5 * float(want.norm())

@@ -26,12 +26,47 @@ def _worker(rank, world, port, out_dir):
     # different seeds per rank: the reducer must broadcast rank 0's weights
     net = build_model("small", n_classes=8, seed=rank, gamma=0.5).train()
     reducer = BucketedGradReducer(net, first_bucket_mb=0.5, bucket_mb=4.0)
+    provisional = reducer.bucket_summary()
     step = TrainStep(net, make_criteria(2, 96, 96, "cpu"), reducer=reducer)
     im, lb = synthetic_batch(2, 96, 96, 8, "cpu", seed=100 + rank)
-    losses = [float(step(im, lb)) for _ in range(2)]  # two steps: re-arming of the buckets
+    losses = [float(step(im, lb)) for _ in range(2)]  # two steps: bucket rebuild after the first, re-arming
     grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
-    torch.save({"grads": grads, "losses": losses, "buckets": reducer.bucket_megabytes,
-                "w0": net.sb.conv1.conv.weight.detach().clone()}, os.path.join(out_dir, f"r{rank}.pt"))
+    out = {"grads": grads, "losses": losses, "buckets": reducer.bucket_megabytes, "provisional": provisional,
+           "summary": reducer.bucket_summary(), "launch_log": reducer.last_launch_log,
+           "hooks": reducer.hooks_in_last_backward, "rebuilt": reducer.rebuilt,
+           "w0": net.sb.conv1.conv.weight.detach().clone()}
+
+    # a second backward outside no_sync() must be refused, not silently mixed into already-averaged buckets
+    o, o16 = net(im)
+    (o.sum() * 0 + o16.sum() * 0).backward()
+    try:
+        (net(im)[0].sum() * 0).backward()
+        out["double_backward"] = "accepted"
+    except RuntimeError as e:
+        out["double_backward"] = str(e)
+    reducer.finish()
+
+    # gradient accumulation (reference train.py:435-439,478-480): 2 micro-batches per window, collectives only on the
+    # last micro-step; then a trailing partial window closed by flush()
+    acc = TrainStep(net, make_criteria(2, 96, 96, "cpu"), reducer=reducer, accum_steps=2)
+    micro = [synthetic_batch(2, 96, 96, 8, "cpu", seed=200 + 10 * rank + j) for j in range(3)]
+    acc(*micro[0])
+    out["launches_after_micro0"] = len(reducer.launch_log)
+    acc(*micro[1])
+    out["acc_launch_log"] = reducer.last_launch_log
+    out["acc_grads"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
+    acc(*micro[2])          # first micro-step of a window that never completes ...
+    acc.flush()             # ... closed at "epoch end"
+    out["flush_grads"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
+
+    # a rank whose loss is the constant zero (every label ignored) runs no backward at all: the other rank launches
+    # from its hooks, this one from finish(); same collectives in the same order -> no hang, gradient = other / world
+    im_z, lb_z = synthetic_batch(2, 96, 96, 8, "cpu", seed=300 + rank)
+    if rank == 1:
+        lb_z = torch.full_like(lb_z, 255)
+    float(step(im_z, lb_z))
+    out["zero_rank_grads"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -43,6 +78,17 @@ def test_two_rank_bucketed_allreduce(tmp_path):
     r = [torch.load(tmp_path / f"r{i}.pt", weights_only=False) for i in range(world)]
     assert torch.equal(r[0]["w0"], r[1]["w0"])                      # weights were broadcast from rank 0
     assert len(r[0]["buckets"]) >= 3 and abs(sum(r[0]["buckets"]) - 5.36e6 * 4 / 2 ** 20) < 6
+    # buckets were re-packed in the arrival order of the first backward, identically on both ranks:
+    # decoder first, spatial branch last (it runs first in forward)
+    assert r[0]["rebuilt"] and r[0]["summary"] == r[1]["summary"] and r[0]["summary"] != r[0]["provisional"]
+    assert r[0]["summary"][0][1].startswith("conv_out.") and r[0]["summary"][-1][2].startswith("sb.conv1.")
+    assert min(m for m, *_ in r[0]["summary"]) >= 0.25   # no 8-KB collective
+    # launch order is the bucket order, and every bucket but the last was launched before backward ended
+    log, hooks = r[0]["launch_log"], r[0]["hooks"]
+    assert [i for i, _ in log] == list(range(len(r[0]["buckets"])))
+    assert all(h < hooks for _, h in log[:-1]) and log[-1][1] == hooks
+    assert r[0]["summary"][-1][0] <= 0.6                 # the exposed tail bucket is the small one
+    assert "no_sync" in r[0]["double_backward"] and "no_sync" in r[1]["double_backward"]
     for k in r[0]["grads"]:
         assert torch.equal(r[0]["grads"][k], r[1]["grads"][k]), k   # identical on both ranks
     # single-process reference: mean of the two per-rank gradients (per-rank BN / OHEM, as under DDP)
@@ -61,6 +107,50 @@ def test_two_rank_bucketed_allreduce(tmp_path):
         got = r[0]["grads"][k]
         err, den = float((got - want).norm()), float(want.norm())
         assert err <= 2e-3 * den + 1e-7, (k, err, den)
+    # accumulation: nothing reduced on the first micro-step, everything on the second; identical on both ranks
+    assert r[0]["launches_after_micro0"] == 0 and len(r[0]["acc_launch_log"]) == len(r[0]["buckets"])
+    for key in ("acc_grads", "flush_grads", "zero_rank_grads"):
+        for k in r[0][key]:
+            assert torch.equal(r[0][key][k], r[1][key][k]), (key, k)
+    gn = lambda d: float(torch.sqrt(sum(v.double().pow(2).sum() for v in d.values())))  # noqa: E731
+    assert gn(r[0]["acc_grads"]) > 0 and gn(r[0]["flush_grads"]) > 0 and gn(r[0]["zero_rank_grads"]) > 0
+
+
+def test_accumulation_contract_single_process():
+    """TrainStep(accum_steps=N) == the reference's loop (train.py:435-439): loss/N per micro-step, gradients summed
+    over the window, optimizer only on the last micro-step, flush() for a trailing partial window."""
+    from cabinet_amd.train import TrainStep, build_model, make_criteria, synthetic_batch
+
+    batches = [synthetic_batch(2, 64, 64, 8, "cpu", seed=40 + j) for j in range(3)]
+    net = build_model("small", n_classes=8, seed=0, gamma=0.5).train()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    step = TrainStep(net, make_criteria(2, 64, 64, "cpu"), optimizer=opt, accum_steps=2)
+    l0 = float(step(*batches[0]))
+    w_mid = net.ffm.conv1.weight.detach().clone()
+    assert torch.equal(w_mid, sd0["ffm.conv1.weight"])            # no optimizer step inside the window
+    step(*batches[1])
+    w_after = net.ffm.conv1.weight.detach().clone()
+    assert not torch.equal(w_after, w_mid)                        # stepped on the last micro-step
+    # reference loop restated with plain autograd
+    ref = build_model("small", n_classes=8, seed=0, gamma=0.5).train()
+    crit = make_criteria(2, 64, 64, "cpu")
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    ropt.zero_grad()
+    for j in range(2):
+        o, o16 = ref(batches[j][0])
+        loss = (crit[0](o, batches[j][1]) + crit[1](o16, batches[j][1])) / 2
+        loss.backward()
+        if j == 0:
+            assert abs(float(loss) - l0) < 1e-6
+    ropt.step()
+    assert torch.allclose(ref.ffm.conv1.weight, w_after, rtol=0, atol=1e-7)
+    # trailing partial window
+    step(*batches[2])
+    assert torch.equal(net.ffm.conv1.weight, w_after)
+    step.flush()
+    assert not torch.equal(net.ffm.conv1.weight, w_after)
+    step.flush()  # idempotent when no micro-step is pending
 
 
 def test_reducer_requires_process_group():

@@ -168,3 +168,42 @@ def test_ffm_upsampled_vs_oracle(B, Cs, Cc, Co, Cm, H, W, Hl, Wl, training):
     assert_close(t[3].grad.flatten(1), gr["dw1"], TOL, "dw1")
     assert_close(t[4].grad.flatten(1), gr["dw2"], TOL, "dw2")
     assert_close(bn.running_var, ref["new_running_var"], 1e-5, "running_var")
+
+
+def test_ffm_bn_statistics_with_large_channel_means():
+    """z = 1x1 conv output whose channels have |mean| >> std (mean ~ 100 std): the one-pass variance
+    E[z^2] - mean^2 must not cancel (row sums are accumulated in double); K7's BatchNorm on the same tensor agrees."""
+    from cabinet_amd.functional import bn_act, ffm_fused
+    from oracle.cab_math import ffm_bwd, ffm_fwd
+
+    gen = torch.Generator().manual_seed(11)
+    B, Cs, Cc, Co, Cm, H, W = 2, 32, 32, 64, 16, 48, 48
+    fsp = torch.randn(B, Cs, H, W, generator=gen) * 0.1 + 10.0   # every input channel ~ 10 +- 0.1
+    fcp = torch.randn(B, Cc, H, W, generator=gen) * 0.1 - 10.0
+    wb = torch.randn(Co, Cs + Cc, 1, 1, generator=gen) * 0.2
+    w1 = torch.randn(Cm, Co, 1, 1, generator=gen) * 0.1
+    w2 = torch.randn(Co, Cm, 1, 1, generator=gen) * 0.1
+    g = torch.randn(B, Co, H, W, generator=gen)
+    bn = torch.nn.BatchNorm2d(Co).train()
+    z64 = torch.nn.functional.conv2d(torch.cat([fsp, fcp], 1).double(), wb.double())
+    ratio = (z64.mean(dim=(0, 2, 3)).abs() / z64.std(dim=(0, 2, 3))).median()
+    assert float(ratio) > 50  # the case the test is about
+    ref = ffm_fwd(fsp.double(), fcp.double(), wb.flatten(1).double(), bn.weight.detach().double(),
+                  bn.bias.detach().double(), bn.running_mean.double(), bn.running_var.double(),
+                  w1.flatten(1).double(), w2.flatten(1).double(), True)
+    gr = ffm_bwd(g.double(), ref, wb.flatten(1).double(), bn.weight.detach().double(), w1.flatten(1).double(),
+                 w2.flatten(1).double(), True, Cs)
+    bn = bn.cuda()
+    t = [x.cuda().requires_grad_(True) for x in (fsp, fcp, wb, w1, w2)]
+    out = ffm_fused(t[0], t[1], t[2], bn, t[3], t[4])
+    out.backward(g.cuda())
+    torch.cuda.synchronize()
+    # the conv output itself carries ~1e-7 * (mean/std) relative error into xhat; beyond that nothing may be lost
+    tol = max(TOL, 1e-6 * float(ratio))
+    assert_close(out, ref["out"], tol, "out")
+    assert_close(bn.running_var, ref["new_running_var"], 1e-4, "running_var")
+    assert_close(t[0].grad, gr["dfsp"], 10 * tol, "dfsp")
+    bn2 = torch.nn.BatchNorm2d(Co).cuda().train()
+    y = bn_act(z64.float().cuda(), bn2, "relu")
+    assert_close(bn2.running_var, bn.running_var, 1e-4, "K7 vs FFM running_var")
+    assert float(y.abs().sum()) > 0

@@ -76,3 +76,28 @@ def test_train_step_fused_loss_matches_unfused():
         gb = res[1][1][k]
         err, den = float((ga - gb).norm()), float(ga.norm())
         assert err <= 5e-3 * den + 1e-6 * ga.numel() ** 0.5, (k, err, den)
+
+
+def test_fused_ohem_rejects_wrong_label_dtype_shape_and_range():
+    """The kernels read int64 labels of exactly (B,H,W) in [0,C) or ignore_lb; everything else raises, like
+    F.cross_entropy does, instead of reinterpreting bytes or returning logsumexp."""
+    from cabinet_amd.loss import OhemCELoss
+
+    crit = OhemCELoss(0.7, 64).cuda()
+    low = torch.randn(1, 8, 8, 8, device="cuda")
+    lab = torch.randint(0, 8, (1, 64, 64), device="cuda")
+    with pytest.raises(RuntimeError, match="int64"):
+        crit.forward_upsampled(low, lab.int(), (64, 64))
+    with pytest.raises(RuntimeError, match="int64"):
+        crit.forward_upsampled(low, lab.to(torch.uint8), (64, 64))
+    with pytest.raises(RuntimeError, match="do not match"):
+        crit.forward_upsampled(low, lab[:, :32], (64, 64))
+    bad = lab.clone()
+    bad[0, 5, 7] = 8  # == C, not ignore_lb
+    with pytest.raises(RuntimeError, match="out of range"):
+        crit.forward_upsampled(low, bad, (64, 64))
+    bad[0, 5, 7] = -1
+    with pytest.raises(RuntimeError, match="out of range"):
+        crit.forward_upsampled(low, bad, (64, 64))
+    bad[0, 5, 7] = 255  # ignore_lb is fine
+    assert torch.isfinite(crit.forward_upsampled(low, bad, (64, 64)))
