@@ -40,4 +40,42 @@ void bn_rowstats(const float* z, double* stat_part, int B, int C, int P, hipStre
 void bn_finalize(const double* stat_part, int ntiles, int C, int nch, long long count, int training, float momentum, float eps,
                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, hipStream_t stream);
 
+// ---- job-batched small GEMMs (small_gemm.hip) ----
+struct SgSeg {
+    const float* a;   // A rows of this K-segment: K-major (k, lda) or, with a_mmajor, the (M, lda) row-major matrix + k offset
+    const float* b;   // B operand (B, b_rows, P); rows [0, k) of each image are contracted
+    int k, b_rows;
+};
+struct SgJob {
+    SgSeg seg[3];
+    int nseg, lda, a_mmajor;
+    int M, P;         // P positions are computed ...
+    int ldp;          // ... out of rows that are ldp floats long in B and dst (0: ldp = P); lets a job work on a column window
+    float* dst;       // (B, dst_rows, ldp); rows [0, M) of each image are written
+    int dst_rows;
+    int tiles_m, tiles_n, tile_base, nck[3], vec;  // filled by sg_gemm
+};
+struct SgJobs {
+    SgJob j[12];
+    int n;
+};
+const char* sg_gemm_unsupported(const SgJob& j);  // nullptr when the small path can take the job
+void sg_gemm(SgJobs& jobs, int B, hipStream_t stream);
+
+struct SdJob {
+    const float* a;   // (B, a_rows, P), rows [0, M)
+    const float* x;   // (B, x_rows, P), rows [0, N)
+    int a_rows, x_rows, M, N, P;
+    float* out;       // out[m * ldo + col_off + n]
+    int ldo, col_off;
+    int tiles_m, tiles_n, cpi, cps, nsplit, tile_base, elem_base;  // filled by sd_plan
+    size_t slab_off;
+};
+struct SdJobs {
+    SdJob j[8];
+    int n, total_tiles, total_elems;
+};
+size_t sd_plan(SdJobs& jobs, int B);  // slab floats needed for `part`
+hipError_t sd_run(SdJobs& jobs, int B, float* part, hipStream_t stream);
+
 }  // namespace cabinet

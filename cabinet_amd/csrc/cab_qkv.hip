@@ -14,10 +14,10 @@
 // four full-resolution pyramid maps are never formed; the pyramid terms are (Kc x Kc) x (Kc x s^2) products on
 // the pooled bins (110 positions for sizes 1,3,6,8), done as ONE GEMM per branch over a block-expanded
 // operand, and come back as a 4-tap gather from LDS.  The three projections share one GEMM (stacked weights).
-//   fwd : transposes, G(x -> zq|zk|vv), BN row statistics, BN finalize (x2), plane pass (BN+ReLU, q, kk, pooled bins),
-//         G(pooled -> T) x2, G(kk -> k), G(vv -> v), pyramid add                       = 11 launches
-//   bwd : the adjoint chain, ~20 launches, all deterministic (no atomics)
-// GEMMs are the exact-fp32 MFMA kernels of ffm.hip (blocks.hpp).
+//   fwd : G(x -> zq|zk|vv) as one 3-job launch, BN row statistics, BN finalize, plane pass (BN+ReLU, q, kk, pooled bins),
+//         G(pooled -> T_k, T_v) + G(kk -> k, vv -> v) as one 4-job launch, pyramid add              = 6 launches
+//   bwd : the adjoint chain in 7 launches, all deterministic (no atomics)
+// GEMMs are the job-batched exact-fp32 MFMA kernels of small_gemm.hip (64x64 tiles: the batch has only 8192 positions).
 #include "cab_qkv.hpp"
 
 #include "blocks.hpp"
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256) void qkv_plane_fwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = g.H * g.W, Mtot = 2 * Kc + Vc;
     const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot, tid = threadIdx.x;
-    float* plane = smem;               // [P]
-    float* rowpart = smem + P;         // [H][NCB]
+    const int WS = g.W + 1;            // padded row stride: column sums below walk rows in lock step (bank conflicts otherwise)
+    float* plane = smem;               // [H][WS]
+    float* rowpart = smem + g.H * WS;  // [H][NCB]
     float* binv = rowpart + g.H * g.NCB;  // [NBp]
     float* pooled;
     int ch, nch;
@@ -118,17 +119,24 @@ __global__ __launch_bounds__(256) void qkv_plane_fwd_kernel(const float* __restr
         const float gam = is_q ? bnq_w[ch] : bnk_w[ch], bet = is_q ? bnq_b[ch] : bnk_b[ch];
         const float mu = mean[m], inv = invstd[m];
         float* dst = (is_q ? q : kk) + ((size_t)b * Kc + ch) * P;
+        if (is_q) {
+            for (int p = tid; p < P; p += 256) dst[p] = fmaxf(fmaf((src[p] - mu) * inv, gam, bet), 0.f);
+            return;
+        }
         for (int p = tid; p < P; p += 256) {
             const float v = fmaxf(fmaf((src[p] - mu) * inv, gam, bet), 0.f);  // same expression as the backward mask
+            const int y = p / g.W;
             dst[p] = v;
-            plane[p] = v;
+            plane[y * WS + (p - y * g.W)] = v;
         }
-        if (is_q) return;
         pooled = pooled_k, nch = Kc;
     } else {
         ch = m - 2 * Kc, nch = Vc, pooled = pooled_v;
         const float* src = vv + ((size_t)b * Vc + ch) * P;
-        for (int p = tid; p < P; p += 256) plane[p] = src[p];
+        for (int p = tid; p < P; p += 256) {
+            const int y = p / g.W;
+            plane[y * WS + (p - y * g.W)] = src[p];
+        }
     }
     __syncthreads();
     // separable adaptive average pooling: column bins per row, then row bins
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(256) void qkv_plane_fwd_kernel(const float* __restr
         while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
         const int c = cb - g.coff[i], xs = bin_start(c, g.W, g.s[i]), xe = bin_end(c, g.W, g.s[i]);
         float acc = 0.f;
-        for (int x = xs; x < xe; ++x) acc += plane[y * g.W + x];
+        for (int x = xs; x < xe; ++x) acc += plane[y * WS + x];
         rowpart[it] = acc;
     }
     __syncthreads();
@@ -205,11 +213,17 @@ __global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __res
     const bool is_k = m < Kc;
     const float* src = is_k ? dk + ((size_t)b * Kc + m) * P : dv + ((size_t)b * Vc + (m - Kc)) * P;
     float* dst = is_k ? dTk + ((size_t)b * Kc + m) * g.NBp : dTv + ((size_t)b * Vc + (m - Kc)) * g.NBp;
-    float* plane = smem;                     // [P]
-    float* wx = smem + P;                    // [NCB][W]
-    float* wy = wx + g.NCB * g.W;            // [NCB][H]
-    float* colpart = wy + g.NCB * g.H;       // [H][NCB]
-    for (int p = tid; p < P; p += 256) plane[p] = src[p];
+    // row strides W+1 / H+1: with W = 32 the unpadded tables put a whole column in one LDS bank (32-way conflicts on every
+    // read of the dot products below; the kernel took 49 us for 2048 planes)
+    const int WS = g.W + 1, HS = g.H + 1;
+    float* plane = smem;                     // [H][WS]
+    float* wx = plane + g.H * WS;            // [NCB][WS]
+    float* wy = wx + g.NCB * WS;             // [NCB][HS]
+    float* colpart = wy + g.NCB * HS;        // [H][NCB]
+    for (int p = tid; p < P; p += 256) {
+        const int oy = p / g.W;
+        plane[oy * WS + (p - oy * g.W)] = src[p];
+    }
     for (int it = tid; it < g.NCB * g.W; it += 256) {
         const int cb = it / g.W, ox = it - cb * g.W;
         int i = 0;
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __res
         int x0, x1;
         float lx;
         bilinear_taps(ox, (float)g.s[i] / (float)g.W, g.s[i], x0, x1, lx);
-        wx[it] = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+        wx[cb * WS + ox] = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
     }
     for (int it = tid; it < g.NCB * g.H; it += 256) {
         const int cb = it / g.H, oy = it - cb * g.H;
@@ -228,13 +242,13 @@ __global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __res
         int y0, y1;
         float ly;
         bilinear_taps(oy, (float)g.s[i] / (float)g.H, g.s[i], y0, y1, ly);
-        wy[it] = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+        wy[cb * HS + oy] = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
     }
     __syncthreads();
     for (int it = tid; it < g.H * g.NCB; it += 256) {
         const int oy = it / g.NCB, cb = it - oy * g.NCB;
-        const float* w = wx + cb * g.W;
-        const float* row = plane + oy * g.W;
+        const float* w = wx + cb * WS;
+        const float* row = plane + oy * WS;
         float acc = 0.f;
         for (int ox = 0; ox < g.W; ++ox) acc += w[ox] * row[ox];
         colpart[it] = acc;
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(256) void pyramid_adjoint_kernel(const float* __res
             int i = 0;
             while (i + 1 < g.ns && t >= g.off[i + 1]) ++i;
             const int s = g.s[i], ys = (t - g.off[i]) / s, xs = (t - g.off[i]) - ys * s;
-            const float* w = wy + (g.coff[i] + ys) * g.H;
+            const float* w = wy + (g.coff[i] + ys) * HS;
             for (int oy = 0; oy < g.H; ++oy) acc += w[oy] * colpart[oy * g.NCB + g.coff[i] + xs];
         }
         dst[t] = acc;
@@ -272,8 +286,21 @@ __global__ __launch_bounds__(256) void qkv_plane_bwd_kernel(const float* __restr
     const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot;
     float* dp = smem;            // [NBp]   dpooled / bin size
     float* E = smem + g.NBp;     // [H][NCB] row-expanded
+    int* xr = reinterpret_cast<int*>(E + g.H * g.NCB);  // [ns][W]  lo | hi << 8 : column bins of size i that contain x
+    int* yr = xr + g.ns * g.W;                            // [ns][H]  row bins that contain y
     const bool is_q = m < Kc, is_v = m >= 2 * Kc;
     if (!is_q) {
+        // which bins cover a coordinate is a contiguous range; tabulate it once (the per-pixel form spent ~24 emulated
+        // integer divisions per pixel and size)
+        for (int it = tid; it < g.ns * (g.W + g.H); it += 256) {
+            const bool isx = it < g.ns * g.W;
+            const int j = isx ? it : it - g.ns * g.W, n = isx ? g.W : g.H;
+            const int i = j / n, c = j - i * n, s = g.s[i];
+            int lo = s, hi = -1;
+            for (int r = 0; r < s; ++r)
+                if (bin_start(r, n, s) <= c && c < bin_end(r, n, s)) lo = min(lo, r), hi = max(hi, r);
+            (isx ? xr : yr)[j] = lo | (hi << 8);
+        }
         const int ch = is_v ? m - 2 * Kc : m - Kc, nch = is_v ? Vc : Kc;
         const float* dpe = is_v ? dpe_v : dpe_k;
         for (int t = tid; t < g.NBp; t += 256) {
@@ -292,24 +319,20 @@ __global__ __launch_bounds__(256) void qkv_plane_bwd_kernel(const float* __restr
             const int y = it / g.NCB, cb = it - y * g.NCB;
             int i = 0;
             while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
-            const int s = g.s[i], c = cb - g.coff[i];
+            const int s = g.s[i], c = cb - g.coff[i], rr = yr[i * g.H + y];
             float acc = 0.f;
-            for (int r = 0; r < s; ++r)
-                if (bin_start(r, g.H, s) <= y && y < bin_end(r, g.H, s)) acc += dp[g.off[i] + r * s + c];
+            for (int r = rr & 255; r <= (rr >> 8); ++r) acc += dp[g.off[i] + r * s + c];
             E[it] = acc;
         }
         __syncthreads();
     }
     auto pool_adjoint = [&](int p) {
         const int y = p / g.W, x = p - y * g.W;
+        const float* Ey = E + y * g.NCB;
         float acc = 0.f;
         for (int i = 0; i < g.ns; ++i) {
-            const int s = g.s[i], c0 = (x * s) / g.W;
-            // a pixel lies in its nominal bin and possibly a neighbour (bins overlap when W % s != 0);
-            // with more bins than pixels several bins share it, so scan them all
-            const int lo = s <= g.W ? max(c0 - 1, 0) : 0, hi = s <= g.W ? min(c0 + 1, s - 1) : s - 1;
-            for (int c = lo; c <= hi; ++c)
-                if (bin_start(c, g.W, s) <= x && x < bin_end(c, g.W, s)) acc += E[y * g.NCB + g.coff[i] + c];
+            const int cr = xr[i * g.W + x];
+            for (int c = cr & 255; c <= (cr >> 8); ++c) acc += Ey[g.coff[i] + c];
         }
         return acc;
     };
@@ -372,11 +395,13 @@ __global__ __launch_bounds__(256) void qkv_bn_bwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------- host side
 static size_t fbytes(size_t n) { return align_up(n * sizeof(float), 256); }
 
-static size_t lds_fwd_plane(const PyrGeom& g) { return ((size_t)g.H * g.W + (size_t)g.H * g.NCB + g.NBp) * sizeof(float); }
+static size_t lds_fwd_plane(const PyrGeom& g) { return ((size_t)g.H * (g.W + 1) + (size_t)g.H * g.NCB + g.NBp) * sizeof(float); }
 static size_t lds_adjoint(const PyrGeom& g) {
-    return ((size_t)g.H * g.W + (size_t)g.NCB * (g.W + g.H) + (size_t)g.H * g.NCB) * sizeof(float);
+    return ((size_t)g.H * (g.W + 1) + (size_t)g.NCB * (g.W + 1 + g.H + 1) + (size_t)g.H * g.NCB) * sizeof(float);
 }
-static size_t lds_bwd_plane(const PyrGeom& g) { return ((size_t)g.NBp + (size_t)g.H * g.NCB) * sizeof(float); }
+static size_t lds_bwd_plane(const PyrGeom& g) {
+    return ((size_t)g.NBp + (size_t)g.H * g.NCB + (size_t)g.ns * (g.W + g.H)) * sizeof(float);
+}
 
 const char* qkv_unsupported(const QkvShape& s) {
     if (s.ns < 1 || s.ns > 4) return "1..4 pyramid sizes";
@@ -389,12 +414,41 @@ const char* qkv_unsupported(const QkvShape& s) {
     return nullptr;
 }
 
+// BN finalize for both projections in one launch: channels [0,Kc) -> query BN buffers, [Kc,2Kc) -> key BN buffers
+__global__ __launch_bounds__(64) void qk_bn_finalize_kernel(const double* __restrict__ stat_part, int B, int Kc, long long count,
+                                                            int training, float momentum, float eps, float* __restrict__ q_rm,
+                                                            float* __restrict__ q_rv, float* __restrict__ k_rm,
+                                                            float* __restrict__ k_rv, float* __restrict__ save_mean,
+                                                            float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * 64 + threadIdx.x, C2 = 2 * Kc;
+    if (c >= C2) return;
+    float* rm = c < Kc ? q_rm + c : k_rm + (c - Kc);
+    float* rv = c < Kc ? q_rv + c : k_rv + (c - Kc);
+    if (!training) {
+        save_mean[c] = *rm;
+        save_invstd[c] = 1.0f / sqrtf(*rv + eps);
+        return;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        s1 += stat_part[(size_t)c * B + b];
+        s2 += stat_part[((size_t)C2 + c) * B + b];
+    }
+    const double mean = s1 / (double)count;
+    double var = s2 / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double unbiased = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+    *rm = (float)((1.0 - (double)momentum) * (double)*rm + (double)momentum * mean);
+    *rv = (float)((1.0 - (double)momentum) * (double)*rv + (double)momentum * unbiased);
+}
+
 struct FwdWs {
-    size_t at1, at2k, at2v, atpk, atpv, stat, tk, tv, total;
+    size_t stat, tk, tv, total;
 };
 static FwdWs fwd_layout(const QkvShape& s) {
     const PyrGeom g = make_geom(s);
-    const int Mtot = 2 * s.Kc + s.Vc;
     FwdWs w{};
     size_t off = 0;
     auto take = [&](size_t floats) {
@@ -402,11 +456,6 @@ static FwdWs fwd_layout(const QkvShape& s) {
         off += fbytes(floats);
         return o;
     };
-    w.at1 = take((size_t)s.C * Mtot);
-    w.at2k = take((size_t)s.Kc * s.Kc);
-    w.at2v = take((size_t)s.Vc * s.Vc);
-    w.atpk = take((size_t)s.ns * s.Kc * s.Kc);
-    w.atpv = take((size_t)s.ns * s.Vc * s.Vc);
     w.stat = take((size_t)2 * 2 * 2 * s.Kc * s.B);  // doubles
     w.tk = take((size_t)s.B * s.Kc * g.NBp);
     w.tv = take((size_t)s.B * s.Vc * g.NBp);
@@ -416,6 +465,16 @@ static FwdWs fwd_layout(const QkvShape& s) {
 size_t qkv_fwd_workspace(const QkvShape& s) { return fwd_layout(s).total; }
 int qkv_padded_bins(const QkvShape& s) { return make_geom(s).NBp; }
 
+static SgJob sg_job(const float* a, int lda, int a_mmajor, const float* b, int k, int b_rows, int M, int P, float* dst,
+                    int dst_rows) {
+    SgJob j{};
+    j.seg[0] = {a, b, k, b_rows};
+    j.nseg = 1, j.lda = lda, j.a_mmajor = a_mmajor, j.M = M, j.P = P, j.dst = dst, j.dst_rows = dst_rows;
+    return j;
+}
+
+// forward: 6 launches (was 11): [zq|zk|vv] GEMMs (one launch, weights read as stored), BN row statistics, BN finalize,
+// plane pass (BN + ReLU, q, kk, pooled bins), [T_k, T_v, W0 kk, W0 vv] GEMMs (one launch), pyramid add
 hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, int training, float momentum, float eps,
                        const QkvSaved& sv, float* q, float* k, float* v, void* ws, hipStream_t stream) {
     const PyrGeom g = make_geom(s);
@@ -423,45 +482,38 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
     const FwdWs L = fwd_layout(s);
     char* base = static_cast<char*>(ws);
     auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
-    TrJobs jobs{};
-    jobs.j[0] = {w.wq, at(L.at1), s.C, s.Kc, s.C, Mtot, 0, 0};
-    jobs.j[1] = {w.wk, at(L.at1), s.C, s.Kc, s.C, Mtot, s.Kc, 0};
-    jobs.j[2] = {w.wv, at(L.at1), s.C, s.Vc, s.C, Mtot, 2 * s.Kc, 0};
-    jobs.j[3] = {w.wpk, at(L.at2k), ldk, s.Kc, s.Kc, s.Kc, 0, 0};
-    jobs.j[4] = {w.wpv, at(L.at2v), ldv, s.Vc, s.Vc, s.Vc, 0, 0};
-    jobs.j[5] = {w.wpk + s.Kc, at(L.atpk), ldk, s.Kc, s.ns * s.Kc, s.Kc, 0, 0};
-    jobs.j[6] = {w.wpv + s.Vc, at(L.atpv), ldv, s.Vc, s.ns * s.Vc, s.Vc, 0, 0};
-    stage_weights(jobs, 7, stream);
-    {   // [zq | zk | vv] = [W_q; W_k; W_v] x
-        GemmKArgs a{};
-        a.at = at(L.at1), a.lda = Mtot, a.M = Mtot, a.K = s.C;
-        a.src0 = x, a.src1 = x, a.K0 = s.C;
-        a.dst0 = sv.zqk, a.dst1 = sv.vv, a.M0 = 2 * s.Kc;
-        a.P = P;
-        gemm_kmajor(a, s.B, stream);
+    {
+        SgJobs jobs{};
+        jobs.n = 3;
+        jobs.j[0] = sg_job(w.wq, s.C, 1, x, s.C, s.C, s.Kc, P, sv.zqk, 2 * s.Kc);
+        jobs.j[1] = sg_job(w.wk, s.C, 1, x, s.C, s.C, s.Kc, P, sv.zqk + (size_t)s.Kc * P, 2 * s.Kc);
+        jobs.j[2] = sg_job(w.wv, s.C, 1, x, s.C, s.C, s.Vc, P, sv.vv, s.Vc);
+        sg_gemm(jobs, s.B, stream);
     }
     double* stat = reinterpret_cast<double*>(base + L.stat);
     if (training) bn_rowstats(sv.zqk, stat, s.B, 2 * s.Kc, P, stream);
-    bn_finalize(stat, s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps, w.bnq_rm, w.bnq_rv,
-                sv.mean, sv.invstd, stream);
-    bn_finalize(stat + (size_t)s.Kc * s.B, s.B, 2 * s.Kc, s.Kc, (long long)s.B * P, training, momentum, eps,
-                w.bnk_rm, w.bnk_rv, sv.mean + s.Kc, sv.invstd + s.Kc, stream);
+    hipLaunchKernelGGL(qk_bn_finalize_kernel, dim3(ceil_div(2 * s.Kc, 64)), dim3(64), 0, stream, stat, s.B, s.Kc,
+                       (long long)s.B * P, training, momentum, eps, w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean,
+                       sv.invstd);
     hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
                        sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);
-    for (int br = 0; br < 2; ++br) {  // T = W_p[:, Kc:] . pooled (block-expanded), then k = W_0 kk (+ pyramid below)
-        const int Kch = br ? s.Vc : s.Kc;
-        GemmKArgs a{};
-        a.at = at(br ? L.atpv : L.atpk), a.lda = Kch, a.M = Kch, a.K = s.ns * Kch;
-        a.src0 = a.src1 = br ? sv.pooled_v : sv.pooled_k, a.K0 = a.K;
-        a.dst0 = a.dst1 = at(br ? L.tv : L.tk), a.M0 = Kch;
-        a.P = g.NBp;
-        gemm_kmajor(a, s.B, stream);
-        GemmKArgs c{};
-        c.at = at(br ? L.at2v : L.at2k), c.lda = Kch, c.M = Kch, c.K = Kch;
-        c.src0 = c.src1 = br ? sv.vv : sv.kk, c.K0 = Kch;
-        c.dst0 = c.dst1 = br ? v : k, c.M0 = Kch;
-        c.P = P;
-        gemm_kmajor(c, s.B, stream);
+    {   // k, v = W_p[:, :Kc] . kk | vv (pyramid terms added below);  T_i = W_p[:, block i] . pooled_i on the bins of size i:
+        // the block-expanded operand is zero outside its own bins, so each size is its own K = Kc product on a column
+        // window of T (one K = ns*Kc product per branch had 32 workgroups walking 16 dependent chunks: 29 us)
+        SgJobs jobs{};
+        jobs.n = 2;
+        jobs.j[0] = sg_job(w.wpk, ldk, 1, sv.kk, s.Kc, s.Kc, s.Kc, P, k, s.Kc);
+        jobs.j[1] = sg_job(w.wpv, ldv, 1, sv.vv, s.Vc, s.Vc, s.Vc, P, v, s.Vc);
+        for (int br = 0; br < 2; ++br)
+            for (int i = 0; i < s.ns; ++i) {
+                const int Kch = br ? s.Vc : s.Kc, ld = br ? ldv : ldk;
+                const float* pooled = (br ? sv.pooled_v : sv.pooled_k) + (size_t)i * Kch * g.NBp + g.off[i];
+                SgJob j = sg_job((br ? w.wpv : w.wpk) + (i + 1) * Kch, ld, 1, pooled, Kch, s.ns * Kch, Kch, g.s[i] * g.s[i],
+                                 at(br ? L.tv : L.tk) + g.off[i], Kch);
+                j.ldp = g.NBp;
+                jobs.j[jobs.n++] = j;
+            }
+        sg_gemm(jobs, s.B, stream);
     }
     hipLaunchKernelGGL(pyramid_add_kernel, dim3(s.B * (s.Kc + s.Vc)), dim3(256), 0, stream, at(L.tk), at(L.tv), s.Kc, s.Vc,
                        g, k, v);
@@ -469,12 +521,32 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
 }
 
 struct BwdWs {
-    size_t dtk, dtv, dpek, dpev, link, dzqk, dvv, bnpart, wstack, part, total;
+    size_t dtk, dtv, dpek, dpev, link, dzqk, dvv, bnpart, part, total;
 };
-static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+static SdJob sd_job(const float* a, int a_rows, const float* x, int x_rows, int M, int N, int P, float* out, int ldo,
+                    int col_off) {
+    SdJob j{};
+    j.a = a, j.x = x, j.a_rows = a_rows, j.x_rows = x_rows, j.M = M, j.N = N, j.P = P, j.out = out, j.ldo = ldo,
+    j.col_off = col_off;
+    return j;
+}
+static SdJobs qkv_dw_jobs(const QkvShape& s, const PyrGeom& g, const float* x, const QkvSaved& sv, const float* dk,
+                          const float* dv, const float* dtk, const float* dtv, const float* dzqk, const float* dvv,
+                          const QkvGrads& gr) {
+    const int P = s.H * s.W, ldk = (s.ns + 1) * s.Kc, ldv = (s.ns + 1) * s.Vc;
+    SdJobs jobs{};
+    jobs.n = 6;
+    jobs.j[0] = sd_job(dzqk, 2 * s.Kc, x, s.C, 2 * s.Kc, s.C, P, gr.dwqk, s.C, 0);             // [dW_q; dW_k]
+    jobs.j[1] = sd_job(dvv, s.Vc, x, s.C, s.Vc, s.C, P, gr.dwv, s.C, 0);                       // dW_v
+    jobs.j[2] = sd_job(dk, s.Kc, sv.kk, s.Kc, s.Kc, s.Kc, P, gr.dwpk, ldk, 0);                 // dW_p[:, :Kc] (key)
+    jobs.j[3] = sd_job(dv, s.Vc, sv.vv, s.Vc, s.Vc, s.Vc, P, gr.dwpv, ldv, 0);                 // (value)
+    jobs.j[4] = sd_job(dtk, s.Kc, sv.pooled_k, s.ns * s.Kc, s.Kc, s.ns * s.Kc, g.NBp, gr.dwpk, ldk, s.Kc);  // pyramid
+    jobs.j[5] = sd_job(dtv, s.Vc, sv.pooled_v, s.ns * s.Vc, s.Vc, s.ns * s.Vc, g.NBp, gr.dwpv, ldv, s.Vc);
+    return jobs;
+}
 static BwdWs bwd_layout(const QkvShape& s) {
     const PyrGeom g = make_geom(s);
-    const int P = s.H * s.W, Mtot = 2 * s.Kc + s.Vc;
+    const int P = s.H * s.W;
     BwdWs w{};
     size_t off = 0;
     auto take = [&](size_t floats) {
@@ -490,19 +562,18 @@ static BwdWs bwd_layout(const QkvShape& s) {
     w.dzqk = take((size_t)s.B * 2 * s.Kc * P);
     w.dvv = take((size_t)s.B * s.Vc * P);
     w.bnpart = take((size_t)2 * 2 * s.Kc * s.B);
-    w.wstack = take((size_t)Mtot * s.C);
-    size_t part = dw_part_floats(s.B, 2 * s.Kc, s.C, P);
-    part = max_sz(part, dw_part_floats(s.B, s.Vc, s.C, P));
-    part = max_sz(part, dw_part_floats(s.B, s.Kc, s.Kc, P));
-    part = max_sz(part, dw_part_floats(s.B, s.Vc, s.Vc, P));
-    part = max_sz(part, dw_part_floats(s.B, s.Kc, s.ns * s.Kc, g.NBp));
-    part = max_sz(part, dw_part_floats(s.B, s.Vc, s.ns * s.Vc, g.NBp));
-    w.part = take(part);
+    QkvSaved sv{};
+    QkvGrads gr{};
+    SdJobs jobs = qkv_dw_jobs(s, g, nullptr, sv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gr);
+    w.part = take(sd_plan(jobs, s.B));
     w.total = off;
     return w;
 }
 size_t qkv_bwd_workspace(const QkvShape& s) { return bwd_layout(s).total; }
 
+// backward: 7 launches (was ~21): pyramid adjoint, [dpooled_k, dpooled_v, W0^T dk, W0^T dv] GEMMs (one launch), plane
+// pass (pool adjoint, ReLU mask, BN partial sums), BN backward, dx GEMM (one job, three K-segments), all six weight
+// gradients (one split launch + one ordered slab sum)
 hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, const float* dk, const float* dv,
                        const float* x, int training, const QkvSaved& sv, const QkvGrads& gr, void* ws,
                        hipStream_t stream) {
@@ -511,39 +582,17 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
     const BwdWs L = bwd_layout(s);
     char* base = static_cast<char*>(ws);
     auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
-    float* part = at(L.part);
-    hipError_t e;
-    TrJobs jobs{};
-    jobs.j[0] = {w.wq, at(L.wstack), s.C, s.Kc, s.C, s.C, 0, 1};
-    jobs.j[1] = {w.wk, at(L.wstack), s.C, s.Kc, s.C, s.C, s.Kc, 1};
-    jobs.j[2] = {w.wv, at(L.wstack), s.C, s.Vc, s.C, s.C, 2 * s.Kc, 1};
-    stage_weights(jobs, 3, stream);
-    // pyramid terms: dT = U^T d,  dW_p[:, Kc:] = sum dT (x) pooled,  dpooled = W_p[:, Kc:]^T dT
+    // pyramid terms: dT = U^T d
     hipLaunchKernelGGL(pyramid_adjoint_kernel, dim3(s.B * (s.Kc + s.Vc)), dim3(256), lds_adjoint(g), stream, dk, dv, s.Kc,
                        s.Vc, g, at(L.dtk), at(L.dtv));
-    for (int br = 0; br < 2; ++br) {
-        const int Kch = br ? s.Vc : s.Kc, ld = br ? ldv : ldk;
-        const float* wp = br ? w.wpv : w.wpk;
-        float* dT = at(br ? L.dtv : L.dtk);
-        if ((e = dw_product(dT, br ? sv.pooled_v : sv.pooled_k, s.B, Kch, s.ns * Kch, g.NBp, part, br ? gr.dwpv : gr.dwpk,
-                            ld, Kch, stream)) != hipSuccess)
-            return e;
-        GemmKArgs a{};  // dpooled[(i,c)][bin] = sum_m W_p[m][Kc + (i,c)] dT[m][bin]
-        a.at = wp + Kch, a.lda = ld, a.M = s.ns * Kch, a.K = Kch;
-        a.src0 = a.src1 = dT, a.K0 = Kch;
-        a.dst0 = a.dst1 = at(br ? L.dpev : L.dpek), a.M0 = a.M;
-        a.P = g.NBp;
-        gemm_kmajor(a, s.B, stream);
-        GemmKArgs c{};  // identity-branch term: W_0^T d
-        c.at = wp, c.lda = ld, c.M = Kch, c.K = Kch;
-        c.src0 = c.src1 = br ? dv : dk, c.K0 = Kch;
-        c.dst0 = c.dst1 = at(br ? L.dvv : L.link), c.M0 = Kch;
-        c.P = P;
-        gemm_kmajor(c, s.B, stream);
-        // dW_p[:, :Kc] = sum d (x) u,  u = kk | vv
-        if ((e = dw_product(br ? dv : dk, br ? sv.vv : sv.kk, s.B, Kch, Kch, P, part, br ? gr.dwpv : gr.dwpk, ld, 0,
-                            stream)) != hipSuccess)
-            return e;
+    {   // dpooled[(i,c)][bin] = sum_m W_p[m][Kc + (i,c)] dT[m][bin];  identity branch: W_0^T d
+        SgJobs jobs{};
+        jobs.n = 4;
+        jobs.j[0] = sg_job(w.wpk + s.Kc, ldk, 0, at(L.dtk), s.Kc, s.Kc, s.ns * s.Kc, g.NBp, at(L.dpek), s.ns * s.Kc);
+        jobs.j[1] = sg_job(w.wpv + s.Vc, ldv, 0, at(L.dtv), s.Vc, s.Vc, s.ns * s.Vc, g.NBp, at(L.dpev), s.ns * s.Vc);
+        jobs.j[2] = sg_job(w.wpk, ldk, 0, dk, s.Kc, s.Kc, s.Kc, P, at(L.link), s.Kc);
+        jobs.j[3] = sg_job(w.wpv, ldv, 0, dv, s.Vc, s.Vc, s.Vc, P, at(L.dvv), s.Vc);
+        sg_gemm(jobs, s.B, stream);
     }
     hipLaunchKernelGGL(qkv_plane_bwd_kernel, dim3(s.B * Mtot), dim3(256), lds_bwd_plane(g), stream, dq, at(L.link), sv.zqk,
                        at(L.dpek), at(L.dpev), sv.mean, sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.B, s.Kc, s.Vc, g,
@@ -551,29 +600,46 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
     hipLaunchKernelGGL(qkv_bn_bwd_kernel, dim3(s.B * 2 * s.Kc), dim3(256), 0, stream, sv.zqk, sv.mean, sv.invstd, w.bnq_w,
                        w.bnk_w, at(L.bnpart), s.B, s.Kc, P, training, at(L.dzqk), gr.dbnq_w, gr.dbnq_b, gr.dbnk_w,
                        gr.dbnk_b);
-    {   // dx = [W_q; W_k; W_v]^T [dzq; dzk; dvv]
-        GemmKArgs a{};
-        a.at = at(L.wstack), a.lda = s.C, a.M = s.C, a.K = Mtot;
-        a.src0 = at(L.dzqk), a.src1 = at(L.dvv), a.K0 = 2 * s.Kc;
-        a.dst0 = a.dst1 = gr.dx, a.M0 = s.C;
-        a.P = P;
-        gemm_kmajor(a, s.B, stream);
+    {   // dx = W_q^T dzq + W_k^T dzk + W_v^T dvv : the row-major weights ARE the K-major A operands
+        SgJobs jobs{};
+        jobs.n = 1;
+        SgJob& j = jobs.j[0];
+        j.seg[0] = {w.wq, at(L.dzqk), s.Kc, 2 * s.Kc};
+        j.seg[1] = {w.wk, at(L.dzqk) + (size_t)s.Kc * P, s.Kc, 2 * s.Kc};
+        j.seg[2] = {w.wv, at(L.dvv), s.Vc, s.Vc};
+        j.nseg = 3, j.lda = s.C, j.a_mmajor = 0, j.M = s.C, j.P = P, j.dst = gr.dx, j.dst_rows = s.C;
+        sg_gemm(jobs, s.B, stream);
     }
-    if ((e = dw_product(at(L.dzqk), x, s.B, 2 * s.Kc, s.C, P, part, gr.dwqk, s.C, 0, stream)) != hipSuccess) return e;
-    if ((e = dw_product(at(L.dvv), x, s.B, s.Vc, s.C, P, part, gr.dwv, s.C, 0, stream)) != hipSuccess) return e;
-    return hipGetLastError();
+    SdJobs dw = qkv_dw_jobs(s, g, x, sv, dk, dv, at(L.dtk), at(L.dtv), at(L.dzqk), at(L.dvv), gr);
+    return sd_run(dw, s.B, at(L.part), stream);
 }
 
 // ------------------------------------------------------------------------------- plain 1x1 convolution (no bias)
 static int k16(int k) { return (k + 15) & ~15; }
+// the small-tile path serves the CAB's grids (few thousand positions); big planes keep the 128-wide tiles of ffm.hip
+static bool conv1x1_small(int B, int Ci, int Co, int P) {
+    return (Ci % 4) == 0 && (Co % 4) == 0 && (long long)ceil_div(P, 128) * B * ceil_div(Co > Ci ? Co : Ci, 128) < 400;
+}
 
 size_t conv1x1_fwd_workspace(int Ci, int Co) { return fbytes((size_t)k16(Ci) * Co); }
 size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P) {
-    return fbytes(dw_part_floats(B, Co, Ci, P)) + ((Co & 15) ? fbytes((size_t)k16(Co) * Ci) : 0);
+    SdJobs jobs{};
+    jobs.n = 1;
+    jobs.j[0] = sd_job(nullptr, Co, nullptr, Ci, Co, Ci, P, nullptr, Ci, 0);
+    const size_t small = fbytes(sd_plan(jobs, B));
+    const size_t big = fbytes(dw_part_floats(B, Co, Ci, P)) + ((Co & 15) ? fbytes((size_t)k16(Co) * Ci) : 0);
+    return small > big ? small : big;
 }
 
 hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int Co, int P, float* y, void* ws,
                            hipStream_t stream) {
+    if (conv1x1_small(B, Ci, Co, P)) {
+        SgJobs jobs{};
+        jobs.n = 1;
+        jobs.j[0] = sg_job(wgt, Ci, 1, x, Ci, Ci, Co, P, y, Co);
+        sg_gemm(jobs, B, stream);
+        return hipGetLastError();
+    }
     float* wt = static_cast<float*>(ws);  // W^T, [align16(Ci)][Co], zero rows past Ci (K tail of the GEMM)
     if (Ci & 15) {
         hipError_t e = hipMemsetAsync(wt + (size_t)Ci * Co, 0, (size_t)(k16(Ci) - Ci) * Co * sizeof(float), stream);
@@ -594,6 +660,21 @@ hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int 
 hipError_t conv1x1_bwd_run(const float* dy, const float* x, const float* wgt, int B, int Ci, int Co, int P, float* dx,
                            float* dw, void* ws, hipStream_t stream) {
     float* part = static_cast<float*>(ws);
+    if (conv1x1_small(B, Ci, Co, P)) {
+        if (dx) {  // dx = W^T dy: the (Co x Ci) weight is the K-major A operand as stored
+            SgJobs jobs{};
+            jobs.n = 1;
+            jobs.j[0] = sg_job(wgt, Ci, 0, dy, Co, Co, Ci, P, dx, Ci);
+            sg_gemm(jobs, B, stream);
+        }
+        if (dw) {
+            SdJobs jobs{};
+            jobs.n = 1;
+            jobs.j[0] = sd_job(dy, Co, x, Ci, Co, Ci, P, dw, Ci, 0);
+            return sd_run(jobs, B, part, stream);
+        }
+        return hipGetLastError();
+    }
     if (dx) {  // dx = W^T dy: the (Co x Ci) weight is already the K-major A operand (padded copy if Co % 16 != 0)
         const float* at = wgt;
         if (Co & 15) {

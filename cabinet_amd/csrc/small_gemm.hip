@@ -1,0 +1,273 @@
+// Job-batched small GEMMs for the CAB's producers and the 1x1 output projection (reference cab.py:107-123,137-146,155).
+//
+// At the CAB's resolution the whole batch has only B*H'*W' = 8192 positions (config 3), and every product is
+// (128..512) x (128..512) over those positions: 0.03 .. 1.6 GFLOP.  A 128x128-tile GEMM grid has 16..192 workgroups for
+// 256 CUs, so each launch costs ~20 us (33 us for the pyramid-bin products) however little it computes, and the K6
+// chain issued 12 of them plus 7 split-K weight-gradient products with their slab sums.  Here:
+//   sg_gemm   D[m][p] = sum_k A[k][m] B[k][p] per image, 64x64 tiles on 256 threads (4 waves, one 32x32 MFMA block each),
+//             up to 12 independent products ("jobs") per launch, each with up to 3 K-segments (so dx = Wq^T dzq + Wk^T dzk +
+//             Wv^T dvv is one job) and with A taken either K-major (a weight used transposed, as in backward) or
+//             M-major (a row-major (M,K) weight as PyTorch stores it: no staging/transposition kernel in front);
+//   sg_dw     dW[m][n] = sum_{b,p} A[b][m][p] X[b][n][p], 64x64 tiles, split over position ranges, up to 8 products per
+//             launch, ONE ordered slab-sum launch for all of them (deterministic, no atomics).
+// v_mfma_f32_32x32x2_f32 throughout (exact fp32).  Operands with the contracted index contiguous go through stride-33
+// LDS images (conflict-free column reads); the others are read row-wise from stride-68 chunks.
+#include "blocks.hpp"
+#include "common.hpp"
+
+#include <stdint.h>
+
+namespace cabinet {
+
+constexpr int SG_T = 64;     // output tile edge
+constexpr int SG_BK = 32;    // contraction chunk
+constexpr int SG_STR = 68;   // LDS row stride of a [k][64] chunk (16-byte aligned rows)
+constexpr int SD_STR = 33;   // LDS row stride of a [row][32 positions] image
+
+__global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float As[2][SG_BK * SG_STR];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SG_BK * SG_STR];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].tile_base) ++ji;
+    const SgJob& J = jobs.j[ji];
+    int t = blockIdx.x - J.tile_base;
+    const int nt = t % J.tiles_n;
+    t /= J.tiles_n;
+    const int mt = t % J.tiles_m, b = t / J.tiles_m;
+    const int m0 = mt * SG_T, p0 = nt * SG_T, M = J.M, P = J.P, lda = J.lda, ldp = J.ldp;
+    const bool vec_p = J.vec != 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    auto load_chunk = [&](int ci) {
+        int s = 0, c = ci;
+        while (c >= J.nck[s]) c -= J.nck[s], ++s;
+        const int k0 = c * SG_BK, kseg = J.seg[s].k;
+        const float* __restrict__ ap = J.seg[s].a;
+        const float* __restrict__ bp = J.seg[s].b + (size_t)b * J.seg[s].b_rows * ldp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            if (J.a_mmajor) {  // A stored (M, K) row-major: 8 threads read one row's 32-float run
+                const int mrow = idx >> 3, k = k0 + (idx & 7) * 4, m = m0 + mrow;
+                ra[i] = (m < M && k < kseg) ? *reinterpret_cast<const f32x4*>(ap + (size_t)m * lda + k)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {           // A stored (K, M): 16 threads read one k-row's 64-float run
+                const int kk = idx >> 4, m = m0 + (idx & 15) * 4;
+                ra[i] = (k0 + kk < kseg && m < M) ? *reinterpret_cast<const f32x4*>(ap + (size_t)(k0 + kk) * lda + m)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int kk = idx >> 4, p = p0 + (idx & 15) * 4;
+            const float* row = bp + (size_t)min(k0 + kk, kseg - 1) * ldp;  // rows past the segment meet zero A rows
+            if (vec_p && p + 3 < P) {
+                rb[i] = *reinterpret_cast<const f32x4*>(row + p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rb[i][e] = (p + e < P) ? row[p + e] : 0.f;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            if (J.a_mmajor) {
+                const int mrow = idx >> 3, k4 = (idx & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[buf][(k4 + e) * SG_STR + mrow] = ra[i][e];
+            } else {
+                *reinterpret_cast<f32x4*>(&As[buf][(idx >> 4) * SG_STR + (idx & 15) * 4]) = ra[i];
+            }
+            *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 4) * SG_STR + (idx & 15) * 4]) = rb[i];
+        }
+    };
+
+    const int nchunks = J.nck[0] + J.nck[1] + J.nck[2];
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int buf = ci & 1;
+        if (ci + 1 < nchunks) load_chunk(ci + 1);
+        const float* Ab = &As[buf][wm * 32 + li];
+        const float* Bb = &Bs[buf][wn * 32 + li];
+#pragma unroll
+        for (int kk = 0; kk < SG_BK; kk += 2) acc = mfma32(Ab[(kk + h) * SG_STR], Bb[(kk + h) * SG_STR], acc);
+        if (ci + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* dst = J.dst + (size_t)b * J.dst_rows * ldp;
+    const int p = p0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + acc_row(r) + 4 * h;
+        if (m < M && p < P) dst[(size_t)m * ldp + p] = acc[r];
+    }
+}
+
+const char* sg_gemm_unsupported(const SgJob& j) {
+    if (j.lda & 3) return "lda % 4 == 0";
+    for (int s = 0; s < j.nseg; ++s)
+        if (j.seg[s].k & 3) return "K % 4 == 0";
+    if (!j.a_mmajor && (j.M & 3)) return "M % 4 == 0 for a K-major A operand";
+    return nullptr;
+}
+
+void sg_gemm(SgJobs& jobs, int B, hipStream_t stream) {
+    int base = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        SgJob& j = jobs.j[i];
+        if (j.ldp == 0) j.ldp = j.P;
+        j.vec = (j.ldp & 3) == 0;
+        for (int s = 0; s < 3; ++s) {
+            j.nck[s] = s < j.nseg ? ceil_div(j.seg[s].k, SG_BK) : 0;
+            if (s < j.nseg && (reinterpret_cast<uintptr_t>(j.seg[s].b) & 15)) j.vec = 0;  // column window off a 16-byte boundary
+        }
+        j.tiles_m = ceil_div(j.M, SG_T), j.tiles_n = ceil_div(j.P, SG_T), j.tile_base = base;
+        base += j.tiles_m * j.tiles_n * B;
+    }
+    hipLaunchKernelGGL(sg_gemm_kernel, dim3(base), dim3(256), 0, stream, jobs);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients
+__global__ __launch_bounds__(256) void sd_dw_kernel(const SdJobs jobs, float* __restrict__ part, int B) {
+    __shared__ float Az[2][SG_T * SD_STR];
+    __shared__ float Bx[2][SG_T * SD_STR];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].tile_base) ++ji;
+    const SdJob& J = jobs.j[ji];
+    int t = blockIdx.x - J.tile_base;
+    const int nt = t % J.tiles_n;
+    t /= J.tiles_n;
+    const int mt = t % J.tiles_m, split = t / J.tiles_m;  // tiles of one position range are neighbours: operands from L2
+    const int m0 = mt * SG_T, n0 = nt * SG_T, M = J.M, N = J.N, P = J.P;
+    const int chunk_lo = split * J.cps, chunk_hi = min(chunk_lo + J.cps, B * J.cpi);
+    const bool vec_p = (P & 3) == 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 rz[2], rx[2];
+    auto load_chunk = [&](int chunk) {
+        const int b = chunk / J.cpi, p0 = (chunk - b * J.cpi) * SG_BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, p = p0 + (idx & 7) * 4;
+            const float* zr = J.a + ((size_t)b * J.a_rows + m0 + row) * P;
+            const float* xr = J.x + ((size_t)b * J.x_rows + n0 + row) * P;
+            const bool zok = m0 + row < M, xok = n0 + row < N;
+            if (vec_p && p + 3 < P) {
+                rz[i] = zok ? *reinterpret_cast<const f32x4*>(zr + p) : f32x4{0.f, 0.f, 0.f, 0.f};
+                rx[i] = xok ? *reinterpret_cast<const f32x4*>(xr + p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rz[i][e] = (zok && p + e < P) ? zr[p + e] : 0.f;
+                    rx[i][e] = (xok && p + e < P) ? xr[p + e] : 0.f;
+                }
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, col = (idx & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Az[buf][row * SD_STR + col + e] = rz[i][e];
+                Bx[buf][row * SD_STR + col + e] = rx[i][e];
+            }
+        }
+    };
+    if (chunk_lo < chunk_hi) {
+        load_chunk(chunk_lo);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+        const int buf = (chunk - chunk_lo) & 1;
+        if (chunk + 1 < chunk_hi) load_chunk(chunk + 1);
+        const float* Ab = &Az[buf][(wm * 32 + li) * SD_STR + h];
+        const float* Bb = &Bx[buf][(wn * 32 + li) * SD_STR + h];
+#pragma unroll
+        for (int kk = 0; kk < SG_BK; kk += 2) acc = mfma32(Ab[kk], Bb[kk], acc);
+        if (chunk + 1 < chunk_hi) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* slab = part + J.slab_off + (size_t)split * M * N;
+    const int n = n0 + wn * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + acc_row(r) + 4 * h;
+        if (m < M && n < N) slab[(size_t)m * N + n] = acc[r];
+    }
+}
+
+// out[m * ldo + col_off + n] = sum_split slab[split][m][n], all jobs in one launch, fixed order
+__global__ __launch_bounds__(256) void sd_reduce_kernel(const SdJobs jobs, const float* __restrict__ part) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    int ji = 0;
+    while (ji + 1 < jobs.n && gid >= jobs.j[ji + 1].elem_base) ++ji;
+    const SdJob& J = jobs.j[ji];
+    const int i = gid - J.elem_base, count = J.M * J.N;
+    if (i >= count) return;
+    const float* p = part + J.slab_off + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < J.nsplit; k += 4) {
+        s0 += p[(size_t)k * count];
+        s1 += p[(size_t)(k + 1) * count];
+        s2 += p[(size_t)(k + 2) * count];
+        s3 += p[(size_t)(k + 3) * count];
+    }
+    for (; k < J.nsplit; ++k) s0 += p[(size_t)k * count];
+    J.out[(size_t)(i / J.N) * J.ldo + J.col_off + (i % J.N)] = (s0 + s1) + (s2 + s3);
+}
+
+// fills the launch geometry of every job; returns the slab floats needed
+size_t sd_plan(SdJobs& jobs, int B) {
+    int tiles_total = 0;
+    for (int i = 0; i < jobs.n; ++i) tiles_total += ceil_div(jobs.j[i].M, SG_T) * ceil_div(jobs.j[i].N, SG_T);
+    size_t off = 0;
+    int tbase = 0, ebase = 0;
+    for (int i = 0; i < jobs.n; ++i) {
+        SdJob& j = jobs.j[i];
+        j.tiles_m = ceil_div(j.M, SG_T), j.tiles_n = ceil_div(j.N, SG_T);
+        j.cpi = ceil_div(j.P, SG_BK);
+        const int total = B * j.cpi;
+        // ~8 chunks (128 MFMAs per wave) per workgroup, at most 64 splits, and enough workgroups over all jobs (~1000)
+        int nsplit = ceil_div(total, 8);
+        const int want = ceil_div(1024, tiles_total);
+        if (nsplit > want) nsplit = want;
+        if (nsplit > 64) nsplit = 64;
+        if (nsplit < 1) nsplit = 1;
+        j.cps = ceil_div(total, nsplit);
+        j.nsplit = ceil_div(total, j.cps);
+        j.slab_off = off;
+        off += (size_t)j.nsplit * j.M * j.N;
+        off = align_up(off, 64);
+        j.tile_base = tbase;
+        tbase += j.tiles_m * j.tiles_n * j.nsplit;
+        j.elem_base = ebase;
+        ebase += (int)align_up((size_t)j.M * j.N, 256);
+    }
+    jobs.total_tiles = tbase;
+    jobs.total_elems = ebase;
+    return off;
+}
+
+hipError_t sd_run(SdJobs& jobs, int B, float* part, hipStream_t stream) {
+    sd_plan(jobs, B);
+    hipLaunchKernelGGL(sd_dw_kernel, dim3(jobs.total_tiles), dim3(256), 0, stream, jobs, part, B);
+    hipLaunchKernelGGL(sd_reduce_kernel, dim3(jobs.total_elems / 256), dim3(256), 0, stream, jobs, part);
+    return hipGetLastError();
+}
+
+}  // namespace cabinet
