@@ -17,53 +17,58 @@
 
 namespace cabinet {
 
-constexpr int LOC_T = 512;     // threads per workgroup
-constexpr int LOC_EPT = 16;    // elements per thread  ->  B*H*W <= 8192
+constexpr int LOC_T = 1024;    // threads per workgroup: 16 waves = 4 per SIMD; the kernel is latency-bound (one workgroup per
+                               // CU, a dozen barriers per stage), so waves per SIMD are what hides LDS / barrier latency
+constexpr int LOC_EPT = 8;     // elements per thread  ->  B*H*W <= 8192
 constexpr int LOC_MAXN = LOC_T * LOC_EPT;
 
-// sum over the workgroup, result in every thread (two barriers)
-__device__ __forceinline__ float wg_sum(float v, float* red) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+// sum over the workgroup, result in every thread (two barriers).  The per-thread partial (<= 8 terms) is fp32, everything
+// across threads is DOUBLE: these are the BatchNorm sums, and ATen's CPU kernels accumulate them in double too -- the
+// depthwise-weight gradients downstream are cancelling sums that amplify a 1e-7 error of the statistics to 1e-3.
+__device__ __forceinline__ double wg_sum(float v, double* red) {
+    double d = (double)v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
     __syncthreads();
-    float t = 0.f;
+    double t = 0.0;
 #pragma unroll
     for (int w = 0; w < LOC_T / 64; ++w) t += red[w];
     __syncthreads();
     return t;
 }
 
-// z[y][x] = sum_{ky,kx} w[ky][kx] * in[y+ky-1][x+kx-1]        (zero padding, one image plane)
-__device__ __forceinline__ float stencil_fwd(const float* buf, int e, int y, int x, int H, int W, const float (&w)[9]) {
+// LDS planes are stored ZERO-PADDED, (H+2) x (W+2) per image, so the stencils need no border tests: element (b,y,x) sits at
+// pe = b*(H+2)*(W+2) + (y+1)*(W+2) + (x+1) and its neighbours at pe +- (W+2) +- 1 (the pad cells are written once and stay 0).
+// z[y][x] = sum_{ky,kx} w[ky][kx] * in[y+ky-1][x+kx-1]
+__device__ __forceinline__ float stencil_fwd(const float* buf, int pe, int WP, const float (&w)[9]) {
     float acc = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky - 1;
-        if (yy < 0 || yy >= H) continue;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xx = x + kx - 1;
-            if (xx < 0 || xx >= W) continue;
-            acc += w[ky * 3 + kx] * buf[e + (ky - 1) * W + (kx - 1)];
-        }
-    }
+        for (int kx = 0; kx < 3; ++kx) acc += w[ky * 3 + kx] * buf[pe + (ky - 1) * WP + (kx - 1)];
     return acc;
 }
 // din[y][x] = sum_{ky,kx} w[ky][kx] * dz[y-ky+1][x-kx+1]
-__device__ __forceinline__ float stencil_bwd(const float* buf, int e, int y, int x, int H, int W, const float (&w)[9]) {
+__device__ __forceinline__ float stencil_bwd(const float* buf, int pe, int WP, const float (&w)[9]) {
     float acc = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y - ky + 1;
-        if (yy < 0 || yy >= H) continue;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xx = x - kx + 1;
-            if (xx < 0 || xx >= W) continue;
-            acc += w[ky * 3 + kx] * buf[e - (ky - 1) * W - (kx - 1)];
-        }
-    }
+        for (int kx = 0; kx < 3; ++kx) acc += w[ky * 3 + kx] * buf[pe - (ky - 1) * WP - (kx - 1)];
     return acc;
+}
+
+// two sums at the price of one (same two barriers)
+__device__ __forceinline__ void wg_sum2d(double a, double b, double* red, double& A, double& B) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64), b += __shfl_xor(b, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a, red[LOC_T / 64 + (threadIdx.x >> 6)] = b;
+    __syncthreads();
+    A = 0.0, B = 0.0;
+#pragma unroll
+    for (int w = 0; w < LOC_T / 64; ++w) A += red[w], B += red[LOC_T / 64 + w];
+    __syncthreads();
 }
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
@@ -72,21 +77,24 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v
 __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.H * a.W, N = a.B * n, c = blockIdx.x, tid = threadIdx.x;
+    const int WP = a.W + 2, PP = (a.H + 2) * WP, NP = a.B * PP;
     float* bufA = smem;
-    float* bufB = smem + N;
-    float* red = smem + 2 * N;
+    float* bufB = smem + NP;
+    double* red = reinterpret_cast<double*>(smem + ((2 * NP + 1) & ~1));
     float xr[LOC_EPT], v[LOC_EPT];
-    int yx[LOC_EPT];
+    int pe[LOC_EPT];
+    for (int i = tid; i < 2 * NP; i += LOC_T) smem[i] = 0.f;  // pad cells stay zero for the whole kernel
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < LOC_EPT; ++k) {
         const int e = k * LOC_T + tid;
         xr[k] = 0.f;
-        yx[k] = 0;
+        pe[k] = WP + 1;
         if (e < N) {
             const int b = e / n, p = e - b * n, y = p / a.W;
-            yx[k] = (y << 16) | (p - y * a.W);
+            pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
             xr[k] = a.x[((size_t)b * a.C + c) * n + p];
-            bufA[e] = xr[k];
+            bufA[pe[k]] = xr[k];
         }
     }
     __syncthreads();
@@ -98,28 +106,23 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) w[j] = a.st[s].w[c * 9 + j];
 #pragma unroll
-        for (int k = 0; k < LOC_EPT; ++k) {
-            const int e = k * LOC_T + tid;
-            v[k] = (e < N) ? stencil_fwd(in, e, yx[k] >> 16, yx[k] & 0xffff, a.H, a.W, w) : 0.f;
-        }
+        for (int k = 0; k < LOC_EPT; ++k) v[k] = (k * LOC_T + tid < N) ? stencil_fwd(in, pe[k], WP, w) : 0.f;
         float mean, invstd;
-        if (a.training) {  // batch statistics of this channel, two-pass
-            float s1 = 0.f;
+        if (a.training) {  // batch statistics of this channel: one pass, sums in double (see wg_sum)
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < LOC_EPT; ++k) s1 += v[k];
-            mean = wg_sum(s1, red) / (float)N;
-            float s2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < LOC_EPT; ++k) {
-                const int e = k * LOC_T + tid;
-                if (e < N) s2 += (v[k] - mean) * (v[k] - mean);
-            }
-            const float var = wg_sum(s2, red) / (float)N;
-            invstd = 1.0f / sqrtf(var + a.eps);
+            for (int k = 0; k < LOC_EPT; ++k) s1 += (double)v[k], s2 = fma((double)v[k], (double)v[k], s2);
+            double S1, S2;
+            wg_sum2d(s1, s2, red, S1, S2);
+            const double mu = S1 / (double)N;
+            double var = S2 / (double)N - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            invstd = (float)(1.0 / sqrt(var + (double)a.eps));
             if (tid == 0) {
-                const float unbiased = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
-                a.st[s].run_mean[c] = (1.f - a.momentum) * a.st[s].run_mean[c] + a.momentum * mean;
-                a.st[s].run_var[c] = (1.f - a.momentum) * a.st[s].run_var[c] + a.momentum * unbiased;
+                const double unbiased = N > 1 ? var * ((double)N / (double)(N - 1)) : var;
+                a.st[s].run_mean[c] = (float)((1.0 - (double)a.momentum) * (double)a.st[s].run_mean[c] + (double)a.momentum * mu);
+                a.st[s].run_var[c] = (float)((1.0 - (double)a.momentum) * (double)a.st[s].run_var[c] + (double)a.momentum * unbiased);
             }
         } else {
             mean = a.st[s].run_mean[c];
@@ -133,12 +136,10 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
 #pragma unroll
         for (int k = 0; k < LOC_EPT; ++k) v[k] = fmaxf(fmaf(v[k], sc, sh), 0.f);
         if (s < 2) {
-            __syncthreads();  // every stencil read of `in` is done (wg_sum syncs only in training mode)
+            __syncthreads();  // every stencil read of `in` is done (wg_sum2d syncs only in training mode)
 #pragma unroll
-            for (int k = 0; k < LOC_EPT; ++k) {
-                const int e = k * LOC_T + tid;
-                if (e < N) ob[e] = v[k];
-            }
+            for (int k = 0; k < LOC_EPT; ++k)
+                if (k * LOC_T + tid < N) ob[pe[k]] = v[k];
             __syncthreads();
             float* t = in;
             in = ob;
@@ -163,36 +164,29 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
 __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.H * a.W, N = a.B * n, c = blockIdx.x, tid = threadIdx.x;
-    float* bufX = smem;            // x            (stencil input of dW1)
-    float* bufY1 = smem + N;       // y1           (stencil input of dW2 and of z2)
-    float* bufY2 = smem + 2 * N;   // y2           (stencil input of dW3 and of z3)
-    float* bufG = smem + 3 * N;    // current dz   (input of the transposed stencil)
-    float* red = smem + 4 * N;     // [LOC_T/64] + [9][LOC_T/64]
-    float* red9 = red + LOC_T / 64;
+    const int WP = a.W + 2, PP = (a.H + 2) * WP, NP = a.B * PP;
+    float* bufX = smem;             // x            (stencil input of dW1)
+    float* bufY1 = smem + NP;       // y1           (stencil input of dW2 and of z2)
+    float* bufY2 = smem + 2 * NP;   // y2           (stencil input of dW3 and of z3)
+    float* bufG = smem + 3 * NP;    // current dz   (input of the transposed stencil)
+    double* red = reinterpret_cast<double*>(smem + ((4 * NP + 1) & ~1));  // [2][LOC_T/64] doubles, then [9][LOC_T/64] floats
+    float* red9 = reinterpret_cast<float*>(red + 2 * (LOC_T / 64));
 
     float xr[LOC_EPT], xh[3][LOC_EPT], yv[LOC_EPT], g[LOC_EPT];
-    int yx[LOC_EPT];
-    float w[3][9], mean[3], invstd[3], bw[3], bb[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) w[s][j] = a.st[s].w[c * 9 + j];
-        mean[s] = a.save_mean[s * a.C + c];
-        invstd[s] = a.save_invstd[s * a.C + c];
-        bw[s] = a.st[s].bn_w[c];
-        bb[s] = a.st[s].bn_b[c];
-    }
+    int pe[LOC_EPT];
+    for (int i = tid; i < 4 * NP; i += LOC_T) smem[i] = 0.f;  // pad cells stay zero for the whole kernel
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < LOC_EPT; ++k) {
         const int e = k * LOC_T + tid;
-        xr[k] = 0.f, yx[k] = 0, g[k] = 0.f;
+        xr[k] = 0.f, pe[k] = WP + 1, g[k] = 0.f;
         if (e < N) {
             const int b = e / n, p = e - b * n, y = p / a.W;
-            yx[k] = (y << 16) | (p - y * a.W);
+            pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
             const size_t gi = ((size_t)b * a.C + c) * n + p;
             xr[k] = a.x[gi];
             g[k] = a.dout[gi];
-            bufX[e] = xr[k];
+            bufX[pe[k]] = xr[k];
         }
     }
     __syncthreads();
@@ -202,19 +196,24 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
         float* outs[2] = {bufY1, bufY2};
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+            // per-stage constants are (re)loaded where they are used: they are wave-uniform (SGPRs), and holding all three
+            // stages' 27 weights + 12 BatchNorm constants for the whole kernel ran the scalar file out and spilled
+            float w9[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) w9[j] = a.st[s].w[c * 9 + j];
+            const float mean_s = a.save_mean[s * a.C + c], invstd_s = a.save_invstd[s * a.C + c];
+            const float bw_s = a.st[s].bn_w[c], bb_s = a.st[s].bn_b[c];
 #pragma unroll
             for (int k = 0; k < LOC_EPT; ++k) {
-                const int e = k * LOC_T + tid;
-                const float z = (e < N) ? stencil_fwd(in, e, yx[k] >> 16, yx[k] & 0xffff, a.H, a.W, w[s]) : 0.f;
-                xh[s][k] = (z - mean[s]) * invstd[s];
-                yv[k] = fmaxf(fmaf(xh[s][k], bw[s], bb[s]), 0.f);
+                const float z = (k * LOC_T + tid < N) ? stencil_fwd(in, pe[k], WP, w9) : 0.f;
+                xh[s][k] = (z - mean_s) * invstd_s;
+                yv[k] = fmaxf(fmaf(xh[s][k], bw_s, bb_s), 0.f);
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 36 LDS reads in flight, not 72 (register budget)
             }
             if (s < 2) {
 #pragma unroll
-                for (int k = 0; k < LOC_EPT; ++k) {
-                    const int e = k * LOC_T + tid;
-                    if (e < N) outs[s][e] = yv[k];
-                }
+                for (int k = 0; k < LOC_EPT; ++k)
+                    if (k * LOC_T + tid < N) outs[s][pe[k]] = yv[k];
                 __syncthreads();
                 in = outs[s];
             }
@@ -239,56 +238,46 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
             }
         }
         if (a.glob) {
-            dg = wg_sum(dg, red);
-            if (tid == 0) a.dgamma_part[c] = dg;
+            const double dgs = wg_sum(dg, red);
+            if (tid == 0) a.dgamma_part[c] = (float)dgs;
         }
     }
     // ---- stages 3, 2, 1 ----
-    const float inv_n = 1.f / (float)N;
+    const double inv_n = 1.0 / (double)N;
 #pragma unroll
     for (int s = 2; s >= 0; --s) {
         // dy[] holds dL/dy_s already masked by the ReLU of stage s
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < LOC_EPT; ++k) s1 += dy[k], s2 += dy[k] * xh[s][k];
-        s1 = wg_sum(s1, red);
-        s2 = wg_sum(s2, red);
+        for (int k = 0; k < LOC_EPT; ++k) s1 += (double)dy[k], s2 = fma((double)dy[k], (double)xh[s][k], s2);
+        double S1, S2;
+        wg_sum2d(s1, s2, red, S1, S2);
         if (tid == 0) {
-            a.st[s].dbn_b[c] = s1;
-            a.st[s].dbn_w[c] = s2;
+            a.st[s].dbn_b[c] = (float)S1;
+            a.st[s].dbn_w[c] = (float)S2;
         }
-        const float gi_ = bw[s] * invstd[s];
-        const float m1 = a.training ? s1 * inv_n : 0.f, m2 = a.training ? s2 * inv_n : 0.f;
+        const float gi_ = a.st[s].bn_w[c] * a.save_invstd[s * a.C + c];
+        const float m1 = a.training ? (float)(S1 * inv_n) : 0.f, m2 = a.training ? (float)(S2 * inv_n) : 0.f;
         float dz[LOC_EPT];
 #pragma unroll
         for (int k = 0; k < LOC_EPT; ++k) {
-            const int e = k * LOC_T + tid;
-            dz[k] = (e < N) ? gi_ * (dy[k] - m1 - xh[s][k] * m2) : 0.f;
-            if (e < N) bufG[e] = dz[k];
+            const bool ok = k * LOC_T + tid < N;
+            dz[k] = ok ? gi_ * (dy[k] - m1 - xh[s][k] * m2) : 0.f;
+            if (ok) bufG[pe[k]] = dz[k];
         }
         __syncthreads();
-        // weight gradient: dW[ky][kx] = sum_e dz[e] * in_s[e shifted], in_s = x, y1, y2
+        // weight gradient: dW[ky][kx] = sum_e dz[e] * in_s[e shifted], in_s = x, y1, y2 (zero-padded: no border tests)
         const float* ins = (s == 0) ? bufX : (s == 1) ? bufY1 : bufY2;
         float pw[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) pw[j] = 0.f;
 #pragma unroll
         for (int k = 0; k < LOC_EPT; ++k) {
-            const int e = k * LOC_T + tid;
-            if (e < N) {
-                const int y = yx[k] >> 16, x = yx[k] & 0xffff;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = y + ky - 1;
-                    if (yy < 0 || yy >= a.H) continue;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = x + kx - 1;
-                        if (xx < 0 || xx >= a.W) continue;
-                        pw[ky * 3 + kx] += dz[k] * ins[e + (ky - 1) * a.W + (kx - 1)];
-                    }
-                }
-            }
+                for (int kx = 0; kx < 3; ++kx) pw[ky * 3 + kx] += dz[k] * ins[pe[k] + (ky - 1) * WP + (kx - 1)];
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);  // two elements' 18 LDS reads in flight, not all 72 (register budget)
         }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
@@ -297,26 +286,25 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
         }
         __syncthreads();
         if (tid < 9) {
-            float t = 0.f;
+            double t = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < LOC_T / 64; ++wv) t += red9[tid * (LOC_T / 64) + wv];
-            a.st[s].dw[c * 9 + tid] = t;
+            for (int wv = 0; wv < LOC_T / 64; ++wv) t += (double)red9[tid * (LOC_T / 64) + wv];
+            a.st[s].dw[c * 9 + tid] = (float)t;
         }
         // input gradient through the transposed stencil, then through the ReLU of the previous stage
-        float din[LOC_EPT];
+        float din[LOC_EPT], w9[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w9[j] = a.st[s].w[c * 9 + j];
 #pragma unroll
         for (int k = 0; k < LOC_EPT; ++k) {
-            const int e = k * LOC_T + tid;
-            din[k] = (e < N) ? stencil_bwd(bufG, e, yx[k] >> 16, yx[k] & 0xffff, a.H, a.W, w[s]) : 0.f;
+            din[k] = (k * LOC_T + tid < N) ? stencil_bwd(bufG, pe[k], WP, w9) : 0.f;
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // bufG and red9 are free again
         if (s > 0) {
             const float* yprev = (s == 1) ? bufY1 : bufY2;
 #pragma unroll
-            for (int k = 0; k < LOC_EPT; ++k) {
-                const int e = k * LOC_T + tid;
-                dy[k] = (e < N && yprev[e] > 0.f) ? din[k] : 0.f;
-            }
+            for (int k = 0; k < LOC_EPT; ++k) dy[k] = (k * LOC_T + tid < N && yprev[pe[k]] > 0.f) ? din[k] : 0.f;
         } else {
 #pragma unroll
             for (int k = 0; k < LOC_EPT; ++k) {
@@ -330,10 +318,17 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
     }
 }
 
-bool local_shape_supported(int B, int H, int W) { return (long long)B * H * W <= LOC_MAXN && H < 65536 && W < 65536; }
+static size_t local_lds_fwd(int B, int H, int W) { return ((size_t)2 * B * (H + 2) * (W + 2) + 2 + 4 * (LOC_T / 64)) * sizeof(float); }
+static size_t local_lds_bwd(int B, int H, int W) {
+    return ((size_t)4 * B * (H + 2) * (W + 2) + 2 + 4 * (LOC_T / 64) + 9 * (LOC_T / 64) + 16) * sizeof(float);
+}
+
+bool local_shape_supported(int B, int H, int W) {
+    return (long long)B * H * W <= LOC_MAXN && H < 65536 && W < 65536 && local_lds_bwd(B, H, W) <= 160 * 1024;
+}
 
 hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream) {
-    const size_t lds = ((size_t)2 * a.B * a.H * a.W + 64) * sizeof(float);
+    const size_t lds = local_lds_fwd(a.B, a.H, a.W);
     static size_t attr = 0;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_fwd_kernel),
@@ -346,7 +341,7 @@ hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream) {
 }
 
 hipError_t cab_local_bwd_run(const LocalArgs& a, hipStream_t stream) {
-    const size_t lds = ((size_t)4 * a.B * a.H * a.W + 10 * (LOC_T / 64) + 16) * sizeof(float);
+    const size_t lds = local_lds_bwd(a.B, a.H, a.W);
     static size_t attr = 0;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_bwd_kernel),
