@@ -78,4 +78,21 @@ struct SdJobs {
 size_t sd_plan(SdJobs& jobs, int B);  // slab floats needed for `part`
 hipError_t sd_run(SdJobs& jobs, int B, float* part, hipStream_t stream);
 
+inline SgJob sg_make(const float* a, int lda, int a_mmajor, const float* b, int k, int b_rows, int M, int P, float* dst,
+                     int dst_rows) {
+    SgJob j{};
+    j.seg[0] = {a, b, k, b_rows};
+    j.nseg = 1, j.lda = lda, j.a_mmajor = a_mmajor, j.M = M, j.P = P, j.dst = dst, j.dst_rows = dst_rows;
+    return j;
+}
+inline SdJob sd_make(const float* a, int a_rows, const float* x, int x_rows, int M, int N, int P, float* out, int ldo,
+                     int col_off) {
+    SdJob j{};
+    j.a = a, j.x = x, j.a_rows = a_rows, j.x_rows = x_rows, j.M = M, j.N = N, j.P = P, j.out = out, j.ldo = ldo,
+    j.col_off = col_off;
+    return j;
+}
+// true when a product over P positions per image is too small to fill the chip with the 128-wide tiles of gemm_kmajor
+inline bool small_grid(int B, int M, int P) { return (long long)((P + 127) / 128) * B * ((M + 127) / 128) < 400; }
+
 }  // namespace cabinet

@@ -467,10 +467,7 @@ int qkv_padded_bins(const QkvShape& s) { return make_geom(s).NBp; }
 
 static SgJob sg_job(const float* a, int lda, int a_mmajor, const float* b, int k, int b_rows, int M, int P, float* dst,
                     int dst_rows) {
-    SgJob j{};
-    j.seg[0] = {a, b, k, b_rows};
-    j.nseg = 1, j.lda = lda, j.a_mmajor = a_mmajor, j.M = M, j.P = P, j.dst = dst, j.dst_rows = dst_rows;
-    return j;
+    return sg_make(a, lda, a_mmajor, b, k, b_rows, M, P, dst, dst_rows);
 }
 
 // forward: 6 launches (was 11): [zq|zk|vv] GEMMs (one launch, weights read as stored), BN row statistics, BN finalize,
@@ -525,10 +522,7 @@ struct BwdWs {
 };
 static SdJob sd_job(const float* a, int a_rows, const float* x, int x_rows, int M, int N, int P, float* out, int ldo,
                     int col_off) {
-    SdJob j{};
-    j.a = a, j.x = x, j.a_rows = a_rows, j.x_rows = x_rows, j.M = M, j.N = N, j.P = P, j.out = out, j.ldo = ldo,
-    j.col_off = col_off;
-    return j;
+    return sd_make(a, a_rows, x, x_rows, M, N, P, out, ldo, col_off);
 }
 static SdJobs qkv_dw_jobs(const QkvShape& s, const PyrGeom& g, const float* x, const QkvSaved& sv, const float* dk,
                           const float* dv, const float* dtk, const float* dtv, const float* dzqk, const float* dvv,

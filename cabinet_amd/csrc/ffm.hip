@@ -357,46 +357,127 @@ __global__ void reduce_slabs_strided_kernel(const float* __restrict__ part, floa
 // rows): the <= 8*ratio+6 output rows the band touches are staged in LDS with coalesced, independent loads,
 // then each thread produces source pixels from LDS in a fixed summation order.
 constexpr int ADJ_BAND = 8;
+// taps one source column can receive from: ceil(2 / rw) + slack
+static inline int adj_xtaps(int W, int Wl) { return (int)(2.0f * (float)W / (float)Wl) + 4; }
+
+// The bilinear weights depend on (output row, source row) and (output column, source column) only, so they are tabulated
+// once per workgroup; the two gather passes are then one LDS weight (broadcast) + one LDS value + one FMA per term.  (The
+// first version recomputed the taps inside both inner loops and ran at 1.8 TB/s on a pass that only reads dz once.)
+//
+// FUSED form (DzArgs given): the staged rows are not read from a materialised dz but computed on the fly from dout and z
+// (dz = gamma*invstd*(dy - mean_dy - xhat*mean_dyx), dy = 1[bn(z) > 0]*(dout*a1 + a2), exactly ffm_dz_kernel's expression);
+// the band also WRITES the dz rows it owns (rows [ceil(ys_lo*H/Hl), ceil((ys_hi+1)*H/Hl)): a partition of the plane), so
+// the separate dz pass and its 134 MB re-read by the adjoint disappear; the 6 halo rows per band are recomputed.
+struct DzArgs {
+    const float *g, *z, *mean, *invstd, *bn_w, *bn_b, *coef_a1, *coef_a2, *mean_dy, *mean_dyx;
+    float* dz;
+    int C;
+};
+template <bool FUSED>
 __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __restrict__ hi, float* __restrict__ lo,
                                                                 int H, int W, int Hl, int Wl, float rh, float rw,
-                                                                int max_rows) {
-    extern __shared__ float rows[];  // [max_rows][W] staged output rows, then [ADJ_BAND][W] vertical sums
+                                                                int max_rows, int XT, DzArgs d) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [max_rows][W] staged output rows
+    float* tcol = rows + (size_t)max_rows * W;   // [ADJ_BAND][W] vertical sums
+    float* wyt = tcol + ADJ_BAND * W;            // [ADJ_BAND][max_rows] vertical weights
+    float* wxw = wyt + ADJ_BAND * max_rows;      // [Wl][XT] horizontal weights of the taps ox = xlo[xs] + t
+    int* xlo = reinterpret_cast<int*>(wxw + Wl * XT);  // [Wl]
+    int* yr = xlo + Wl;                          // [ADJ_BAND] r_lo | r_hi << 16 (staged-row range with non-zero weight)
     const int bands = (Hl + ADJ_BAND - 1) / ADJ_BAND, pl = blockIdx.x / bands;
     const int ys_lo = (blockIdx.x % bands) * ADJ_BAND, ys_hi = min(ys_lo + ADJ_BAND, Hl) - 1;
     const int oy_lo = max(0, (int)floorf(((float)ys_lo - 0.5f) / rh - 0.5f) - 1);
     const int oy_hi = min(min(H - 1, (int)ceilf(((float)ys_hi + 1.5f) / rh - 0.5f) + 1), oy_lo + max_rows - 1);
-    const float* src = hi + ((size_t)pl * H + oy_lo) * W;
-    const int n_in = (oy_hi - oy_lo + 1) * W;
-    for (int i = threadIdx.x; i < n_in; i += 256) rows[i] = src[i];
-    __syncthreads();
-    // separable: vertical taps first (weights depend on the row only), then horizontal
-    float* tcol = rows + (size_t)max_rows * W;  // [ADJ_BAND][W]
-    const int nys = ys_hi - ys_lo + 1;
-    for (int o = threadIdx.x; o < nys * W; o += 256) {
-        const int yi = o / W, ox = o - yi * W, ys = ys_lo + yi;
-        const int a_lo = max(oy_lo, (int)floorf(((float)ys - 0.5f) / rh - 0.5f) - 1);
-        const int a_hi = min(oy_hi, (int)ceilf(((float)ys + 1.5f) / rh - 0.5f) + 1);
-        float acc = 0.f;
-        for (int oy = a_lo; oy <= a_hi; ++oy) {
+    const int nrows = oy_hi - oy_lo + 1, n_in = nrows * W, nys = ys_hi - ys_lo + 1, tid = threadIdx.x;
+    if (FUSED) {
+        const int c = pl % d.C;
+        const float mu = d.mean[c], is = d.invstd[c], gw = d.bn_w[c], gb = d.bn_b[c];
+        const float a1 = d.coef_a1[pl], a2 = d.coef_a2[pl], mdy = d.mean_dy[c], mdyx = d.mean_dyx[c], gi = gw * is;
+        const size_t base = ((size_t)pl * H + oy_lo) * W;
+        const float* zs = d.z + base;
+        const float* gs = d.g + base;
+        float* dzs = d.dz + base;
+        // rows this band owns (written to dz): a partition of [0, H) over the bands
+        const int own_lo = (ys_lo * H + Hl - 1) / Hl - oy_lo, own_hi = ((ys_hi + 1) * H + Hl - 1) / Hl - 1 - oy_lo;
+        auto body = [&](float zv, float gv) {
+            const float xh = (zv - mu) * is;
+            const float y = fmaf(xh, gw, gb);
+            const float dy = y > 0.f ? fmaf(gv, a1, a2) : 0.f;
+            return gi * (dy - mdy - xh * mdyx);
+        };
+        if ((W & 3) == 0) {
+            for (int i = tid * 4; i < n_in; i += 1024) {
+                const f32x4 zv = *reinterpret_cast<const f32x4*>(zs + i);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(gs + i);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = body(zv[e], gv[e]);
+                *reinterpret_cast<f32x4*>(rows + i) = o;
+                const int r = i / W;
+                if (r >= own_lo && r <= own_hi) *reinterpret_cast<f32x4*>(dzs + i) = o;
+            }
+        } else {
+            for (int i = tid; i < n_in; i += 256) {
+                const float o = body(zs[i], gs[i]);
+                rows[i] = o;
+                const int r = i / W;
+                if (r >= own_lo && r <= own_hi) dzs[i] = o;
+            }
+        }
+    } else {
+        const float* src = hi + ((size_t)pl * H + oy_lo) * W;
+        if ((W & 3) == 0) {
+            for (int i = tid * 4; i < n_in; i += 1024)
+                *reinterpret_cast<f32x4*>(rows + i) = *reinterpret_cast<const f32x4*>(src + i);
+        } else {
+            for (int i = tid; i < n_in; i += 256) rows[i] = src[i];
+        }
+    }
+    for (int i = tid; i < nys * max_rows; i += 256) {
+        const int yi = i / max_rows, r = i - yi * max_rows, ys = ys_lo + yi;
+        float wgt = 0.f;
+        if (r < nrows) {
             int y0, y1;
             float ly;
-            bilinear_taps(oy, rh, Hl, y0, y1, ly);
-            acc += ((y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f)) * rows[(oy - oy_lo) * W + ox];
+            bilinear_taps(oy_lo + r, rh, Hl, y0, y1, ly);
+            wgt = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
         }
-        tcol[o] = acc;
+        wyt[i] = wgt;
     }
-    __syncthreads();
-    for (int o = threadIdx.x; o < nys * Wl; o += 256) {
-        const int yi = o / Wl, xs = o - yi * Wl;
-        const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1);
-        const int b_hi = min(W - 1, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1);
-        float acc = 0.f;
-        for (int ox = b_lo; ox <= b_hi; ++ox) {
+    for (int i = tid; i < Wl * XT; i += 256) {
+        const int xs = i / XT, t = i - xs * XT;
+        const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1), ox = b_lo + t;
+        float wgt = 0.f;
+        if (ox < W) {
             int x0, x1;
             float lx;
             bilinear_taps(ox, rw, Wl, x0, x1, lx);
-            acc += ((x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f)) * tcol[yi * W + ox];
+            wgt = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
         }
+        wxw[i] = wgt;
+        if (t == 0) xlo[xs] = b_lo;
+    }
+    if (tid < nys) {
+        const int ys = ys_lo + tid;
+        const int a_lo = max(oy_lo, (int)floorf(((float)ys - 0.5f) / rh - 0.5f) - 1);
+        const int a_hi = min(oy_hi, (int)ceilf(((float)ys + 1.5f) / rh - 0.5f) + 1);
+        yr[tid] = (a_lo - oy_lo) | ((a_hi - oy_lo) << 16);
+    }
+    __syncthreads();
+    // separable: vertical taps first (weights depend on the row only), then horizontal
+    for (int o = tid; o < nys * W; o += 256) {
+        const int yi = o / W, ox = o - yi * W, rr = yr[yi];
+        const float* wv = wyt + yi * max_rows;
+        float acc = 0.f;
+        for (int r = rr & 0xffff; r <= (rr >> 16); ++r) acc += wv[r] * rows[r * W + ox];
+        tcol[o] = acc;
+    }
+    __syncthreads();
+    for (int o = tid; o < nys * Wl; o += 256) {
+        const int yi = o / Wl, xs = o - yi * Wl, b_lo = xlo[xs];
+        const float* wh = wxw + xs * XT;
+        const float* tr = tcol + yi * W;
+        float acc = 0.f;
+        for (int t = 0; t < XT; ++t) acc += wh[t] * tr[min(b_lo + t, W - 1)];  // weights past the row end are zero
         lo[((size_t)pl * Hl + ys_lo + yi) * Wl + xs] = acc;
     }
 }
@@ -675,11 +756,13 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
         for (int j0 = 0; j0 < Cm; j0 += per_pass) {
             const int j = j0 + tid / G, q = tid % G;
             float acc = 0.f, dr = 0.f;
-            if (j < Cm)
-                for (int c = q; c < Co; c += G) {
+            if (j < Cm) {
+#pragma unroll 8
+                for (int c = q; c < Co; c += G) {  // unrolled: the loads are independent, keep many in flight
                     acc += w1[(size_t)j * Co + c] * m[c];
                     dr += w2[(size_t)c * Cm + j] * ds[c];
                 }
+            }
             for (int o = G >> 1; o >= 1; o >>= 1) {
                 acc += __shfl_xor(acc, o, 64);
                 dr += __shfl_xor(dr, o, 64);
@@ -699,8 +782,17 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
     }
     const float inv_p = 1.f / (float)P;
     for (int c = tid; c < Co; c += 256) {
-        float dm = 0.f;
-        for (int j = 0; j < Cm; ++j) dm += w1[(size_t)j * Co + c] * du[j];
+        float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dm3 = 0.f;  // a serial chain of Cm dependent L2 loads took 20 us per image
+        int j = 0;
+#pragma unroll 4
+        for (; j + 3 < Cm; j += 4) {
+            dm0 += w1[(size_t)j * Co + c] * du[j];
+            dm1 += w1[(size_t)(j + 1) * Co + c] * du[j + 1];
+            dm2 += w1[(size_t)(j + 2) * Co + c] * du[j + 2];
+            dm3 += w1[(size_t)(j + 3) * Co + c] * du[j + 3];
+        }
+        for (; j < Cm; ++j) dm0 += w1[(size_t)j * Co + c] * du[j];
+        const float dm = (dm0 + dm1) + (dm2 + dm3);
         const float a1 = 1.f + a[c], a2 = dm * inv_p;
         const float* s = sums + ((size_t)b * Co + c) * 5;
         coef_a1[(size_t)b * Co + c] = a1;
@@ -852,7 +944,13 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
     float* ylow = reinterpret_cast<float*>(base + wt_bytes(s) + stat_bytes(s));
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
                        s.Co, Cin);
-    {   // y_low = W_c . low   at (Hl x Wl)
+    if (small_grid(s.B, s.Co, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0) {
+        // y_low = W_c . low at (Hl x Wl): a few thousand positions -> 64x64 tiles, the weight read as stored
+        SgJobs jobs{};
+        jobs.n = 1;
+        jobs.j[0] = sg_make(w_blk + s.Cs, Cin, 1, low, s.Cc, s.Cc, s.Co, Pl, ylow, s.Co);
+        sg_gemm(jobs, s.B, stream);
+    } else {   // y_low = W_c . low   at (Hl x Wl)
         GemmKArgs a{};
         a.at = wt + (size_t)s.Cs * s.Co, a.lda = s.Co, a.M = s.Co, a.K = s.Cc;
         a.src0 = low, a.src1 = low, a.K0 = s.Cc;
@@ -911,7 +1009,7 @@ size_t ffm_up_bwd_workspace(const FfmShape& s, int Hl, int Wl) { return bwd_layo
 static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const float* dout, const float* z,
                          const float* save_mean, const float* save_invstd, const float* bn_w, const float* bn_b,
                          const float* w1, const float* w2, const float* pooled, const float* gate, int training,
-                         float* dbn_w, float* dbn_b, float* dw1, float* dw2, hipStream_t stream) {
+                         float* dbn_w, float* dbn_b, float* dw1, float* dw2, hipStream_t stream, bool dz_pass = true) {
     const int P = s.H * s.W;
     float* sums = reinterpret_cast<float*>(base + L.sums);
     float* a1 = reinterpret_cast<float*>(base + L.a1);
@@ -928,6 +1026,7 @@ static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const fl
                        sums, pooled, gate, w1, w2, s.Co, s.Cm, P, dw1p, dw2p, dbnp, a1, a2);
     hipLaunchKernelGGL(ffm_bwd_combine_kernel, dim3(ceil_div(s.Co * s.Cm, 256)), dim3(256), 0, stream, dw1p, dw2p, dbnp,
                        s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, mdy, mdyx);
+    if (!dz_pass) return;  // the fused-upsample form computes dz inside the upsample-adjoint kernel
     const int cpr = ceil_div(P, 4096);
     hipLaunchKernelGGL(ffm_dz_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
                        bn_w, bn_b, a1, a2, mdy, mdyx, dz, s.Co, P, cpr);
@@ -1006,8 +1105,39 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
     float* dz = reinterpret_cast<float*>(base + L.dz);
     float* part = reinterpret_cast<float*>(base + L.part);
     float* dzl = reinterpret_cast<float*>(base + L.dzl);
+    // the band decomposition must cover every output row exactly once and fit the staging buffer
+    const int max_rows = (int)((ADJ_BAND + 2) * ((float)s.H / (float)Hl)) + 6, XT = adj_xtaps(s.W, Wl);
+    const bool fuse_dz = s.H >= Hl;  // an upsample (the model's x4); shrinking resizes keep the two-pass form
     ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training, dbn_w, dbn_b,
-                 dw1, dw2, stream);
+                 dw1, dw2, stream, !fuse_dz);
+    // dz_low = U^T dz  (adjoint of the bilinear upsample), then everything on the Cc side is low resolution
+    {
+        const size_t lds = ((size_t)(max_rows + ADJ_BAND) * s.W + (size_t)ADJ_BAND * max_rows + (size_t)Wl * XT + Wl +
+                            ADJ_BAND) * sizeof(float);
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_lds = lds;
+        }
+        DzArgs da{};
+        const dim3 grid(s.B * s.Co * ((Hl + ADJ_BAND - 1) / ADJ_BAND));
+        if (fuse_dz) {
+            da.g = dout, da.z = z, da.mean = save_mean, da.invstd = save_invstd, da.bn_w = bn_w, da.bn_b = bn_b;
+            da.coef_a1 = reinterpret_cast<float*>(base + L.a1), da.coef_a2 = reinterpret_cast<float*>(base + L.a2);
+            da.mean_dy = reinterpret_cast<float*>(base + L.mdy), da.mean_dyx = reinterpret_cast<float*>(base + L.mdyx);
+            da.dz = dz, da.C = s.Co;
+            hipLaunchKernelGGL(upsample_adjoint_kernel<true>, grid, dim3(256), lds, stream, dz, dzl, s.H, s.W, Hl, Wl,
+                               (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, da);
+        } else {
+            hipLaunchKernelGGL(upsample_adjoint_kernel<false>, grid, dim3(256), lds, stream, dz, dzl, s.H, s.W, Hl, Wl,
+                               (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, da);
+        }
+    }
     {   // dfsp = W_s^T dz
         GemmKArgs a{};
         a.at = w_blk, a.lda = Cin, a.M = s.Cs, a.K = s.Co;
@@ -1016,23 +1146,13 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
         a.P = P;
         gemm_kmajor(a, s.B, stream);
     }
-    // dz_low = U^T dz  (adjoint of the bilinear upsample), then everything on the Cc side is low resolution
-    {
-        // output rows one band of ADJ_BAND source rows can touch (ratio = H / Hl), with slack
-        const int max_rows = (int)((ADJ_BAND + 2) * ((float)s.H / (float)Hl)) + 6;
-        const size_t lds = (size_t)(max_rows + ADJ_BAND) * s.W * sizeof(float);
-        static size_t attr_lds = 0;
-        if (lds > attr_lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_lds = lds;
-        }
-        hipLaunchKernelGGL(upsample_adjoint_kernel, dim3(s.B * s.Co * ((Hl + ADJ_BAND - 1) / ADJ_BAND)), dim3(256), lds,
-                           stream, dz, dzl, s.H, s.W, Hl, Wl, (float)Hl / (float)s.H, (float)Wl / (float)s.W,
-                           max_rows);
-    }
-    {   // dlow = W_c^T dz_low
+    const bool small = small_grid(s.B, s.Cc, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0 && (s.Co % 4) == 0;
+    if (small) {  // dlow = W_c^T dz_low: the (Co x Cin) weight is the K-major A operand as stored
+        SgJobs jobs{};
+        jobs.n = 1;
+        jobs.j[0] = sg_make(w_blk + s.Cs, Cin, 0, dzl, s.Co, s.Co, s.Cc, Pl, dlow, s.Cc);
+        sg_gemm(jobs, s.B, stream);
+    } else {   // dlow = W_c^T dz_low
         GemmKArgs a{};
         a.at = w_blk + s.Cs, a.lda = Cin, a.M = s.Cc, a.K = s.Co;
         a.src0 = dzl, a.src1 = dzl, a.K0 = s.Co;
@@ -1042,6 +1162,12 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
     }
     hipError_t e = dw_product(dz, fsp, s.B, s.Co, s.Cs, P, part, dw_blk, Cin, 0, stream);
     if (e != hipSuccess) return e;
+    if (small) {  // dW_c = dz_low low^T over the low-resolution positions
+        SdJobs jobs{};
+        jobs.n = 1;
+        jobs.j[0] = sd_make(dzl, s.Co, low, s.Cc, s.Co, s.Cc, Pl, dw_blk, Cin, s.Cs);
+        return sd_run(jobs, s.B, part, stream);
+    }
     return dw_product(dzl, low, s.B, s.Co, s.Cc, Pl, part, dw_blk, Cin, s.Cs, stream);
 }
 
