@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--kernels-only", action="store_true", help="only time the hand-written kernels (dev aid)")
+    ap.add_argument("--no-graph", action="store_true", help="single GPU: enqueue every step eagerly instead of replaying "
+                    "the step's two captured hipGraphs")
     return ap.parse_args()
 
 
@@ -81,63 +83,33 @@ def time_kernel(fn, iters, warm=3):
     return start.elapsed_time(stop) / iters
 
 
-_PMC_KEYS = {  # bench kernel group -> rocprofv3 kernel names whose HBM traffic it sums
-    "cab_attn_fwd": ["cabinet::cab_attn_fwd_kernel<128, 128>"],
-    "cab_attn_bwd": ["cabinet::cab_attn_bwd_dq_fast_kernel<128, 128>", "cabinet::cab_attn_bwd_dkdv_fast_kernel<128, 128>"],
-    "ffm_fwd": ["cabinet::transpose_kernel", "cabinet::gemm_kmajor_kernel<2, true>", "cabinet::bn_finalize_kernel",
-                "cabinet::ffm_pool_kernel", "cabinet::ffm_se_kernel", "cabinet::ffm_gate_kernel"],
-    "ffm_bwd": None,      # (plain form: not re-profiled after the dW split; see profiles/r01_pmc_counters.json)
-    "ffm_up_fwd": None,   # several launches of the same kernel symbols with different shapes: per-launch PMC
-    "ffm_up_bwd": None,   # rows cannot be attributed by name alone
-}
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
-_PMC_GROUP_KEYS = {  # bench kernel group -> (group of profiles/r01_pmc_groups.json, kernels summed, one launch each)
-    "bn_act_fwd": ("bn_act", ["cabinet::bn_act_stats_kernel", "cabinet::bn_act_finalize_kernel",
-                              "cabinet::bn_act_apply_kernel"]),
-    "bn_act_bwd": ("bn_act", ["cabinet::bn_act_bwd_reduce_kernel", "cabinet::bn_act_bwd_finalize_kernel",
-                              "cabinet::bn_act_bwd_dx_kernel"]),
-    "ohem_up_fwd": ("ohem", ["cabinet::ohem_up_fwd_kernel<8>"]),
-    "ohem_up_bwd": ("ohem", ["cabinet::ohem_up_bwd_x_kernel<8>", "cabinet::ohem_up_bwd_y_kernel"]),
-    "cab_local_fwd": ("cab", ["cabinet::cab_local_fwd_kernel"]),
-    "cab_local_bwd": ("cab", ["cabinet::cab_local_bwd_kernel"]),
-}
+def load_traffic(batch, size):
+    """HBM bytes per launch of every kernel group, from the committed PMC profile (tools/pmc_traffic.sh: rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE in separate passes, counters only; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950
+    FETCH calibration of MI355X_MICROARCH.md).  The profile records the digest of the kernel sources it was collected
+    on: it is used ONLY when that digest equals the one of the library this process loaded and the shape matches --
+    otherwise every `traffic` is null (stale evidence is not evidence)."""
+    from cabinet_amd import build as _build
+
+    if not os.path.exists(TRAFFIC_PROFILE):
+        return {}, "none: profiles/r02_pmc_traffic.json absent"
+    prof = json.load(open(TRAFFIC_PROFILE))
+    if prof.get("source_digest") != _build.source_digest():
+        return {}, "none: profiles/r02_pmc_traffic.json was collected on other kernel sources (digest mismatch)"
+    if (prof.get("batch"), prof.get("size")) != (batch, size):
+        return {}, "none: profiles/r02_pmc_traffic.json was collected at another shape"
+    return prof.get("traffic", {}), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, FETCH x2 calibrated, digest-checked)"
 
 
-def measured_traffic(group, batch, size):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_counters.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per the gfx950 calibration in that file).
-    Only valid for the shape the counters were collected at (config 3); otherwise None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
-    if (batch, size) != (8, 1024) or not os.path.exists(path):
-        return None
-    pmc = json.load(open(path))
-    total = 0.0
-    if group in _PMC_GROUP_KEYS:
-        gpath = os.path.join(ROOT, "profiles", "r01_pmc_groups.json")
-        if not os.path.exists(gpath):
-            return None
-        gname, kernels = _PMC_GROUP_KEYS[group]
-        g = json.load(open(gpath)).get(gname, {})
-        for name in kernels:
-            c = g.get(name)
-            if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-                return None
-            total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        return round(total)
-    if not _PMC_KEYS.get(group):
-        return None
-    for name in _PMC_KEYS[group]:
-        c = pmc.get(name)
-        if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-            return None
-        total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-    return round(total)
-
-
-def kernel_rooflines(batch, size, iters):
-    """Per hand-written kernel group at this workload's shapes: duration from HIP events, algorithmic
-    work per launch from SURVEY.md section 8(d) / BASELINE.md section 3."""
+def kernel_cases(batch, size):
+    """Generator over the hand-written kernel groups at this workload's shapes: yields
+    (name, launch closure, algorithmic FLOPs, algorithmic bytes, bound) one group at a time (operands of a finished group
+    are freed before the next is built).  Algorithmic work per launch: SURVEY.md section 8(d) / BASELINE.md section 3.
+    Consumers: kernel_rooflines() below (HIP-event timing) and tools/run_kernels.py (the same launches under rocprofv3
+    for the PMC / kernel-trace passes)."""
     from cabinet_amd import functional as Fh
 
     dev = "cuda"
@@ -152,40 +124,9 @@ def kernel_rooflines(batch, size, iters):
     dctx = torch.randn(B, Vc, n, generator=g).to(dev)
     scale = Kc ** -0.5
     ctx, lse = Fh.attn_fwd_hip(q, k, v, scale)
-    out = []
-
-    notes = {
-        "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
-        "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
-        "cab_qkv_fwd": "11 dependent launches of <= 10 us of work each: launch-latency bound",
-        "cab_qkv_bwd": "~20 dependent launches of <= 10 us of work each: launch-latency bound",
-        "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
-        "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
-        "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
-        "bn_dwconv_bwd": "the depthwise stencil backward is VALU bound; the BatchNorm dx pass is HBM bound",
-    }
-
-    def entry(name, ms, flops, bytes_, bound):
-        tf = flops / (ms * 1e-3) / 1e12
-        gbs = bytes_ / (ms * 1e-3) / 1e9
-        if bound == "mfma":
-            r = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                     frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
-        else:
-            r = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                     frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None)
-        r["traffic"] = measured_traffic(name.split(" ")[0], batch, size)
-        if name.split(" ")[0] in notes:
-            r["note"] = notes[name.split(" ")[0]]
-        r.update(kernel=name, ms_per_launch=round(ms, 4), algorithmic_gflop=round(flops / 1e9, 3),
-                 algorithmic_mbytes=round(bytes_ / 1e6, 1), tflops=round(tf, 2), gbytes_per_s=round(gbs, 1))
-        out.append(r)
-
-    ms = time_kernel(lambda: Fh.attn_fwd_hip(q, k, v, scale), iters)
-    entry("cab_attn_fwd (K1: affinity+softmax+aggregate)", ms, 2.0 * B * n * n * (Kc + Vc),
+    yield ("cab_attn_fwd (K1: affinity+softmax+aggregate)", lambda: Fh.attn_fwd_hip(q, k, v, scale), 2.0 * B * n * n * (Kc + Vc),
           4.0 * B * n * (2 * Kc + 2 * Vc) + 4.0 * B * n, "mfma")
-    ms = time_kernel(lambda: Fh.attn_bwd_hip(dctx, q, k, v, ctx, lse, scale), iters)
-    entry("cab_attn_bwd (K2: dq + dk/dv, S recomputed)", ms, 2.0 * B * n * n * (3 * Kc + 2 * Vc),
+    yield ("cab_attn_bwd (K2: dq + dk/dv, S recomputed)", lambda: Fh.attn_bwd_hip(dctx, q, k, v, ctx, lse, scale), 2.0 * B * n * n * (3 * Kc + 2 * Vc),
           4.0 * B * n * (3 * Kc + 3 * Vc) * 2 + 8.0 * B * n, "mfma")
 
     Cs, Cc, Co, Cm = 128, 256, 256, 64
@@ -199,13 +140,11 @@ def kernel_rooflines(batch, size, iters):
     dout = torch.randn(B, Co, h, w, generator=g).to(dev)
     fwd = lambda: Fh.ffm_fwd_hip(fsp, fcp, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
     o, z, mean, invstd, pooled, gate = fwd()
-    ms = time_kernel(fwd, iters)
     # this build's pass structure: read fsp,fcp; write z; read z (stats); read z (pool); read z, write out
-    entry("ffm_fwd (K3: 1x1 GEMM + BN stats, pool, gate)", ms, 2.0 * B * P * (Cs + Cc) * Co,
+    yield ("ffm_fwd (K3: 1x1 GEMM + BN stats, pool, gate)", fwd, 2.0 * B * P * (Cs + Cc) * Co,
           4.0 * B * P * ((Cs + Cc) + 5 * Co), "mfma")
     bwd = lambda: Fh.ffm_bwd_hip(dout, fsp, fcp, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
-    ms = time_kernel(bwd, iters)
-    entry("ffm_bwd (K4: reduce, dz, dX GEMM, dW split-K GEMM)", ms, 4.0 * B * P * (Cs + Cc) * Co,
+    yield ("ffm_bwd (K4: reduce, dz, dX GEMM, dW split-K GEMM)", bwd, 4.0 * B * P * (Cs + Cc) * Co,
           4.0 * B * P * (2 * Co + 2 * Co + Co + Co + (Cs + Cc) + Co + (Cs + Cc)), "mfma")
     # ---- the form CABiNet.forward uses: bilinear upsample of `low` fused into the FFM.
     # conv and resize commute, so the Cc part runs at low resolution: executed GEMM work drops 2.7x and the
@@ -215,15 +154,13 @@ def kernel_rooflines(batch, size, iters):
     low = torch.randn(B, Cc, hl, wl, generator=g).to(dev)
     upf = lambda: Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
     o, z, mean, invstd, pooled, gate = upf()
-    ms = time_kernel(upf, iters)
     fl_f = 2.0 * B * Co * (P * Cs + Pl * Cc)
     by_f = 4.0 * B * (P * (Cs + 5 * Co) + Pl * (Cc + 2 * Co))
-    entry("ffm_up_fwd (K3': resize fused, conv commuted to low res)", ms, fl_f, by_f, "hbm")
+    yield ("ffm_up_fwd (K3': resize fused, conv commuted to low res)", upf, fl_f, by_f, "hbm")
     upb = lambda: Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
-    ms = time_kernel(upb, iters)
     fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
     by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))
-    entry("ffm_up_bwd (K4': reduce, dz, dfsp GEMM, U^T dz, low-res GEMMs, dW)", ms, fl_b, by_b, "hbm")
+    yield ("ffm_up_bwd (K4': reduce, dz, dfsp GEMM, U^T dz, low-res GEMMs, dW)", upb, fl_b, by_b, "hbm")
     del fsp, fcp, dout, o, z, low
     torch.cuda.empty_cache()
 
@@ -236,13 +173,11 @@ def kernel_rooflines(batch, size, iters):
     bnw, bnb = torch.ones(Cb, device=dev), torch.zeros(Cb, device=dev)
     brm, brv = torch.zeros(Cb, device=dev), torch.ones(Cb, device=dev)
     fwd = lambda: Fh._BnAct.apply(xb, bnw, bnb, brm, brv, 2, True, 0.1, 1e-5)  # noqa: E731
-    ms = time_kernel(fwd, iters)
     nbytes = 4.0 * xb.numel()
-    entry("bn_act_fwd (K7: BatchNorm + HardSwish, stats + apply)", ms, 12.0 * xb.numel(), 3 * nbytes, "hbm")
+    yield ("bn_act_fwd (K7: BatchNorm + HardSwish, stats + apply)", fwd, 12.0 * xb.numel(), 3 * nbytes, "hbm")
     xg = xb.clone().requires_grad_(True)
     yb = Fh._BnAct.apply(xg, bnw, bnb, brm, brv, 2, True, 0.1, 1e-5)
-    ms = time_kernel(lambda: torch.autograd.grad(yb, xg, gb, retain_graph=True), iters)
-    entry("bn_act_bwd (K7: reduce + dx, pre-activation recomputed)", ms, 30.0 * xb.numel(), 5 * nbytes, "hbm")
+    yield ("bn_act_bwd (K7: reduce + dx, pre-activation recomputed)", lambda: torch.autograd.grad(yb, xg, gb, retain_graph=True), 30.0 * xb.numel(), 5 * nbytes, "hbm")
     del xb, gb, xg, yb
     torch.cuda.empty_cache()
 
@@ -257,11 +192,9 @@ def kernel_rooflines(batch, size, iters):
     yb = Fh.bn_act_dwconv(zb, bn, "hardswish", conv)
     gy = torch.randn(yb.shape, generator=g).to(dev)
     nz, ny = 4.0 * zb.numel(), 4.0 * yb.numel()
-    ms = time_kernel(lambda: Fh.bn_act_dwconv(zb.detach(), bn, "hardswish", conv), iters)
-    entry("bn_dwconv_fwd (K8: BN stats + 3x3/2 depthwise conv with BN+HardSwish folded in)", ms, 28.0 * yb.numel(),
+    yield ("bn_dwconv_fwd (K8: BN stats + 3x3/2 depthwise conv with BN+HardSwish folded in)", lambda: Fh.bn_act_dwconv(zb.detach(), bn, "hardswish", conv), 28.0 * yb.numel(),
           2 * nz + ny, "hbm")
-    ms = time_kernel(lambda: torch.autograd.grad(yb, (zb, conv.weight, bn.weight), gy, retain_graph=True), iters)
-    entry("bn_dwconv_bwd (K8: dx + dw + BN partial sums, then BN dx)", ms, 60.0 * yb.numel(), ny + 5 * nz, "hbm")
+    yield ("bn_dwconv_bwd (K8: dx + dw + BN partial sums, then BN dx)", lambda: torch.autograd.grad(yb, (zb, conv.weight, bn.weight), gy, retain_graph=True), 60.0 * yb.numel(), ny + 5 * nz, "hbm")
     del zb, yb, gy
     torch.cuda.empty_cache()
 
@@ -271,10 +204,8 @@ def kernel_rooflines(batch, size, iters):
     ys = Fh.stem_conv(img, stem)
     gs = torch.randn(ys.shape, generator=g).to(dev)
     fl_s = 2.0 * ys.numel() * 147
-    ms = time_kernel(lambda: Fh.stem_conv(img, stem), iters)
-    entry("stem_conv_fwd (K9: 7x7/2, patch gather from LDS)", ms, fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
-    ms = time_kernel(lambda: torch.autograd.grad(ys, stem.weight, gs, retain_graph=True), iters)
-    entry("stem_conv_wrw (K9: contraction over pixels, ordered slabs)", ms, fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
+    yield ("stem_conv_fwd (K9: 7x7/2, patch gather from LDS)", lambda: Fh.stem_conv(img, stem), fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
+    yield ("stem_conv_wrw (K9: contraction over pixels, ordered slabs)", lambda: torch.autograd.grad(ys, stem.weight, gs, retain_graph=True), fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
     del img, ys, gs
     torch.cuda.empty_cache()
 
@@ -284,10 +215,8 @@ def kernel_rooflines(batch, size, iters):
     yp = Fh.pwconv(xp, pw)
     gp = torch.randn(yp.shape, generator=g).to(dev)
     nx, nyp = 4.0 * xp.numel(), 4.0 * yp.numel()
-    ms = time_kernel(lambda: Fh.pwconv(xp.detach(), pw), iters)
-    entry("pwconv_fwd (K10: streaming 1x1 conv 16->64)", ms, 2.0 * yp.numel() * 16, nx + nyp, "hbm")
-    ms = time_kernel(lambda: torch.autograd.grad(yp, (xp, pw.weight), gp, retain_graph=True), iters)
-    entry("pwconv_bwd (K10: dx stream + wgrad slabs)", ms, 4.0 * yp.numel() * 16, 2 * nyp + 2 * nx, "hbm")
+    yield ("pwconv_fwd (K10: streaming 1x1 conv 16->64)", lambda: Fh.pwconv(xp.detach(), pw), 2.0 * yp.numel() * 16, nx + nyp, "hbm")
+    yield ("pwconv_bwd (K10: dx stream + wgrad slabs)", lambda: torch.autograd.grad(yp, (xp, pw.weight), gp, retain_graph=True), 4.0 * yp.numel() * 16, 2 * nyp + 2 * nx, "hbm")
     del xp, yp, gp
     torch.cuda.empty_cache()
 
@@ -295,12 +224,10 @@ def kernel_rooflines(batch, size, iters):
     ncls = 8
     lowl = torch.randn(B, ncls, size // 8, size // 8, generator=g).to(dev)
     lab = torch.randint(0, ncls, (B, size, size), generator=g).to(dev)
-    ms = time_kernel(lambda: Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255), iters)
     px = float(B * size * size)
-    entry("ohem_up_fwd (f3: upsample + CE + OHEM partials)", ms, px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
+    yield ("ohem_up_fwd (f3: upsample + CE + OHEM partials)", lambda: Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255), px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
     loss_px = Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255)[0]
-    ms = time_kernel(lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (size, size), 0.7, 255, 1e-6), iters)
-    entry("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)", ms, px * ncls * 16,
+    yield ("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)", lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (size, size), 0.7, 255, 1e-6), px * ncls * 16,
           px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * size * (size // 8), "hbm")
 
     # ---- K5 / K6: the rest of the Context Aggregation Block at (B, 256, size/32, size/32)
@@ -311,17 +238,51 @@ def kernel_rooflines(batch, size, iters):
     gc = torch.randn(B, 256, size // 32, size // 32, generator=g).to(dev)
     elems = float(xc.numel())
     yl = cab.local_attn(xc)
-    ms = time_kernel(lambda: cab.local_attn(xc.detach()), iters)
-    entry("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", ms, elems * 3 * 22, 8.0 * elems, "hbm")
-    ms = time_kernel(lambda: torch.autograd.grad(yl, xc, gc, retain_graph=True), iters)
-    entry("cab_local_bwd (K5: chain recomputed in LDS)", ms, elems * 3 * 60, 12.0 * elems, "hbm")
+    yield ("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", lambda: cab.local_attn(xc.detach()), elems * 3 * 22, 8.0 * elems, "hbm")
+    yield ("cab_local_bwd (K5: chain recomputed in LDS)", lambda: torch.autograd.grad(yl, xc, gc, retain_graph=True), elems * 3 * 60, 12.0 * elems, "hbm")
     q3 = Fh.cab_qkv(xc, cab.global_attn)
     gq = [torch.randn_like(t) for t in q3]
-    ms = time_kernel(lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), iters)
     fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
-    entry("cab_qkv_fwd (K6: projections + BN + PSP, 11 launches)", ms, fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
-    ms = time_kernel(lambda: torch.autograd.grad(q3, xc, gq, retain_graph=True), iters)
-    entry("cab_qkv_bwd (K6: adjoint chain, ~20 launches)", ms, 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
+    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 6 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
+    yield ("cab_qkv_bwd (K6: adjoint chain, 7 launches)", lambda: torch.autograd.grad(q3, xc, gq, retain_graph=True), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
+
+
+
+_NOTES = {
+    "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
+    "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
+    "cab_qkv_fwd": "6 dependent launches of <= 25 us each on 8192 positions: latency / small-tile MFMA bound",
+    "cab_qkv_bwd": "7 dependent launches on 8192 positions: latency / small-tile MFMA bound",
+    "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
+    "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
+    "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
+    "bn_dwconv_bwd": "the depthwise stencil backward is VALU bound; the BatchNorm dx pass is HBM bound",
+}
+
+
+def kernel_rooflines(batch, size, iters):
+    """Per hand-written kernel group: launch duration from HIP events on the stream the kernels run on, achieved
+    TFLOP/s / GB/s against the gfx950 peaks, and the measured HBM traffic when a PMC profile of THIS build exists."""
+    out = []
+    traffic, traffic_src = load_traffic(batch, size)
+    for name, fn, flops, bytes_, bound in kernel_cases(batch, size):
+        ms = time_kernel(fn, iters)
+        tf = flops / (ms * 1e-3) / 1e12
+        gbs = bytes_ / (ms * 1e-3) / 1e9
+        if bound == "mfma":
+            r = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                     frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+        else:
+            r = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                     frac=round(gbs / PEAK_HBM_GBS, 4))
+        key = name.split(" ")[0]
+        r["traffic"] = traffic.get(key)
+        r["traffic_source"] = traffic_src
+        if key in _NOTES:
+            r["note"] = _NOTES[key]
+        r.update(kernel=name, ms_per_launch=round(ms, 4), algorithmic_gflop=round(flops / 1e9, 3),
+                 algorithmic_mbytes=round(bytes_ / 1e6, 1), tflops=round(tf, 2), gbytes_per_s=round(gbs, 1))
+        out.append(r)
     return out
 
 
@@ -329,7 +290,7 @@ def main():
     args = parse()
     t_start = time.perf_counter()
     from cabinet_amd.ddp import BucketedGradReducer, init_distributed
-    from cabinet_amd.train import TrainStep, build_model, make_criteria, synthetic_batch
+    from cabinet_amd.train import GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -351,7 +312,14 @@ def main():
     reducer = BucketedGradReducer(net, always_reduce=True) if ddp else None
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
                           weight_decay=5e-4)
-    step = TrainStep(net, make_criteria(args.batch, args.size, args.size, dev), reducer=reducer, optimizer=opt)
+    graphed = not ddp and not args.no_graph
+    crit = make_criteria(args.batch, args.size, args.size, dev)
+    if graphed:   # the step replayed from two hipGraphs around its one host read (cabinet_amd/train.py)
+        step = GraphedTrainStep(net, crit, optimizer=opt)
+        step_nopt = GraphedTrainStep(net, crit, optimizer=None)
+    else:
+        step = TrainStep(net, crit, reducer=reducer, optimizer=opt)
+        step_nopt = None
     im, lb = synthetic_batch(args.batch, args.size, args.size, args.classes, dev, seed=1 + rank)
 
     def sync():
@@ -382,6 +350,27 @@ def main():
         dt = float(t)
     final_loss = float(loss)
     log(f"timed region {dt:.3f}s -> {world * args.batch * args.steps / dt:.2f} images/s")
+    # SURVEY.md section 8(d) words the metric as forward + 2x OHEM-CE + backward; `value` above also contains the gradient
+    # all-reduce and the SGD step (conservative).  The same K steps without the optimizer, reported next to it:
+    if step_nopt is None:
+        step.optimizer = None
+        runner = step
+    else:
+        runner = step_nopt
+        for _ in range(2):
+            runner(im, lb)  # eager warm-up + capture (outside the timed region)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner(im, lb)
+    sync()
+    dt_nopt = time.perf_counter() - t0
+    if step_nopt is None:
+        step.optimizer = opt
+    if ddp:
+        t = torch.tensor([dt_nopt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt_nopt = float(t)
 
     result = None
     if rank == 0:
@@ -400,12 +389,18 @@ def main():
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image_size": args.size,
                 "n_classes": args.classes, "parallelism": f"dp{world}",
                 "grad_buckets_mb": [round(x, 2) for x in reducer.bucket_megabytes] if reducer else None,
+                "host_path": ("two captured hipGraphs per step around the one OHEM read-back (GraphedTrainStep)" if graphed
+                              else "eager enqueue (TrainStep)"),
             },
             "final_loss": round(final_loss, 5),
+            "fwd_loss_bwd_only": {"value": round(images / dt_nopt, 3), "unit": "images/s",
+                                  "ms_per_step": round(dt_nopt / args.steps * 1e3, 3),
+                                  "what": "the same K steps without the SGD step (forward + 2x OHEM-CE + backward"
+                                          + (" + gradient all-reduce)" if ddp else ")")},
         }
     # ---- per-kernel rooflines and CPU baseline: rank 0, outside the timed region -----------------
     if rank == 0 and not args.no_kernel_roofline:
-        del step, opt
+        del step, step_nopt, runner, opt
         torch.cuda.empty_cache()
         ks = kernel_rooflines(args.batch, args.size, args.kernel_iters)
         log("kernel rooflines measured")
@@ -417,7 +412,7 @@ def main():
         result["roofline"] = {k: k1[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
         result["roofline"].update(kernel=k1["kernel"], ms_per_launch=k1["ms_per_launch"],
                                   algorithmic_bytes=round(k1["algorithmic_mbytes"] * 1e6),
-                                  traffic_source="profiles/r01_pmc_counters.json (rocprofv3 --pmc, FETCH x2 calibrated)",
+                                  traffic_source=k1["traffic_source"],
                                   peak_is="dense fp32 MFMA (v_mfma_f32_32x32x2_f32), not bf16",
                                   longest_kernel_group=dom["kernel"], longest_kernel_frac=dom["frac"])
     if ddp:
@@ -426,12 +421,23 @@ def main():
         from oracle import model_ref
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         cb = model_ref.time_cpu_baseline(sd, args.mode, args.cpu_batch, args.size, args.classes)
+        # the timed HIP model, on the very sample the CPU leg just ran, from the same weights: the model that was timed is
+        # checked in the run that timed it
+        import copy
+
+        net_chk = copy.deepcopy(net).train()
+        xs, ls = model_ref.baseline_sample(args.cpu_batch, args.size, args.classes)
+        chk = TrainStep(net_chk, make_criteria(args.cpu_batch, args.size, args.size, dev))
+        loss_gpu = float(chk(xs.to(dev), ls.to(dev)))
+        del net_chk, chk
         result["cpu_baseline"] = {
             "value": round(cb["value"], 4), "unit": "images/s", "cores": cb["cores"], "kind": "port",
             "sample": (f"oracle/model_ref.py (PyTorch-CPU fp32 restatement of the reference, pinned to reference "
                        f"vectors): B={args.cpu_batch} {args.size}x{args.size}, 1 warm-up + {cb['timed_steps']} timed steps "
                        f"({cb['seconds']:.1f} s) of fwd + 2x OhemCE + bwd"),
             "seconds_per_step": round(cb["seconds_per_step"], 3),
+            "loss_cpu": round(cb["loss"], 6), "loss_gpu_same_sample": round(loss_gpu, 6),
+            "loss_rel_diff": abs(loss_gpu - cb["loss"]) / abs(cb["loss"]),
         }
     # RCCL (NCCL_DEBUG=VERSION on these boxes) writes its version banner to C stdout, which is only flushed at exit:
     # every rank pushes it out now, so that rank 0's JSON line is the LAST line of the job's stdout

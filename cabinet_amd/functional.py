@@ -356,21 +356,23 @@ def ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, coef):
 
 class _OhemUpSelected(torch.autograd.Function):
     """loss = sum_above / n_above for the 'at least n_min pixels above thresh' branch (reference loss.py:74-75);
-    forward statistics were produced by ohem_up_fwd_hip, backward runs the two adjoint kernels."""
+    forward statistics were produced by ohem_up_fwd_hip, backward runs the two adjoint kernels.  ``n_above`` is a DEVICE
+    scalar: nothing of the step's data-dependent state is baked into a kernel argument, so the op can be replayed from a
+    captured hipGraph (cabinet_amd.train.GraphedTrainStep); the host only reads it to pick the branch."""
 
     @staticmethod
     def forward(fn_ctx, logits_low, labels, loss_px, sum_above, n_above, size, thresh, ignore_lb):
-        fn_ctx.save_for_backward(logits_low, labels, loss_px)
-        fn_ctx.meta = (size, thresh, ignore_lb, n_above)
+        fn_ctx.save_for_backward(logits_low, labels, loss_px, n_above)
+        fn_ctx.meta = (size, thresh, ignore_lb)
         return (sum_above / n_above).to(torch.float32)
 
     @staticmethod
     def backward(fn_ctx, g):
-        logits_low, labels, loss_px = fn_ctx.saved_tensors
-        size, thresh, ignore_lb, n_above = fn_ctx.meta
-        # the upstream gradient is a device scalar: fold it in after the kernels (coef = 1/n_above inside)
-        dlow = ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, 1.0 / n_above)
-        return dlow * g, None, None, None, None, None, None, None
+        logits_low, labels, loss_px, n_above = fn_ctx.saved_tensors
+        size, thresh, ignore_lb = fn_ctx.meta
+        # the kernels produce U^T[sel * (softmax - onehot)]; upstream gradient and 1/n_above are device scalars folded in after
+        dlow = ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, 1.0)
+        return dlow * (g / n_above).to(torch.float32), None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- CAB local branch + block output (K5)

@@ -89,7 +89,7 @@ class OhemCELoss(nn.Module):
             if n_valid == 0:
                 return torch.zeros((), device=logits_low.device, requires_grad=True)
             if n_above >= min(self.n_min, n_valid):
-                return _OhemUpSelected.apply(low, lab, loss_px, stats[2], n_above, size, self.thresh, self.ignore_lb)
+                return _OhemUpSelected.apply(low, lab, loss_px, stats[2], stats[1], size, self.thresh, self.ignore_lb)
         up = F.interpolate(logits_low, size=size, mode="bilinear", align_corners=False)
         return self.forward(up, labels)
 

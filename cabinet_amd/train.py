@@ -103,6 +103,101 @@ class TrainStep:
         return loss.detach()
 
 
+class GraphedTrainStep:
+    """TrainStep replayed from two hipGraphs around the step's ONE host read (single process, fused loss).
+
+    Per step the host normally enqueues ~1,100 kernels (13 ms of Python / ctypes / autograd at config 3, for 28 ms of GPU
+    work; with 8 ranks on a 16-core host that margin is gone).  Here the step is captured once:
+
+        graph A   forward of the network + the OHEM forward kernels of both heads + their reduced statistics
+        host      reads the 2 x (n_valid, n_above) counts and decides the OHEM branch      (the step's one sync)
+        graph B   OHEM 'at least n_min pixels above thresh' branch, loss, backward, optimizer step
+
+    and replayed with three host calls.  Nothing data-dependent is baked into a kernel argument (n_above is a device
+    scalar in the loss).  If the host read says a head needs the rare top-n_min branch (or has no valid pixel), the step
+    restores the BatchNorm buffers graph A advanced and runs eagerly instead -- same result as TrainStep, just slower.
+    Inputs are copied into static tensors; the returned loss is a static device tensor (read it before the next step).
+    Data-parallel runs keep the eager TrainStep: its reducer launches collectives from autograd hooks."""
+
+    def __init__(self, net, criteria, optimizer=None, warmup=2):
+        self.net, (self.crit_p, self.crit_16) = net, criteria
+        self.optimizer, self.warmup = optimizer, warmup
+        self.eager = TrainStep(net, criteria, optimizer=optimizer)
+        self.g_fwd = self.g_bwd = None
+        self.fallbacks = self._calls = 0
+
+    def _capture(self, im, lb):
+        """Record the two graphs on this batch.  Nothing of the step executes here (capture only records), except one
+        replay of graph A to learn the batch's OHEM branch, whose BatchNorm side effects are undone."""
+        self.s_im, self.s_lb = im.clone(), lb.clone()
+        self.buffers = [b for b in self.net.buffers()]
+        self.backup = [b.clone() for b in self.buffers]
+        for p in self.net.parameters():
+            p.grad = None
+        size = tuple(im.shape[2:])
+        torch.cuda.synchronize()
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd):
+            low, low16 = self.net.forward_lowres(self.s_im)
+            self.pa = self.crit_p._fused_launch(low, self.s_lb, size)
+            self.pb = self.crit_16._fused_launch(low16, self.s_lb, size)
+            if self.pa[5] is None or self.pb[5] is None:
+                raise RuntimeError("GraphedTrainStep needs the fused OHEM head (device logits, <= 32 classes, no class weights)")
+            self.s_stats = torch.stack([self.pa[5][1], self.pb[5][1]])
+        # capture does not execute: replay once to learn the capture batch's branch, then undo its BatchNorm side effects
+        torch._foreach_copy_(self.backup, self.buffers)
+        self.g_fwd.replay()
+        host = self.s_stats.tolist()
+        torch._foreach_copy_(self.buffers, self.backup)
+        if not all(self._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
+            raise RuntimeError("GraphedTrainStep: capture batch does not take the OHEM 'n_min above thresh' branch; "
+                               "capture on a representative batch")
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+            loss = self.crit_p._fused_finish(self.pa, host[0]) + self.crit_16._fused_finish(self.pb, host[1])
+            loss.backward()
+            if self.optimizer is not None:
+                self.optimizer.step()
+            self.s_loss = loss.detach()
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def _selected_branch(crit, host):
+        n_valid, n_above = int(host[0]), int(host[1])
+        if n_valid < 0:
+            raise RuntimeError("OhemCELoss: label out of range (and != ignore_lb)")
+        return n_valid > 0 and n_above >= min(crit.n_min, n_valid)
+
+    def __call__(self, im, lb):
+        if self.g_fwd is None:
+            # the first max(1, warmup) steps run eagerly: every lazy initialisation happens outside capture (MIOpen solver
+            # choice, kernel attributes, and the optimizer's state -- SGD creates its momentum buffers in the first step(),
+            # a captured first step would re-create them on every replay); the graphs are recorded after the last of them
+            self._calls += 1
+            loss = self.eager(im, lb)
+            if self._calls >= max(1, self.warmup):
+                self._capture(im, lb)
+            return loss
+        self.s_im.copy_(im, non_blocking=True)
+        self.s_lb.copy_(lb, non_blocking=True)
+        torch._foreach_copy_(self.backup, self.buffers)
+        self.g_fwd.replay()
+        host = self.s_stats.tolist()  # the step's one host sync
+        if all(self._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
+            self.g_bwd.replay()
+            return self.s_loss
+        # rare branch (late training: fewer than n_min hard pixels): undo graph A's BatchNorm side effects, run eagerly
+        self.fallbacks += 1
+        torch._foreach_copy_(self.buffers, self.backup)
+        grads = [p.grad for p in self.net.parameters()]
+        loss = self.eager(im, lb)
+        for p, g in zip(self.net.parameters(), grads):  # keep the static gradient tensors the graphs write to
+            if g is not None and p.grad is not None and p.grad is not g:
+                g.copy_(p.grad)
+                p.grad = g
+        return loss
+
+
 def synthetic_batch(batch, height, width, n_classes, device, seed=1):
     """Inputs of BASELINE.md section 2: images ~ N(0,1), labels uniform over classes, no ignore pixels."""
     g = torch.Generator().manual_seed(seed)

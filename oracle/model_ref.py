@@ -267,20 +267,26 @@ def usable_cpu_threads(cap=64):
     return max(1, min(n, cap))
 
 
+def baseline_sample(batch, size, n_classes):
+    """The bounded sample the CPU baseline is timed on (and the HIP model is checked on, in the same bench run)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    lb = torch.randint(0, n_classes, (batch, size, size), generator=g)
+    return x, lb
+
+
 def time_cpu_baseline(state_dict, mode, batch, size, n_classes, steps=8, warmup=1, threads=None,
                       min_seconds=10.0, max_seconds=40.0):
     """Images/s of the CPU restatement on synthetic data (bench.py cpu_baseline leg)."""
     threads = threads or usable_cpu_threads()
     torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(batch, 3, size, size, generator=g)
-    lb = torch.randint(0, n_classes, (batch, size, size), generator=g)
-    times, it = [], 0
+    x, lb = baseline_sample(batch, size, n_classes)
+    times, it, loss = [], 0, None
     # bounded sample: `warmup` untimed steps, then timed steps until ~min_seconds of CPU work or `steps`
     while True:
         w = Weights(state_dict)
         t0 = time.perf_counter()
-        train_step(w, x, lb, mode)
+        loss = train_step(w, x, lb, mode)[2]
         dt = time.perf_counter() - t0
         if it >= warmup:
             times.append(dt)
@@ -290,4 +296,4 @@ def time_cpu_baseline(state_dict, mode, batch, size, n_classes, steps=8, warmup=
             break
     dt = sum(times) / len(times)
     return dict(value=batch / dt, seconds_per_step=dt, cores=threads, batch=batch, timed_steps=len(times),
-                seconds=sum(times))
+                seconds=sum(times), loss=float(loss))

@@ -229,3 +229,34 @@ def test_non_contiguous_and_channels_last_inputs_are_accepted():
         a = ffm(fsp, fcp)
         b = ffm(fsp.contiguous(memory_format=torch.channels_last), fcp.contiguous(memory_format=torch.channels_last))
     assert_close(b, a, 1e-6, "channels_last input")
+
+
+def test_graphed_train_step_equals_eager():
+    """GraphedTrainStep (two captured hipGraphs around the one OHEM host read) reproduces TrainStep step for step: same
+    losses, same weights after SGD, same BatchNorm buffers; a batch that needs the rare branch (here: every label ignored)
+    falls back to the eager step without double-counting the BatchNorm side effects of the replayed forward."""
+    from cabinet_amd.train import GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
+
+    batches = [synthetic_batch(2, 256, 256, 8, "cuda", seed=20 + i) for i in range(4)]
+    ign = (batches[0][0], torch.full_like(batches[0][1], 255))
+    res = []
+    for graphed in (False, True):
+        net = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
+        opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-2, momentum=0.9)
+        crit = make_criteria(2, 256, 256, "cuda")
+        if graphed:
+            step = GraphedTrainStep(net, crit, optimizer=opt, warmup=1)
+        else:
+            step = TrainStep(net, crit, optimizer=opt)
+        losses = [float(step(*b)) for b in batches]
+        losses.append(float(step(*ign)))       # all-ignored batch: zero loss, eager fallback inside the graphed step
+        losses.append(float(step(*batches[1])))
+        if graphed:
+            assert step.fallbacks == 1 and step.g_bwd is not None
+        res.append((losses, {k: v.clone() for k, v in net.state_dict().items()}))
+    (la, sa), (lb_, sb) = res
+    assert la[4] == 0.0 and lb_[4] == 0.0
+    for x, y in zip(la, lb_):
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (la, lb_)
+    for k in sa:
+        assert_close(sb[k].double(), sa[k].double(), 1e-5, k)
