@@ -290,7 +290,7 @@ def main():
     args = parse()
     t_start = time.perf_counter()
     from cabinet_amd.ddp import BucketedGradReducer, init_distributed
-    from cabinet_amd.train import GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
+    from cabinet_amd.train import GraphedDDPStep, GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -309,17 +309,21 @@ def main():
 
     net = build_model(args.mode, n_classes=args.classes, device=dev, seed=0, gamma=0.5).train()
     ddp = world > 1 or os.environ.get("CABINET_FORCE_DDP") == "1"
-    reducer = BucketedGradReducer(net, always_reduce=True) if ddp else None
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
                           weight_decay=5e-4)
-    graphed = not ddp and not args.no_graph
+    graphed = not args.no_graph
     crit = make_criteria(args.batch, args.size, args.size, dev)
-    if graphed:   # the step replayed from two hipGraphs around its one host read (cabinet_amd/train.py)
+    reducer = step_nopt = None
+    if graphed and ddp:
+        # hipGraph segments with the bucket all-reduces issued between them: the decoder's 23 MB reduce while the encoders
+        # back-propagate (cabinet_amd/train.py::GraphedDDPStep); no per-kernel Python on any rank's host
+        step = reducer = GraphedDDPStep(net, crit, optimizer=opt, always_reduce=True)
+    elif graphed:  # the step replayed from two hipGraphs around its one host read (cabinet_amd/train.py)
         step = GraphedTrainStep(net, crit, optimizer=opt)
         step_nopt = GraphedTrainStep(net, crit, optimizer=None)
     else:
+        reducer = BucketedGradReducer(net, always_reduce=True) if ddp else None
         step = TrainStep(net, crit, reducer=reducer, optimizer=opt)
-        step_nopt = None
     im, lb = synthetic_batch(args.batch, args.size, args.size, args.classes, dev, seed=1 + rank)
 
     def sync():
@@ -353,7 +357,10 @@ def main():
     # SURVEY.md section 8(d) words the metric as forward + 2x OHEM-CE + backward; `value` above also contains the gradient
     # all-reduce and the SGD step (conservative).  The same K steps without the optimizer, reported next to it:
     if step_nopt is None:
-        step.optimizer = None
+        if isinstance(step, GraphedDDPStep):
+            gC, step.graphs = step.graphs[3], step.graphs[:3] + (None,)  # same graphs, optimizer segment skipped
+        else:
+            step.optimizer = None
         runner = step
     else:
         runner = step_nopt
@@ -365,7 +372,9 @@ def main():
         runner(im, lb)
     sync()
     dt_nopt = time.perf_counter() - t0
-    if step_nopt is None:
+    if step_nopt is None and isinstance(step, GraphedDDPStep):
+        step.graphs = step.graphs[:3] + (gC,)
+    elif step_nopt is None:
         step.optimizer = opt
     if ddp:
         t = torch.tensor([dt_nopt], device=dev, dtype=torch.float64)
@@ -389,8 +398,9 @@ def main():
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image_size": args.size,
                 "n_classes": args.classes, "parallelism": f"dp{world}",
                 "grad_buckets_mb": [round(x, 2) for x in reducer.bucket_megabytes] if reducer else None,
-                "host_path": ("two captured hipGraphs per step around the one OHEM read-back (GraphedTrainStep)" if graphed
-                              else "eager enqueue (TrainStep)"),
+                "host_path": ("hipGraph segments, bucket all-reduces between them (GraphedDDPStep)" if graphed and ddp
+                              else "two captured hipGraphs per step around the one OHEM read-back (GraphedTrainStep)"
+                              if graphed else "eager enqueue (TrainStep)"),
             },
             "final_loss": round(final_loss, 5),
             "fwd_loss_bwd_only": {"value": round(images / dt_nopt, 3), "unit": "images/s",

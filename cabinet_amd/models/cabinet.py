@@ -175,12 +175,18 @@ class CABiNet(nn.Module):
         self.ffm = FeatureFusionModule(128 + 256, 256)
         self.conv_out = CABiNetOutput(256, 256, n_classes)
 
-    def forward_lowres(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_lowres(self, x: torch.Tensor, boundary: Optional[list] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Both heads at H/8 x W/8, i.e. ``forward`` without its two final x8 bilinear upsamples (reference
-        cabinet.py:240-245).  ``OhemCELoss.forward_upsampled`` fuses exactly those resizes into the loss."""
+        cabinet.py:240-245).  ``OhemCELoss.forward_upsampled`` fuses exactly those resizes into the loss.
+        ``boundary`` (a list) receives the two tensors that separate the decoder (``ab``, ``ffm``, ``conv_out``) from the
+        encoders (``sb``, ``mobile``): the data-parallel step back-propagates the two halves separately so that the
+        decoder's gradient all-reduce overlaps the encoders' backward (cabinet_amd.train.GraphedDDPStep)."""
         with batched_bn_counters():  # one multi-tensor `num_batches_tracked += 1` for the model's 59 BatchNorms
             feat_sb = self.sb(x)
-            low, high = self.ab(self.mobile(x))
+            mob = self.mobile(x)
+            if boundary is not None:
+                boundary.extend([feat_sb, mob])
+            low, high = self.ab(mob)
             high_up = _resize(high, feat_sb.shape[2:])
             final = self.conv_out(self.ffm.forward_upsampled(feat_sb, low))
         return final, high_up

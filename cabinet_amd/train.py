@@ -198,6 +198,203 @@ class GraphedTrainStep:
         return loss
 
 
+class GraphedDDPStep:
+    """Data-parallel step for one node of MI355X: hipGraph segments with the gradient all-reduces issued BETWEEN them.
+
+    The eager reducer (cabinet_amd.ddp.BucketedGradReducer) launches collectives from autograd hooks, which keeps the
+    whole ~1,100-launch Python / autograd enqueue path (13 ms per step at config 3) on every rank's host -- 8 ranks share
+    the node's host cores.  Here the step is cut where the model cuts itself: the decoder (``conv_out, ffm, ab``: 23 MB of
+    gradients) is back-propagated first, the encoders (``mobile, sb``: 13 MB, two thirds of the backward time) second:
+
+        graph A    zero the gradient buckets, forward, OHEM forward kernels + statistics
+        host       one read-back (OHEM branch), as in GraphedTrainStep
+        graph B1   loss, backward of the decoder down to the two boundary tensors (sb output, mobile output)
+        RCCL       all-reduce(AVG) of the decoder buckets, asynchronous on RCCL's stream        <- overlaps graph B2
+        graph B2   backward of the encoders from the boundary gradients
+        RCCL       all-reduce of the encoder buckets (the only exposed communication: 13 MB over xGMI), join
+        graph C    optimizer step
+
+    Collectives are ordinary eager calls between replays (nothing of RCCL is captured), always the same buckets in the
+    same order on every rank, also on a rank that falls back to the eager path for this step (rare OHEM branch).
+    Gradients are views into flat fp32 buckets (no copy in or out); BatchNorm statistics and OHEM stay per rank.
+    ``use_graphs=False`` (default on CPU tensors) runs the identical schedule eagerly -- that is what the gloo tests drive."""
+
+    DECODER = ("conv_out", "ffm", "ab")
+
+    def __init__(self, net, criteria, optimizer=None, process_group=None, bucket_mb=8.0, warmup=2, use_graphs=None,
+                 always_reduce=False, broadcast_parameters=True):
+        import torch.distributed as dist
+
+        from .ddp import plan_buckets
+
+        if not dist.is_initialized():
+            raise RuntimeError("GraphedDDPStep needs an initialised torch.distributed process group")
+        self.dist, self.group = dist, process_group
+        self.world, self.backend = dist.get_world_size(process_group), dist.get_backend(process_group)
+        self.always_reduce = always_reduce
+        self.net, (self.crit_p, self.crit_16) = net, criteria
+        self.optimizer, self.warmup = optimizer, warmup
+        dev = next(net.parameters()).device
+        self.use_graphs = (dev.type == "cuda") if use_graphs is None else bool(use_graphs)
+        dec, enc = [], []
+        for name, child in net.named_children():
+            for p in child.parameters():
+                if p.requires_grad:
+                    (dec if name in self.DECODER else enc).append(p)
+        self.dec_params = dec
+        cap = int(bucket_mb * 2 ** 20)
+        self.segments = []
+        for params in (list(reversed(dec)), list(reversed(enc))):  # ~ gradient arrival order inside each half
+            flats = []
+            for plan in plan_buckets([p.numel() * 4 for p in params], cap, cap, 2 ** 18):
+                group = [params[i] for i in plan]
+                flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=dev)
+                off = 0
+                for p in group:
+                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+                flats.append(flat)
+            self.segments.append(flats)
+        if broadcast_parameters and self.world > 1:
+            with torch.no_grad():
+                for t in list(net.parameters()) + list(net.buffers()):
+                    dist.broadcast(t, src=0, group=process_group)
+        self.graphs = None
+        self.fallbacks = self._calls = 0
+
+    # ---- the pieces of one step (run eagerly, or recorded once and replayed) ----
+    def _zero(self):
+        for flats in self.segments:
+            for f in flats:
+                f.zero_()
+
+    def _forward(self, im, lb):
+        """-> (fused preps | None, loss | None, boundary tensors)"""
+        boundary = []
+        if im.is_cuda:
+            low, low16 = self.net.forward_lowres(im, boundary)
+            size = tuple(im.shape[2:])
+            pa = self.crit_p._fused_launch(low, lb, size)
+            pb = self.crit_16._fused_launch(low16, lb, size)
+            if pa[5] is not None and pb[5] is not None:
+                return (pa, pb, torch.stack([pa[5][1], pb[5][1]])), None, boundary
+            return None, self.crit_p._fused_finish(pa, None) + self.crit_16._fused_finish(pb, None), boundary
+        final, high_up = self.net.forward_lowres(im, boundary)
+        size = im.shape[2:]
+        out = torch.nn.functional.interpolate(final, size=size, mode="bilinear", align_corners=False)
+        out16 = torch.nn.functional.interpolate(high_up, size=size, mode="bilinear", align_corners=False)
+        return None, self.crit_p(out, lb) + self.crit_16(out16, lb), boundary
+
+    def _backward_decoder(self, loss, boundary):
+        """Gradients of the decoder parameters (into their bucket views) and of the two boundary tensors (into .grad).
+        Returns False when the loss does not depend on the network (constant zero: every label ignored)."""
+        torch.autograd.backward(loss, inputs=self.dec_params + boundary, retain_graph=True)
+        return all(self._grad_of(t) is not None for t in boundary)
+
+    @staticmethod
+    def _grad_of(t):
+        import warnings
+
+        with warnings.catch_warnings():  # .grad of a non-leaf: populated because the tensor was named in `inputs`
+            warnings.simplefilter("ignore")
+            return t.grad
+
+    def _backward_encoders(self, boundary):
+        torch.autograd.backward(boundary, [self._grad_of(t) for t in boundary])
+
+    def _reduce(self, seg):
+        if self.world == 1 and not self.always_reduce:
+            return []
+        op = self.dist.ReduceOp.AVG if self.backend == "nccl" else self.dist.ReduceOp.SUM
+        return [(self.dist.all_reduce(f, op=op, group=self.group, async_op=True), f) for f in self.segments[seg]]
+
+    def _join(self, works):
+        for w, f in works:
+            w.wait()
+            if self.backend != "nccl":
+                f.div_(self.world)
+
+    def _eager_step(self, im, lb):
+        self._zero()
+        fused, loss, boundary = self._forward(im, lb)
+        if fused is not None:
+            host = fused[2].tolist()
+            loss = self.crit_p._fused_finish(fused[0], host[0]) + self.crit_16._fused_finish(fused[1], host[1])
+        ran = self._backward_decoder(loss, boundary)
+        works = self._reduce(0)
+        if ran:
+            self._backward_encoders(boundary)
+        works += self._reduce(1)
+        self._join(works)
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss.detach()
+
+    def _capture(self, im, lb):
+        self.s_im, self.s_lb = im.clone(), lb.clone()
+        self.buffers = list(self.net.buffers())
+        self.backup = [b.clone() for b in self.buffers]
+        torch.cuda.synchronize()
+        gA, gB1, gB2, gC = (torch.cuda.CUDAGraph() for _ in range(4))
+        with torch.cuda.graph(gA):
+            self._zero()
+            self.fused, _, self.boundary = self._forward(self.s_im, self.s_lb)
+            if self.fused is None:
+                raise RuntimeError("GraphedDDPStep with graphs needs the fused OHEM head")
+            self.s_stats = self.fused[2]
+        torch._foreach_copy_(self.backup, self.buffers)
+        gA.replay()
+        host = self.s_stats.tolist()
+        torch._foreach_copy_(self.buffers, self.backup)
+        if not all(GraphedTrainStep._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
+            raise RuntimeError("GraphedDDPStep: capture batch does not take the OHEM 'n_min above thresh' branch")
+        with torch.cuda.graph(gB1, pool=gA.pool()):
+            loss = self.crit_p._fused_finish(self.fused[0], host[0]) + self.crit_16._fused_finish(self.fused[1], host[1])
+            self._backward_decoder(loss, self.boundary)
+            self.s_loss = loss.detach()
+        with torch.cuda.graph(gB2, pool=gA.pool()):
+            self._backward_encoders(self.boundary)
+        if self.optimizer is not None:
+            with torch.cuda.graph(gC, pool=gA.pool()):
+                self.optimizer.step()
+        else:
+            gC = None
+        torch.cuda.synchronize()
+        self.graphs = (gA, gB1, gB2, gC)
+
+    def __call__(self, im, lb):
+        if not self.use_graphs:
+            return self._eager_step(im, lb)
+        if self.graphs is None:
+            self._calls += 1
+            loss = self._eager_step(im, lb)
+            if self._calls >= max(1, self.warmup):
+                self._capture(im, lb)
+            return loss
+        gA, gB1, gB2, gC = self.graphs
+        self.s_im.copy_(im, non_blocking=True)
+        self.s_lb.copy_(lb, non_blocking=True)
+        torch._foreach_copy_(self.backup, self.buffers)
+        gA.replay()
+        host = self.s_stats.tolist()  # the step's one host sync
+        if not all(GraphedTrainStep._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
+            self.fallbacks += 1       # same collectives, same order, issued by the eager path
+            torch._foreach_copy_(self.buffers, self.backup)
+            return self._eager_step(im, lb)
+        gB1.replay()
+        works = self._reduce(0)       # RCCL's stream waits for graph B1, the host goes on to launch B2
+        gB2.replay()
+        works += self._reduce(1)
+        self._join(works)
+        if gC is not None:
+            gC.replay()
+        return self.s_loss
+
+    @property
+    def bucket_megabytes(self):
+        return [f.numel() * 4 / 2 ** 20 for flats in self.segments for f in flats]
+
+
 def synthetic_batch(batch, height, width, n_classes, device, seed=1):
     """Inputs of BASELINE.md section 2: images ~ N(0,1), labels uniform over classes, no ignore pixels."""
     g = torch.Generator().manual_seed(seed)

@@ -160,3 +160,73 @@ def test_reducer_requires_process_group():
         pytest.skip("process group active")
     with pytest.raises(RuntimeError, match="process group"):
         BucketedGradReducer(torch.nn.Linear(2, 2))
+
+
+def _seg_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(4)
+    from cabinet_amd.ddp import init_distributed
+    from cabinet_amd.train import GraphedDDPStep, build_model, make_criteria, synthetic_batch
+
+    init_distributed("gloo")
+    net = build_model("small", n_classes=8, seed=rank, gamma=0.5).train()
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.05, momentum=0.9)
+    step = GraphedDDPStep(net, make_criteria(2, 96, 96, "cpu"), optimizer=opt, bucket_mb=4.0)  # CPU: the eager schedule
+    out = {"buckets": step.bucket_megabytes, "w_start": net.ffm.conv1.weight.detach().clone()}
+    losses = []
+    for i in range(2):
+        im, lb = synthetic_batch(2, 96, 96, 8, "cpu", seed=100 + rank + 10 * i)
+        losses.append(float(step(im, lb)))
+    out["grads"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
+    out["w"] = {k: v.detach().clone() for k, v in net.state_dict().items() if v.is_floating_point() and "running" not in k}
+    # one rank with a constant-zero loss: same collectives on both ranks, no hang, gradient = other rank's / world
+    im, lb = synthetic_batch(2, 96, 96, 8, "cpu", seed=300 + rank)
+    if rank == 1:
+        lb = torch.full_like(lb, 255)
+    losses.append(float(step(im, lb)))
+    out["zero_rank_grads"] = {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad}
+    out["losses"] = losses
+    torch.save(out, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_segmented_step(tmp_path):
+    """GraphedDDPStep's schedule (decoder backward -> all-reduce of its buckets while the encoders back-propagate ->
+    their all-reduce -> optimizer), run eagerly on CPU over gloo: weights start from rank 0's, gradients are the rank
+    average of what single-process steps produce, parameters stay identical across ranks after SGD."""
+    world, port = 2, _free_port()
+    mp.spawn(_seg_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"s{i}.pt", weights_only=False) for i in range(world)]
+    assert torch.equal(r[0]["w_start"], r[1]["w_start"])
+    assert abs(sum(r[0]["buckets"]) - 5.36e6 * 4 / 2 ** 20) < 6 and len(r[0]["buckets"]) >= 2
+    for key in ("grads", "w", "zero_rank_grads"):
+        for k in r[0][key]:
+            assert torch.equal(r[0][key][k], r[1][key][k]), (key, k)
+    assert r[0]["losses"][2] > 0 and r[1]["losses"][2] == 0.0
+    # reference: two single-process models stepping on their own rank's data with the AVERAGED gradient
+    from cabinet_amd.train import build_model, make_criteria, synthetic_batch
+
+    nets = [build_model("small", n_classes=8, seed=0, gamma=0.5).train() for _ in range(world)]
+    opts = [torch.optim.SGD([p for p in n.parameters() if p.requires_grad], lr=0.05, momentum=0.9) for n in nets]
+    crit = make_criteria(2, 96, 96, "cpu")
+    for i in range(2):
+        for rank, n in enumerate(nets):
+            for p in n.parameters():
+                p.grad = None
+            im, lb = synthetic_batch(2, 96, 96, 8, "cpu", seed=100 + rank + 10 * i)
+            o, o16 = n(im)
+            (crit[0](o, lb) + crit[1](o16, lb)).backward()
+        for pa, pb in zip(nets[0].parameters(), nets[1].parameters()):
+            if pa.grad is not None:
+                avg = (pa.grad + pb.grad) / 2
+                pa.grad, pb.grad = avg, avg.clone()
+        for o in opts:
+            o.step()
+    want = {k: p.grad for k, p in nets[0].named_parameters() if p.requires_grad and p.grad is not None}
+    for k, g in want.items():
+        got = r[0]["grads"][k]
+        err, den = float((got - g).norm()), float(g.norm())
+        assert err <= 2e-3 * den + 1e-7, (k, err, den)
