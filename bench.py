@@ -68,13 +68,38 @@ def parse():
     return ap.parse_args()
 
 
-def time_kernel(fn, iters, warm=3):
-    """Average launch duration (ms) with HIP events on the stream the kernels run on (torch's current
-    stream is the stream handed to the C ABI)."""
+def time_kernel(fn, iters, warm=3, reps=5):
+    """Average duration (ms) of one launch group, with HIP events on the stream the kernels run on (torch's current
+    stream is the stream handed to the C ABI).  The group is captured `reps` times into one hipGraph and the graph is
+    replayed: several groups are a few launches of 5 .. 30 us each, and timing them through the Python binding measures
+    the host (60 us per call), not the kernels.  Falls back to eager launches if a group cannot be captured."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    graph = None
+    if os.environ.get("CABINET_BENCH_EAGER_KERNELS") != "1":
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(reps):
+                    fn()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] kernel group not capturable ({type(e).__name__}: {e}); timing it eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if graph is not None:
+        n = max(2, iters // reps)
+        start.record()
+        for _ in range(n):
+            graph.replay()
+        stop.record()
+        torch.cuda.synchronize()
+        ms = start.elapsed_time(stop) / (n * reps)
+        del graph
+        return ms
     start.record()
     for _ in range(iters):
         fn()
@@ -105,7 +130,11 @@ def load_traffic(batch, size):
 
 
 def kernel_cases(batch, size):
-    """Generator over the hand-written kernel groups at this workload's shapes: yields
+    """(Backward groups call the autograd Function's ``backward`` on the node their forward built: the same C-ABI calls as
+    under autograd, issued from this thread on the current stream -- the autograd engine would run them on the forward's
+    stream, outside a hipGraph capture.)
+
+    Generator over the hand-written kernel groups at this workload's shapes: yields
     (name, launch closure, algorithmic FLOPs, algorithmic bytes, bound) one group at a time (operands of a finished group
     are freed before the next is built).  Algorithmic work per launch: SURVEY.md section 8(d) / BASELINE.md section 3.
     Consumers: kernel_rooflines() below (HIP-event timing) and tools/run_kernels.py (the same launches under rocprofv3
@@ -177,7 +206,7 @@ def kernel_cases(batch, size):
     yield ("bn_act_fwd (K7: BatchNorm + HardSwish, stats + apply)", fwd, 12.0 * xb.numel(), 3 * nbytes, "hbm")
     xg = xb.clone().requires_grad_(True)
     yb = Fh._BnAct.apply(xg, bnw, bnb, brm, brv, 2, True, 0.1, 1e-5)
-    yield ("bn_act_bwd (K7: reduce + dx, pre-activation recomputed)", lambda: torch.autograd.grad(yb, xg, gb, retain_graph=True), 30.0 * xb.numel(), 5 * nbytes, "hbm")
+    yield ("bn_act_bwd (K7: reduce + dx, pre-activation recomputed)", lambda: Fh._BnAct.backward(yb.grad_fn, gb), 30.0 * xb.numel(), 5 * nbytes, "hbm")
     del xb, gb, xg, yb
     torch.cuda.empty_cache()
 
@@ -194,7 +223,7 @@ def kernel_cases(batch, size):
     nz, ny = 4.0 * zb.numel(), 4.0 * yb.numel()
     yield ("bn_dwconv_fwd (K8: BN stats + 3x3/2 depthwise conv with BN+HardSwish folded in)", lambda: Fh.bn_act_dwconv(zb.detach(), bn, "hardswish", conv), 28.0 * yb.numel(),
           2 * nz + ny, "hbm")
-    yield ("bn_dwconv_bwd (K8: dx + dw + BN partial sums, then BN dx)", lambda: torch.autograd.grad(yb, (zb, conv.weight, bn.weight), gy, retain_graph=True), 60.0 * yb.numel(), ny + 5 * nz, "hbm")
+    yield ("bn_dwconv_bwd (K8: dx + dw + BN partial sums, then BN dx)", lambda: Fh._BnActDwConv.backward(yb.grad_fn, gy), 60.0 * yb.numel(), ny + 5 * nz, "hbm")
     del zb, yb, gy
     torch.cuda.empty_cache()
 
@@ -205,7 +234,7 @@ def kernel_cases(batch, size):
     gs = torch.randn(ys.shape, generator=g).to(dev)
     fl_s = 2.0 * ys.numel() * 147
     yield ("stem_conv_fwd (K9: 7x7/2, patch gather from LDS)", lambda: Fh.stem_conv(img, stem), fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
-    yield ("stem_conv_wrw (K9: contraction over pixels, ordered slabs)", lambda: torch.autograd.grad(ys, stem.weight, gs, retain_graph=True), fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
+    yield ("stem_conv_wrw (K9: contraction over pixels, ordered slabs)", lambda: Fh._StemConv.backward(ys.grad_fn, gs), fl_s, 4.0 * (img.numel() + ys.numel()), "mfma")
     del img, ys, gs
     torch.cuda.empty_cache()
 
@@ -216,7 +245,7 @@ def kernel_cases(batch, size):
     gp = torch.randn(yp.shape, generator=g).to(dev)
     nx, nyp = 4.0 * xp.numel(), 4.0 * yp.numel()
     yield ("pwconv_fwd (K10: streaming 1x1 conv 16->64)", lambda: Fh.pwconv(xp.detach(), pw), 2.0 * yp.numel() * 16, nx + nyp, "hbm")
-    yield ("pwconv_bwd (K10: dx stream + wgrad slabs)", lambda: torch.autograd.grad(yp, (xp, pw.weight), gp, retain_graph=True), 4.0 * yp.numel() * 16, 2 * nyp + 2 * nx, "hbm")
+    yield ("pwconv_bwd (K10: dx stream + wgrad slabs)", lambda: Fh._PwConv.backward(yp.grad_fn, gp), 4.0 * yp.numel() * 16, 2 * nyp + 2 * nx, "hbm")
     del xp, yp, gp
     torch.cuda.empty_cache()
 
@@ -239,12 +268,12 @@ def kernel_cases(batch, size):
     elems = float(xc.numel())
     yl = cab.local_attn(xc)
     yield ("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", lambda: cab.local_attn(xc.detach()), elems * 3 * 22, 8.0 * elems, "hbm")
-    yield ("cab_local_bwd (K5: chain recomputed in LDS)", lambda: torch.autograd.grad(yl, xc, gc, retain_graph=True), elems * 3 * 60, 12.0 * elems, "hbm")
+    yield ("cab_local_bwd (K5: chain recomputed in LDS)", lambda: Fh._CabLocal.backward(yl.grad_fn, gc), elems * 3 * 60, 12.0 * elems, "hbm")
     q3 = Fh.cab_qkv(xc, cab.global_attn)
     gq = [torch.randn_like(t) for t in q3]
     fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
     yield ("cab_qkv_fwd (K6: projections + BN + PSP, 6 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
-    yield ("cab_qkv_bwd (K6: adjoint chain, 7 launches)", lambda: torch.autograd.grad(q3, xc, gq, retain_graph=True), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
+    yield ("cab_qkv_bwd (K6: adjoint chain, 7 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
 
 
 
@@ -266,6 +295,8 @@ def kernel_rooflines(batch, size, iters):
     out = []
     traffic, traffic_src = load_traffic(batch, size)
     for name, fn, flops, bytes_, bound in kernel_cases(batch, size):
+        if os.environ.get("CABINET_BENCH_VERBOSE") == "1":
+            print(f"[bench] timing {name}", file=sys.stderr, flush=True)
         ms = time_kernel(fn, iters)
         tf = flops / (ms * 1e-3) / 1e12
         gbs = bytes_ / (ms * 1e-3) / 1e9

@@ -21,6 +21,7 @@ _INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_
 SIGNATURES = {
     "cabinet_abi_version": (_INT, []),
     "cabinet_last_error": (ctypes.c_char_p, []),
+    "cabinet_cab_attn_supported": (_INT, [_INT] * 2),
     "cabinet_cab_attn_fwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_cab_attn_fwd": (_INT, [_PTR, _PTR, _PTR, _FLT, _INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _SZ, _PTR]),
     "cabinet_cab_attn_bwd_workspace_bytes": (_SZ, [_INT] * 4),

@@ -53,6 +53,11 @@ struct SgJob {
     int ldp;          // ... out of rows that are ldp floats long in B and dst (0: ldp = P); lets a job work on a column window
     float* dst;       // (B, dst_rows, ldp); rows [0, M) of each image are written
     int dst_rows;
+    int b_pmajor;     // B stored position-major: (B, P, ldb) with the contracted index contiguous (a transposed operand)
+    int ldb;
+    const float* a_bias;  // optional (B, M): subtracted from every A row (m) of image b while staging (M-major A only)
+    float alpha;      // scale applied to the result (0 means 1)
+    size_t a_img_stride;  // floats between the A operands of consecutive images (0: one A shared by all images, a weight)
     int tiles_m, tiles_n, tile_base, nck[3], vec;  // filled by sg_gemm
 };
 struct SgJobs {

@@ -25,6 +25,7 @@
 // sits on the lane, so every accumulator is directly the B operand of the next product
 // and only the operand that must be read "channel on lane" crosses LDS, in 32-channel
 // chunks through a small wave-private double buffer (no workgroup barrier in the loop).
+#include "blocks.hpp"
 #include "common.hpp"
 
 namespace cabinet {
@@ -40,7 +41,39 @@ __device__ __forceinline__ void stage_chunk(float* tb, const float* __restrict__
     for (int s = 0; s < 16; ++s) tb[(2 * s + h) * TSTR + li] = src[(size_t)(2 * s) * row_stride];
 }
 
-// kmean[b][c] = mean_j k[b][c][j]; one wave per row.  (Any vector near the mean serves the identity above; fp32 is ample.)
+// Pre-pass of the stored-dS form, ONE launch with two roles:
+//   blocks [0, nb_delta)  D_i = sum_c g[b][c][i] ctx[b][c][i] for 64 queries per workgroup (4 waves split the channels)
+//   the rest              kmean[b][c] = mean_j k[b][c][j], one wave per row (any vector near the mean serves the identity
+//                         of the header; fp32 is ample)
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ ctx,
+                                                             const float* __restrict__ k, float* __restrict__ delta,
+                                                             float* __restrict__ kmean, int VC, int rows, int n, int nb_delta) {
+    __shared__ float part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < nb_delta) {
+        const int tiles = (n + 63) >> 6, b = blockIdx.x / tiles, i = (blockIdx.x - b * tiles) * 64 + lane;
+        float acc = 0.f;
+        if (i < n) {
+            const float* gp = g + (size_t)b * VC * n + i;
+            const float* cp = ctx + (size_t)b * VC * n + i;
+#pragma unroll 8
+            for (int c = wave; c < VC; c += 4) acc += gp[(size_t)c * n] * cp[(size_t)c * n];
+        }
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && i < n) delta[(size_t)b * n + i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        return;
+    }
+    const int row = (blockIdx.x - nb_delta) * 4 + wave;
+    if (row >= rows) return;
+    const float* p = k + (size_t)row * n;
+    float a = 0.f;
+    for (int j = lane; j < n; j += 64) a += p[j];
+    a = wave_sum(a);
+    if (lane == 0) kmean[row] = a / (float)n;
+}
+
+// kmean only (the recompute form, whose dq kernel forms D_i in its own prologue)
 __global__ __launch_bounds__(256) void attn_key_mean_kernel(const float* __restrict__ k, float* __restrict__ kmean, int rows, int n) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -168,7 +201,7 @@ template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
-    float* __restrict__ dk, float* __restrict__ dv, int n, float scale) {
+    float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ ds, int n, float scale) {
     constexpr int KB = KC / 32, VB = VC / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* kt = smem;                  // [KC][32] raw k tile   (B operand of S)
@@ -222,6 +255,7 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_kernel(
             const float l2 = lse[si] * LOG2E_F, dl = delta[si];
             p[r] = valid ? fast_exp2(s[r] * qscale - l2) : 0.f;  // P[query][key]
             s[r] = p[r] * (dp[r] - dl);                           // dS[query][key]
+            if (ds && valid && j0 + li < n) ds[((size_t)b * n + irow) * n + j0 + li] = s[r];  // rows of 128 contiguous bytes
         }
         // dv[c][j] += sum_i g[c][i] P[i][j] ; dk[c][j] += sum_i q[c][i] dS[i][j]
 #pragma unroll
@@ -455,7 +489,7 @@ template <int KC, int VC>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
-    float* __restrict__ dk, float* __restrict__ dv, int n, float scale, int B, int nsplit) {
+    float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ ds, int n, float scale, int B, int nsplit) {
     constexpr int KB = KC / 32, VB = VC / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* kt = smem;                    // [KC][32] raw k tile   (B operand of S)
@@ -535,6 +569,12 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
             p[r] = valid ? fast_exp2(fmaf(s[r], qscale, -l2[r] * LOG2E_F)) : 0.f;  // P[query][key]
             s[r] = p[r] * (dp[r] - dl[r]);                                          // dS[query][key]
         }
+        if (ds && j0 + li < n) {  // dS leaves the kernel once, as rows of 128 contiguous bytes: dq = dS (K - mean K) is then ONE
+            float* dsp = ds + ((size_t)b * n + i0 + 4 * h) * n + j0 + li;  // product instead of a second S / dP recomputation
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (i0 + acc_row(r) + 4 * h < n) dsp[(size_t)acc_row(r) * n] = s[r];
+        }
         // dv += g P (g registers refilled with the next tile meanwhile), dk += q dS
         product_ldsA<VB>(dva, [&](int cb, int r) { return gim[simg(cb * 32 + li, acc_row(r) + 4 * h)]; }, p,
                          [&](int slot) {
@@ -586,12 +626,55 @@ static int bwd_nsplit(int B, int n) {
     return split;
 }
 
+// dq from the stored dS: dq[b][c][i] = scale * sum_j dS[b][i][j] (k[b][c][j] - mean_j k[b][c][.])  -- one job of the small
+// GEMM (A = K as stored, row-biased; B = dS position-major), 2 n^2 Kc FLOP per image instead of the 6 n^2 Kc of a dq
+// kernel that recomputes S and dP.
+// The key range is cut into `ksplit` segments, one job each (the launch then has 4x .. 8x more workgroups than CUs and
+// every workgroup only 8 dependent chunks: a single job had one workgroup per CU walking 32 chunks, latency-bound at 64 us);
+// the partial dq slabs are summed in order.
+static int dq_ksplit(int n) {
+    int s = n / 256;
+    s = s < 1 ? 1 : (s > 8 ? 8 : s);
+    while (s > 1 && (n / s) % 4) --s;  // every segment keeps 16-byte aligned rows
+    return s;
+}
+static void launch_dq_from_ds(const float* k, const float* kmean, const float* ds, float scale, int B, int KC, int n,
+                              float* dq, float* slabs, hipStream_t stream) {
+    const int ks = dq_ksplit(n), seg = (n / ks + 3) & ~3;
+    SgJobs jobs{};
+    jobs.n = ks;
+    for (int i = 0; i < ks; ++i) {
+        const int k0 = i * seg, kl = (i == ks - 1) ? n - k0 : seg;
+        SgJob& j = jobs.j[i];
+        j.seg[0] = {k + k0, ds + k0, kl, n};
+        j.nseg = 1, j.lda = n, j.a_mmajor = 1, j.M = KC, j.P = n, j.dst = ks == 1 ? dq : slabs + (size_t)i * B * KC * n,
+        j.dst_rows = KC;
+        j.b_pmajor = 1, j.ldb = n, j.a_bias = kmean, j.alpha = scale;
+        j.a_img_stride = (size_t)KC * n;  // A = the keys of image b
+    }
+    sg_gemm(jobs, B, stream);
+    if (ks > 1) {
+        const size_t cq = (size_t)B * KC * n;
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, slabs, dq, cq, ks);
+    }
+}
+
+// the stored-dS form needs 16-byte aligned rows of K and dS for the small GEMM's vector loads
+static bool use_ds_path(int n) { return (n & 3) == 0; }
+
 template <int KC, int VC>
 static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k, const float* v,
                                   const float* ctx, const float* lse, float scale, int B, int n, float* dq,
                                   float* dk, float* dv, float* delta, hipStream_t stream) {
     float* kmean = delta + align_up((size_t)B * n, 64);
-    hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
+    const bool dsp = use_ds_path(n);
+    if (dsp) {
+        const int nb_delta = B * ((n + 63) / 64);
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 3) / 4), dim3(256), 0, stream, g, ctx, k, delta,
+                           kmean, VC, B * KC, n, nb_delta);
+    } else {
+        hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
+    }
     const size_t lds_dq = (size_t)((KC + VC) * 32 + 4 * KC * 32 + KC * 32 + 256 + 64 + KC) * sizeof(float);
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 4 * (KC + VC) * 32) * sizeof(float);
     auto k_dq = cab_attn_bwd_dq_fast_kernel<KC, VC>;
@@ -607,21 +690,26 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
         attr_done = true;
     }
     const int nsplit = bwd_nsplit(B, n);
+    float* part_k = kmean + align_up((size_t)B * KC, 64);
+    float* part_v = part_k + (size_t)(nsplit > 1 ? nsplit : 0) * B * KC * n;
+    float* ds = dsp ? part_v + (size_t)(nsplit > 1 ? nsplit : 0) * B * VC * n : nullptr;
     dim3 grid(((n + 31) / 32) * B * nsplit);
     if (nsplit == 1) {
-        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale, B, 1);
-        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale, B, 1);
+        if (!dsp)
+            hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale, B, 1);
+        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, ds, n, scale, B, 1);
     } else {
-        // partial slabs live behind D_i in the workspace: [nsplit][B][KC][n] then [nsplit][B][VC][n]
-        float* part_k = kmean + align_up((size_t)B * KC, 64);
-        float* part_v = part_k + (size_t)nsplit * B * KC * n;
+        // partial slabs live behind D_i and the mean key in the workspace: [nsplit][B][KC][n] then [nsplit][B][VC][n]
         const size_t cq = (size_t)B * KC * n, cv = (size_t)B * VC * n;
-        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, part_k, delta, n, scale, B, nsplit);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dq, cq, nsplit);
-        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, part_k, part_v, n, scale, B, nsplit);
+        if (!dsp) {
+            hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, part_k, delta, n, scale, B, nsplit);
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dq, cq, nsplit);
+        }
+        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, part_k, part_v, ds, n, scale, B, nsplit);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dk, cq, nsplit);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cv + 255) / 256)), dim3(256), 0, stream, part_v, dv, cv, nsplit);
     }
+    if (dsp) launch_dq_from_ds(k, kmean, ds, scale, B, KC, n, dq, ds + (size_t)B * n * n, stream);
     return hipGetLastError();
 }
 
@@ -630,7 +718,14 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
                              const float* lse, float scale, int B, int n, float* dq, float* dk, float* dv,
                              float* delta, hipStream_t stream) {
     float* kmean = delta + align_up((size_t)B * n, 64);
-    hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
+    const bool dsp = use_ds_path(n);
+    if (dsp) {
+        const int nb_delta = B * ((n + 63) / 64);
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 3) / 4), dim3(256), 0, stream, g, ctx, k, delta,
+                           kmean, VC, B * KC, n, nb_delta);
+    } else {
+        hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
+    }
     const size_t lds_dq = (size_t)((KC + VC) * 32 + 8 * TCHUNK + KC * 32 + 256 + 64 + KC) * sizeof(float);
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 8 * TCHUNK + (KC + VC) * 32) * sizeof(float);
     auto k_dq = cab_attn_bwd_dq_kernel<KC, VC>;
@@ -646,8 +741,11 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
         attr_done = true;
     }
     dim3 grid((n + 31) / 32, 1, B);
-    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale);
-    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, n, scale);
+    float* ds = dsp ? kmean + align_up((size_t)B * KC, 64) : nullptr;
+    if (!dsp)
+        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale);
+    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, ds, n, scale);
+    if (dsp) launch_dq_from_ds(k, kmean, ds, scale, B, KC, n, dq, ds + (size_t)B * n * n, stream);
     return hipGetLastError();
 }
 
@@ -655,6 +753,8 @@ size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
     size_t bytes = (align_up((size_t)B * n, 64) + align_up((size_t)B * Kc, 64)) * sizeof(float);  // D_i, mean key
     const int nsplit = (Kc <= 128 && Kc + Vc <= 256) ? bwd_nsplit(B, n) : 1;
     if (nsplit > 1) bytes += (size_t)nsplit * B * (Kc + Vc) * n * sizeof(float);  // partial dq|dk and dv slabs
+    if (use_ds_path(n))                                                            // dS, then the dq key-range slabs
+        bytes += ((size_t)B * n * n + (size_t)(dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * B * Kc * n) * sizeof(float);
     return align_up(bytes, 256);
 }
 

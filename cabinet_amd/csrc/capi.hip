@@ -137,6 +137,8 @@ static int check_attn_shape(int B, int Kc, int Vc, int n) {
     return CABINET_OK;
 }
 
+int cabinet_cab_attn_supported(int Kc, int Vc) { return cabinet::attn_shape_supported(Kc, Vc) ? 1 : 0; }
+
 size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n) {
     if (B <= 0 || Kc <= 0 || Vc <= 0 || n <= 0) return 0;
     const int split = cabinet::attn_fwd_kvsplit(B, n);

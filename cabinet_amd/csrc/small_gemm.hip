@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
     const int mt = t % J.tiles_m, b = t / J.tiles_m;
     const int m0 = mt * SG_T, p0 = nt * SG_T, M = J.M, P = J.P, lda = J.lda, ldp = J.ldp;
     const bool vec_p = J.vec != 0;
+    // LDS row strides: 68 keeps float4 stores aligned for operands stored as read; an operand transposed on the way in is
+    // written with scalar stores down a column, where stride 65 gives 2-way bank conflicts (free for ds_write_b32) instead
+    // of the 4-way of stride 68
+    const int astr = J.a_mmajor ? 65 : SG_STR, bstr = J.b_pmajor ? 65 : SG_STR;
 
     f32x16 acc;
 #pragma unroll
@@ -48,19 +52,33 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
         int s = 0, c = ci;
         while (c >= J.nck[s]) c -= J.nck[s], ++s;
         const int k0 = c * SG_BK, kseg = J.seg[s].k;
-        const float* __restrict__ ap = J.seg[s].a;
+        const float* __restrict__ ap = J.seg[s].a + (size_t)b * J.a_img_stride;
         const float* __restrict__ bp = J.seg[s].b + (size_t)b * J.seg[s].b_rows * ldp;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 256;
             if (J.a_mmajor) {  // A stored (M, K) row-major: 8 threads read one row's 32-float run
                 const int mrow = idx >> 3, k = k0 + (idx & 7) * 4, m = m0 + mrow;
-                ra[i] = (m < M && k < kseg) ? *reinterpret_cast<const f32x4*>(ap + (size_t)m * lda + k)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < M && k < kseg) {
+                    ra[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)m * lda + k);
+                    if (J.a_bias) {
+                        const float bias = J.a_bias[(size_t)b * M + m];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ra[i][e] -= bias;
+                    }
+                } else {
+                    ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             } else {           // A stored (K, M): 16 threads read one k-row's 64-float run
                 const int kk = idx >> 4, m = m0 + (idx & 15) * 4;
                 ra[i] = (k0 + kk < kseg && m < M) ? *reinterpret_cast<const f32x4*>(ap + (size_t)(k0 + kk) * lda + m)
                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (J.b_pmajor) {  // B stored (P, K): 8 threads read one position's 32-float run, transposed on the way to LDS
+                const int prow = idx >> 3, k = k0 + (idx & 7) * 4, pp = p0 + prow;
+                rb[i] = (pp < P && k < kseg) ? *reinterpret_cast<const f32x4*>(J.seg[s].b + ((size_t)b * J.seg[s].b_rows + pp) * J.ldb + k)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+                continue;
             }
             const int kk = idx >> 4, p = p0 + (idx & 15) * 4;
             const float* row = bp + (size_t)min(k0 + kk, kseg - 1) * ldp;  // rows past the segment meet zero A rows
@@ -79,11 +97,17 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
             if (J.a_mmajor) {
                 const int mrow = idx >> 3, k4 = (idx & 7) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][(k4 + e) * SG_STR + mrow] = ra[i][e];
+                for (int e = 0; e < 4; ++e) As[buf][(k4 + e) * astr + mrow] = ra[i][e];
             } else {
                 *reinterpret_cast<f32x4*>(&As[buf][(idx >> 4) * SG_STR + (idx & 15) * 4]) = ra[i];
             }
-            *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 4) * SG_STR + (idx & 15) * 4]) = rb[i];
+            if (J.b_pmajor) {
+                const int prow = idx >> 3, k4 = (idx & 7) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[buf][(k4 + e) * bstr + prow] = rb[i][e];
+            } else {
+                *reinterpret_cast<f32x4*>(&Bs[buf][(idx >> 4) * SG_STR + (idx & 15) * 4]) = rb[i];
+            }
         }
     };
 
@@ -97,16 +121,17 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
         const float* Ab = &As[buf][wm * 32 + li];
         const float* Bb = &Bs[buf][wn * 32 + li];
 #pragma unroll
-        for (int kk = 0; kk < SG_BK; kk += 2) acc = mfma32(Ab[(kk + h) * SG_STR], Bb[(kk + h) * SG_STR], acc);
+        for (int kk = 0; kk < SG_BK; kk += 2) acc = mfma32(Ab[(kk + h) * astr], Bb[(kk + h) * bstr], acc);
         if (ci + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
     float* dst = J.dst + (size_t)b * J.dst_rows * ldp;
     const int p = p0 + wn * 32 + li;
+    const float alpha = J.alpha != 0.f ? J.alpha : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + acc_row(r) + 4 * h;
-        if (m < M && p < P) dst[(size_t)m * ldp + p] = acc[r];
+        if (m < M && p < P) dst[(size_t)m * ldp + p] = acc[r] * alpha;
     }
 }
 

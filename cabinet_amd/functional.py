@@ -9,10 +9,16 @@
 ``stem_conv``       cabinet.py:111                                        (K9)     ``pwconv``   mobilenetv3.py:128-131
 OHEM head           src/utils/loss.py:51-80 + cabinet.py:240-245          (``ohem_up_*``, used by cabinet_amd.loss)
 
-Device tensors ALWAYS go through the hand-written HIP kernels (RuntimeError if the
-library is absent or rejects the shape -- never a silent PyTorch fallback).  Host (CPU)
-tensors take the composite ATen path of the modules so they stay usable for
-checkpoint surgery, EMA copies and CPU unit tests, exactly like any nn.Module.
+ONE dispatch rule for every operator here:
+  * device tensor, shape inside the kernel family's coverage (each family exports ``*_supported``): the hand-written
+    HIP kernels run; a missing / mismatching library or a failing launch raises RuntimeError -- nothing is caught and
+    retried on another path;
+  * device tensor, shape outside the coverage (attention channel pairs other than (128,128) (256,128) (64,64); the local
+    branch above 8192 positions per channel; producers with channel counts that are not multiples of 16; depthwise
+    kernels other than 3 / 5): the module's composite ATen forward, on the device -- the reference API accepts any
+    channel count, so must this one;
+  * host (CPU) tensors: the composite ATen forward, so modules stay usable for checkpoint surgery, EMA copies and CPU
+    unit tests, exactly like any nn.Module.
 """
 
 from __future__ import annotations
@@ -97,6 +103,11 @@ class _CabAttention(torch.autograd.Function):
         return dq, dk, dv, None
 
 
+def cab_attention_supported(Kc, Vc):
+    """True for the (key, value) channel pairs K1 / K2 are instantiated for."""
+    return bool(_lib.load().cabinet_cab_attn_supported(int(Kc), int(Vc)))
+
+
 def cab_attention(q, k, v, scale):
     """ctx[b,c,i] = sum_j softmax_j(scale * <q[b,:,i], k[b,:,j]>) v[b,c,j].
 
@@ -104,9 +115,9 @@ def cab_attention(q, k, v, scale):
     """
     if q.dim() != 3 or k.shape != q.shape or v.dim() != 3 or v.shape[0] != q.shape[0] or v.shape[2] != q.shape[2]:
         raise RuntimeError(f"cab_attention: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
-    if q.is_cuda:
+    if q.is_cuda and cab_attention_supported(q.shape[1], v.shape[1]):
         return _CabAttention.apply(q, k, v, float(scale))
-    # host tensors: composite ATen ops
+    # host tensors, and channel pairs without a gfx950 instantiation: composite ATen ops (module docstring: one rule)
     attn = torch.bmm(q.transpose(1, 2), k) * scale
     attn = F.softmax(attn, dim=-1)
     return torch.bmm(v, attn.transpose(1, 2))
@@ -281,7 +292,16 @@ class batched_bn_counters:
         if self.owner:
             pending, _NBT_PENDING = _NBT_PENDING, None
             if pending:
-                torch._foreach_add_(pending, 1)
+                # a module applied twice inside the context appears twice: a multi-tensor add with a repeated tensor is a
+                # read-modify-write race, so each distinct counter is added its own count
+                counts = {}
+                for t in pending:
+                    counts.setdefault(id(t), [t, 0])[1] += 1
+                by_count = {}
+                for t, c in counts.values():
+                    by_count.setdefault(c, []).append(t)
+                for c, ts in by_count.items():
+                    torch._foreach_add_(ts, c)
         return False
 
 

@@ -55,8 +55,11 @@ const char* cabinet_last_error(void);
  *   ctx[b,c,i] = sum_j softmax_j(scale * sum_c' q[b,c',i] k[b,c',j]) v[b,c,j]
  *   lse[b,i]   = log sum_j exp(scale * S[b,i,j])       (saved for backward)
  * The n x n affinity matrix is never written to memory.
- * Kc must be even, Vc a multiple of 32; n >= 1 arbitrary.
+ * Instantiated for (Kc,Vc) in {(128,128), (256,128), (64,64)}; n >= 1 arbitrary.  cabinet_cab_attn_supported()
+ * answers 1 / 0 for a channel pair; callers route other pairs to their composite path (the fwd / bwd entry points
+ * return CABINET_ERR_UNSUPPORTED for them).
  * ------------------------------------------------------------------------- */
+int cabinet_cab_attn_supported(int Kc, int Vc);
 size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n);
 int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float scale,
                          int B, int Kc, int Vc, int n,

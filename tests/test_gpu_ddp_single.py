@@ -85,6 +85,6 @@ def test_graphed_ddp_step_world1_matches_graphed_single():
             # two GPU runs of stock backward kernels with atomics differ at the 1e-4 level per step and SGD carries it
             # along; a schedule bug (missing average, stale bucket, lost segment) is an O(1) error
             err, den = float((sb[k].double() - sa[k].double()).norm()), float(sa[k].double().norm())
-            assert err <= 2e-3 * den + 1e-6, (k, err, den)
+            assert err <= 2e-3 * den + 1e-5 * sa[k].numel() ** 0.5, (k, err, den)
     finally:
         dist.destroy_process_group()

@@ -9,12 +9,11 @@
 * every hand-written operator of the timed step at its production grid (the grids the model reaches at config 3 /
   config 5) against its fp64 oracle.
 
-Gradient rule in train mode (no blanket bound): a tensor passes when it is within 1e-3 of the fp32 reference or of the
-fp64 oracle.  A tensor beyond both must be listed in tests/golden/grad_allowlist.json together with the measured
-distance of the fp32 CPU REFERENCE ITSELF from the fp64 oracle on that tensor (>= 2.5e-4, checked by the CPU test
-tests/test_oracle_golden.py::test_grad_allowlist_is_justified), and must then be no further from the fp64 oracle than
-3x that listed distance: where the reference's own fp32 result is not decidable at 1e-3, "as close to the truth as the
-reference is" is the claim that can be checked.
+Gradient rule (tests/parity_rules.py, where the measurements behind it are summarised): a tensor passes when it is within
+1e-3 of the fp32 reference or of the fp64 oracle; otherwise it must be no further from the fp64 oracle than 3x the fp32
+REFERENCE's own distance from fp64 (on that tensor, measured live, or the configuration's committed 90th percentile) or the
+effect of three single-unit ReLU flips on the CAB grid.  No blanket tolerance; the per-tensor table of every run is written
+to gpurun_out/ and committed under profiles/.
 """
 import copy
 
@@ -68,15 +67,14 @@ def _full_step(mode, batch, height, width, ncls, tag):
     _, _, loss64 = model_ref.train_step(w64, im.double(), lb, mode)
     ref64 = w64.grads()
     rows = gradient_table(net, ref32, ref64)
-    allow = load_allowlist().get(tag, {})
-    failures, listed = judge_gradients(rows, allow)
+    failures, listed = judge_gradients(rows, load_allowlist()[tag])
     worst = sorted(((r["gpu_vs_f64"], k) for k, r in rows.items() if not r["analytic_zero"]), reverse=True)[:10]
     write_table(f"parity_{tag}.json", dict(
         config=dict(mode=mode, batch=batch, height=height, width=width, n_classes=ncls, gamma=0.5, model_seed=0,
                     data_seed=1),
         logits_rel=e / d, logits16_rel=e16 / d16, loss_gpu=loss, loss_ref32=float(loss_ref), loss_f64=float(loss64),
-        tolerance=TOL, allow_factor=ALLOW_FACTOR, tensors_past_tol_vs_both=[k for k, _ in failures] + listed,
-        allow_listed=listed, failures=[k for k, _ in failures], worst_vs_f64=worst, tensors=rows))
+        tolerance=TOL, allow_factor=ALLOW_FACTOR, rule=load_allowlist()[tag],
+        past_1e3_within_bound=listed, failures=[k for k, _ in failures], worst_vs_f64=worst, tensors=rows))
     assert e <= TOL * d, f"final_logit rel {e / d:.3e}"
     assert e16 <= TOL * d16, f"high_res_logit_up rel {e16 / d16:.3e}"
     assert abs(loss - float(loss_ref)) <= TOL * abs(float(loss_ref)), (loss, float(loss_ref))
@@ -103,13 +101,12 @@ def test_full_step_config5_large_2x2048x1024_19cls():
 def test_model_eval_bn_gradients_flat_1e3(mode, batch, size, ncls):
     """BatchNorm in eval mode on populated running statistics: the network keeps every hand-written kernel in the
     loop (eval-mode BN folds, attention, FFM, OHEM) but loses the batch-statistic coupling that makes the train-mode
-    gradient ill-conditioned, so EVERY gradient tensor is held to a flat 1e-3 -- against the fp32 reference or the fp64
-    oracle.  What is left past that are ReLU-mask flips, which no fp32 implementation can avoid: a pre-activation within
-    rounding distance of zero lands on the other side and the gradient through that unit toggles.  On big maps they
-    average to ~sqrt(0.8 * forward error) per ReLU layer (sb.*: three layers of 4.5e-4 for the CPU reference itself); on
-    the 16x16 maps of Large 2x512^2 ONE flipped unit of q (1 of 65,536, found with tools/diag_cab_internal.py: with the
-    fp64 mask the GPU's own dq gives d(beta_q) to 3.4e-5) moves d(beta_q) by 2e-3 and dW_q by 4.5e-3.  Those entries are
-    in tests/golden/grad_allowlist.json under the eval_* tags, each with an explicit bound and its explanation."""
+    gradient ill-conditioned: the fp32 reference is then within 1e-4 of fp64 on the median tensor, and so is the HIP model
+    (profiles/r02_parity_eval_*.json).  What is left are ReLU-mask flips, which no fp32 implementation can avoid: on big
+    maps ~sqrt(0.8 * forward error) per ReLU layer (sb.*: three layers, 1.4e-3 for the CPU reference itself); on the 16x16
+    maps of Large 2x512^2 ONE flipped unit of q (1 of 65,536, found with tools/diag_cab_internal.py: with the fp64 mask the
+    GPU's own dq gives d(beta_q) to 3.4e-5) moves d(beta_q) by 2e-3 and dW_q by 4.5e-3.  Same rule as everywhere
+    (tests/parity_rules.py); in this mode it is the flip term that decides."""
     from cabinet_amd.train import build_model, make_criteria, synthetic_batch
     from oracle import model_ref
 
@@ -146,8 +143,8 @@ def test_model_eval_bn_gradients_flat_1e3(mode, batch, size, ncls):
     tag = f"eval_{mode}_{batch}x{size}"
     rows = gradient_table(net, ref32, refs[torch.float64][3])
     assert len(rows) > 150
-    failures, listed = judge_gradients(rows, load_allowlist().get(tag, {}))
-    write_table(f"parity_{tag}.json", dict(allow_listed=listed, failures=[k for k, _ in failures], tensors=rows))
+    failures, listed = judge_gradients(rows, load_allowlist()[tag])
+    write_table(f"parity_{tag}.json", dict(past_1e3_within_bound=listed, failures=[k for k, _ in failures], tensors=rows))
     assert not failures, [(k, {n: f"{v:.2e}" for n, v in r.items() if isinstance(v, float)}) for k, r in failures]
     for k, v in net.state_dict().items():  # eval mode: no buffer moved
         if "running_" in k:
