@@ -38,7 +38,10 @@ constexpr int GK_NT = 128;  // pixels per tile (2 waves x 2 blocks x 32)
 // INTERIOR: every tile is full (P % 128 == 0, M % tile == 0, 16-byte aligned rows): the staging loads
 // carry no guards, so nothing forces the compiler to wait for them before the MFMA block of the
 // current chunk (the guarded form branches per load and drains vmcnt at every join).
-template <int WM, bool INTERIOR>  // 32-row blocks per wave along m; tile = 4 waves x WM x 32 rows
+// UP: 0 = no epilogue term, 1 = + bilinear upsample with the tile inside ONE output row (two source rows lerped into LDS),
+// 2 = + bilinear upsample by four gathers per output (any geometry).  A template parameter, not a runtime branch: with the
+// gather epilogue compiled into every instance the WM = 2 kernel needed 256 VGPRs and spilled 324 bytes per lane.
+template <int WM, bool INTERIOR, int UP>  // 32-row blocks per wave along m; tile = 4 waves x WM x 32 rows
 __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
     constexpr int MT = 128 * WM;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -117,9 +120,9 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
     }
 
     // ---- optional epilogue term: + bilinear upsample of a low-resolution (B, M, Hl, Wl) map ----
-    if (a.up_src) {
+    if (UP != 0) {
         const size_t plane = (size_t)a.Hl * a.Wl;
-        if (INTERIOR && (a.W % GK_NT) == 0 && a.Wl <= 32) {  // vrow (MT x Wl floats) must fit the staging LDS
+        if (UP == 1) {  // host guarantees: INTERIOR, W % 128 == 0, Wl == 32 (vrow = MT x 32 floats fits the staging LDS)
             // the tile is a 128-pixel segment of ONE output row: interpolate the two source rows vertically
             // into LDS once (coalesced), then every output needs two LDS reads instead of four L2 gathers
             float* vrow = smem;  // [MT][Wl], aliases the staging buffers (all waves are past the last barrier)
@@ -127,8 +130,9 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
             int y0, y1;
             float ly;
             bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
-            for (int idx = tid; idx < MT * a.Wl; idx += 512) {
-                const int ml = idx / a.Wl, xs = idx - ml * a.Wl;
+#pragma unroll 2
+            for (int idx = tid; idx < MT * 32; idx += 512) {  // Wl == 32 (see above)
+                const int ml = idx >> 5, xs = idx & 31;
                 const float* src = a.up_src + ((size_t)b * M + m0 + ml) * plane;
                 vrow[idx] = (1.f - ly) * src[y0 * a.Wl + xs] + ly * src[y1 * a.Wl + xs];
             }
@@ -137,15 +141,25 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
             float lx[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bilinear_taps(ox0 + wn * 64 + j * 32 + li, a.rw, a.Wl, x0[j], x1[j], lx[j]);
+            // the accumulators live in the AGPR half of the register file: adding the upsample term IN PLACE made the
+            // compiler copy all 64 of them to VGPRs (206 registers, one workgroup per CU); the term is therefore added
+            // in the store loop, one value at a time (117 registers, two workgroups per CU)
+            const float* v0[2] = {vrow + (wm * (WM * 32) + 4 * h) * 32 + x0[0], vrow + (wm * (WM * 32) + 4 * h) * 32 + x0[1]};
+            const float* v1[2] = {vrow + (wm * (WM * 32) + 4 * h) * 32 + x1[0], vrow + (wm * (WM * 32) + 4 * h) * 32 + x1[1]};
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int i = 0; i < WM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float* vr = vrow + (wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h) * a.Wl;
+                    const int m = m0 + wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h;
+                    float* drow = (m < a.M0) ? a.dst0 + ((size_t)b * a.M0 + m) * P
+                                             : a.dst1 + ((size_t)b * (M - a.M0) + (m - a.M0)) * P;
+                    const int off = (i * 32 + acc_row(r)) * 32;  // compile-time: an immediate LDS offset
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j][r] += (1.f - lx[j]) * vr[x0[j]] + lx[j] * vr[x1[j]];
+                    for (int j = 0; j < 2; ++j)
+                        drow[p0 + wn * 64 + j * 32 + li] = acc[i][j][r] + ((1.f - lx[j]) * v0[j][off] + lx[j] * v1[j][off]);
                 }
-            __syncthreads();  // vrow is dead before s_stat (same LDS) is written below
+            }
+            return;  // INTERIOR: every row and column of the tile exists, nothing left to store
         } else {
             int o00[2], o01[2], o10[2], o11[2];
             float w00[2], w01[2], w10[2], w11[2];
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j][r] += w00[j] * src[o00[j]] + w01[j] * src[o01[j]] + w10[j] * src[o10[j]] +
                                         w11[j] * src[o11[j]];
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 32 gathers in flight, not 256 (register budget)
                 }
         }
     }
@@ -192,18 +207,30 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
     }
 }
 
-template <int WM, bool INTERIOR>
+template <int WM, bool INTERIOR, int UP>
 static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
     constexpr int MT = 128 * WM;
     const size_t lds = (size_t)(2 * GK_BK * MT + 2 * GK_BK * GK_NT) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR, UP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid(ceil_div(a.P, GK_NT), ceil_div(a.M, MT), B);
-    hipLaunchKernelGGL((gemm_kmajor_kernel<WM, INTERIOR>), grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm_kmajor_kernel<WM, INTERIOR, UP>), grid, dim3(512), lds, stream, a);
+}
+
+template <int WM>
+static void launch_gemm_k_wm(const GemmKArgs& a, int B, bool interior, hipStream_t stream) {
+    // the row form of the upsample epilogue needs full tiles that are segments of one output row, and room for vrow
+    const bool row_up = a.up_src && interior && (a.W % GK_NT) == 0 && a.Wl == 32;
+    if (!a.up_src)
+        interior ? launch_gemm_k<WM, true, 0>(a, B, stream) : launch_gemm_k<WM, false, 0>(a, B, stream);
+    else if (row_up)
+        launch_gemm_k<WM, true, 1>(a, B, stream);
+    else
+        interior ? launch_gemm_k<WM, true, 2>(a, B, stream) : launch_gemm_k<WM, false, 2>(a, B, stream);
 }
 
 void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
@@ -211,11 +238,11 @@ void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
     if (wm > 1 && (a.M % 128) == 0 && ceil_div(a.P, GK_NT) * B * ceil_div(a.M, 128 * wm) < 200) wm = 1;  // small grid
     const bool interior = (a.P % GK_NT) == 0 && (a.M % (128 * wm)) == 0 && (a.lda % 4) == 0;
     if (wm == 1)
-        interior ? launch_gemm_k<1, true>(a, B, stream) : launch_gemm_k<1, false>(a, B, stream);
+        launch_gemm_k_wm<1>(a, B, interior, stream);
     else if (wm == 3)
-        interior ? launch_gemm_k<3, true>(a, B, stream) : launch_gemm_k<3, false>(a, B, stream);
+        launch_gemm_k_wm<3>(a, B, interior, stream);
     else
-        interior ? launch_gemm_k<2, true>(a, B, stream) : launch_gemm_k<2, false>(a, B, stream);
+        launch_gemm_k_wm<2>(a, B, interior, stream);
 }
 
 // =====================================================================================
