@@ -65,7 +65,7 @@ struct SgJobs {
     int n;
 };
 const char* sg_gemm_unsupported(const SgJob& j);  // nullptr when the small path can take the job
-void sg_gemm(SgJobs& jobs, int B, hipStream_t stream);
+void sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb = 1);  // mb: 64-row blocks per workgroup tile (1 | 2)
 
 struct SdJob {
     const float* a;   // (B, a_rows, P), rows [0, M)

@@ -652,7 +652,8 @@ static void launch_dq_from_ds(const float* k, const float* kmean, const float* d
         j.b_pmajor = 1, j.ldb = n, j.a_bias = kmean, j.alpha = scale;
         j.a_img_stride = (size_t)KC * n;  // A = the keys of image b
     }
-    sg_gemm(jobs, B, stream);
+    sg_gemm(jobs, B, stream);  // (128-row tiles, sg_gemm's mb = 2, read every dS tile once but measured 41 vs 36 us: the
+                               // product is bound by the per-chunk latency of its 8-chunk workgroups, not by traffic)
     if (ks > 1) {
         const size_t cq = (size_t)B * KC * n;
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, slabs, dq, cq, ks);

@@ -24,8 +24,12 @@ constexpr int SG_BK = 32;    // contraction chunk
 constexpr int SG_STR = 68;   // LDS row stride of a [k][64] chunk (16-byte aligned rows)
 constexpr int SD_STR = 33;   // LDS row stride of a [row][32 positions] image
 
+// MB: 64-row blocks of the output tile per workgroup (tile = 64*MB x 64).  MB = 2 halves the B-operand traffic of a
+// product whose B is the big operand (dq = dS K^T: dS is 33.5 MB and was read once per 64-row tile of the 128 channels).
+template <int MB>
 __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
-    __shared__ __attribute__((aligned(16))) float As[2][SG_BK * SG_STR];
+    constexpr int MT = SG_T * MB, ASTR = MT + 4, ASTR_T = MT + 1;
+    __shared__ __attribute__((aligned(16))) float As[2][SG_BK * ASTR];
     __shared__ __attribute__((aligned(16))) float Bs[2][SG_BK * SG_STR];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -36,18 +40,20 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
     const int nt = t % J.tiles_n;
     t /= J.tiles_n;
     const int mt = t % J.tiles_m, b = t / J.tiles_m;
-    const int m0 = mt * SG_T, p0 = nt * SG_T, M = J.M, P = J.P, lda = J.lda, ldp = J.ldp;
+    const int m0 = mt * MT, p0 = nt * SG_T, M = J.M, P = J.P, lda = J.lda, ldp = J.ldp;
     const bool vec_p = J.vec != 0;
-    // LDS row strides: 68 keeps float4 stores aligned for operands stored as read; an operand transposed on the way in is
-    // written with scalar stores down a column, where stride 65 gives 2-way bank conflicts (free for ds_write_b32) instead
-    // of the 4-way of stride 68
-    const int astr = J.a_mmajor ? 65 : SG_STR, bstr = J.b_pmajor ? 65 : SG_STR;
+    // LDS row strides: a multiple of 4 keeps float4 stores aligned for operands stored as read; an operand transposed on
+    // the way in is written with scalar stores down a column, where an odd stride gives 2-way bank conflicts (free for
+    // ds_write_b32) instead of 4-way
+    const int astr = J.a_mmajor ? ASTR_T : ASTR, bstr = J.b_pmajor ? 65 : SG_STR;
 
-    f32x16 acc;
+    f32x16 acc[MB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[2 * MB], rb[2];
     auto load_chunk = [&](int ci) {
         int s = 0, c = ci;
         while (c >= J.nck[s]) c -= J.nck[s], ++s;
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
         const float* __restrict__ ap = J.seg[s].a + (size_t)b * J.a_img_stride;
         const float* __restrict__ bp = J.seg[s].b + (size_t)b * J.seg[s].b_rows * ldp;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 * MB; ++i) {
             const int idx = tid + i * 256;
             if (J.a_mmajor) {  // A stored (M, K) row-major: 8 threads read one row's 32-float run
                 const int mrow = idx >> 3, k = k0 + (idx & 7) * 4, m = m0 + mrow;
@@ -69,11 +75,15 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
                 } else {
                     ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-            } else {           // A stored (K, M): 16 threads read one k-row's 64-float run
-                const int kk = idx >> 4, m = m0 + (idx & 15) * 4;
+            } else {           // A stored (K, M): 16*MB threads read one k-row's MT-float run
+                const int kk = idx / (MT / 4), m = m0 + (idx % (MT / 4)) * 4;
                 ra[i] = (k0 + kk < kseg && m < M) ? *reinterpret_cast<const f32x4*>(ap + (size_t)(k0 + kk) * lda + m)
                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
             if (J.b_pmajor) {  // B stored (P, K): 8 threads read one position's 32-float run, transposed on the way to LDS
                 const int prow = idx >> 3, k = k0 + (idx & 7) * 4, pp = p0 + prow;
                 rb[i] = (pp < P && k < kseg) ? *reinterpret_cast<const f32x4*>(J.seg[s].b + ((size_t)b * J.seg[s].b_rows + pp) * J.ldb + k)
@@ -92,15 +102,19 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2 * MB; ++i) {
             const int idx = tid + i * 256;
             if (J.a_mmajor) {
                 const int mrow = idx >> 3, k4 = (idx & 7) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) As[buf][(k4 + e) * astr + mrow] = ra[i][e];
             } else {
-                *reinterpret_cast<f32x4*>(&As[buf][(idx >> 4) * SG_STR + (idx & 15) * 4]) = ra[i];
+                *reinterpret_cast<f32x4*>(&As[buf][(idx / (MT / 4)) * ASTR + (idx % (MT / 4)) * 4]) = ra[i];
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
             if (J.b_pmajor) {
                 const int prow = idx >> 3, k4 = (idx & 7) * 4;
 #pragma unroll
@@ -121,7 +135,11 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
         const float* Ab = &As[buf][wm * 32 + li];
         const float* Bb = &Bs[buf][wn * 32 + li];
 #pragma unroll
-        for (int kk = 0; kk < SG_BK; kk += 2) acc = mfma32(Ab[(kk + h) * astr], Bb[(kk + h) * bstr], acc);
+        for (int kk = 0; kk < SG_BK; kk += 2) {
+            const float bv = Bb[(kk + h) * bstr];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma32(Ab[(kk + h) * astr + mb * 64], bv, acc[mb]);
+        }
         if (ci + 1 < nchunks) store_chunk(buf ^ 1);
         __syncthreads();
     }
@@ -129,10 +147,12 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
     const int p = p0 + wn * 32 + li;
     const float alpha = J.alpha != 0.f ? J.alpha : 1.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + acc_row(r) + 4 * h;
-        if (m < M && p < P) dst[(size_t)m * ldp + p] = acc[r] * alpha;
-    }
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mb * 64 + wm * 32 + acc_row(r) + 4 * h;
+            if (m < M && p < P) dst[(size_t)m * ldp + p] = acc[mb][r] * alpha;
+        }
 }
 
 const char* sg_gemm_unsupported(const SgJob& j) {
@@ -143,7 +163,8 @@ const char* sg_gemm_unsupported(const SgJob& j) {
     return nullptr;
 }
 
-void sg_gemm(SgJobs& jobs, int B, hipStream_t stream) {
+void sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb) {
+    const int MT = SG_T * (mb == 2 ? 2 : 1);
     int base = 0;
     for (int i = 0; i < jobs.n; ++i) {
         SgJob& j = jobs.j[i];
@@ -153,10 +174,13 @@ void sg_gemm(SgJobs& jobs, int B, hipStream_t stream) {
             j.nck[s] = s < j.nseg ? ceil_div(j.seg[s].k, SG_BK) : 0;
             if (s < j.nseg && (reinterpret_cast<uintptr_t>(j.seg[s].b) & 15)) j.vec = 0;  // column window off a 16-byte boundary
         }
-        j.tiles_m = ceil_div(j.M, SG_T), j.tiles_n = ceil_div(j.P, SG_T), j.tile_base = base;
+        j.tiles_m = ceil_div(j.M, MT), j.tiles_n = ceil_div(j.P, SG_T), j.tile_base = base;
         base += j.tiles_m * j.tiles_n * B;
     }
-    hipLaunchKernelGGL(sg_gemm_kernel, dim3(base), dim3(256), 0, stream, jobs);
+    if (mb == 2)
+        hipLaunchKernelGGL(sg_gemm_kernel<2>, dim3(base), dim3(256), 0, stream, jobs);
+    else
+        hipLaunchKernelGGL(sg_gemm_kernel<1>, dim3(base), dim3(256), 0, stream, jobs);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CABINET_ABI_VERSION 1
+#define CABINET_ABI_VERSION 2
 
 #define CABINET_OK 0
 #define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
