@@ -675,16 +675,27 @@ __global__ __launch_bounds__(256) void ffm_se_kernel(const float* __restrict__ p
     for (int j0 = 0; j0 < Cm; j0 += per_pass) {
         const int j = j0 + tid / G, q = tid % G;
         float acc = 0.f;
-        if (j < Cm)
-            for (int c = q; c < Co; c += G) acc += w1[(size_t)j * Co + c] * m[c];
+        if (j < Cm) {
+#pragma unroll 8
+            for (int c = q; c < Co; c += G) acc += w1[(size_t)j * Co + c] * m[c];  // unrolled: independent loads in flight
+        }
         for (int o = G >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (j < Cm && q == 0) r[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
     for (int c = tid; c < Co; c += 256) {
-        float acc = 0.f;
-        for (int j = 0; j < Cm; ++j) acc += w2[(size_t)c * Cm + j] * r[j];
-        gate[(size_t)b * Co + c] = 1.f / (1.f + expf(-acc));
+        const float* wr = w2 + (size_t)c * Cm;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four chains instead of one serial chain of Cm dependent loads
+        int j = 0;
+#pragma unroll 4
+        for (; j + 3 < Cm; j += 4) {
+            a0 += wr[j] * r[j];
+            a1 += wr[j + 1] * r[j + 1];
+            a2 += wr[j + 2] * r[j + 2];
+            a3 += wr[j + 3] * r[j + 3];
+        }
+        for (; j < Cm; ++j) a0 += wr[j] * r[j];
+        gate[(size_t)b * Co + c] = 1.f / (1.f + expf(-((a0 + a1) + (a2 + a3))));
     }
 }
 
@@ -803,9 +814,18 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
     __syncthreads();
     float* d1 = dw1_part + (size_t)b * Co * Cm;
     float* d2 = dw2_part + (size_t)b * Co * Cm;
-    for (int i = tid; i < Co * Cm; i += 256) {
-        d2[i] = ds[i / Cm] * fmaxf(u[i % Cm], 0.f);  // dw2[c][j] = ds[c] relu(u[j])
-        d1[i] = du[i / Co] * m[i % Co];              // dw1[j][c] = du[j] m[c]
+    {   // dw2[c][j] = ds[c] relu(u[j]),  dw1[j][c] = du[j] m[c]: (row, col) advanced incrementally -- the flat-index form
+        // spent four emulated integer divisions per element
+        int r2 = tid / Cm, c2 = tid - r2 * Cm, r1 = tid / Co, c1 = tid - r1 * Co;
+        const int s2r = 256 / Cm, s2c = 256 - s2r * Cm, s1r = 256 / Co, s1c = 256 - s1r * Co;
+        for (int i = tid; i < Co * Cm; i += 256) {
+            d2[i] = ds[r2] * fmaxf(u[c2], 0.f);
+            d1[i] = du[r1] * m[c1];
+            r2 += s2r, c2 += s2c;
+            if (c2 >= Cm) c2 -= Cm, ++r2;
+            r1 += s1r, c1 += s1c;
+            if (c1 >= Co) c1 -= Co, ++r1;
+        }
     }
     const float inv_p = 1.f / (float)P;
     for (int c = tid; c < Co; c += 256) {
