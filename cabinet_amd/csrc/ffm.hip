@@ -654,49 +654,61 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__
 }
 
 // gate[b][c] = sigmoid(W2 relu(W1 pooled[b]))                 one workgroup per image
-// hidden unit j is owned by a group of G = 256/Cm' threads (a power of two dividing 64): one pass, a short
-// in-wave reduction, no per-row loop of dependent wave reductions.
-__device__ __forceinline__ int se_group(int Cm) {  // threads cooperating on one hidden unit
-    int g = 1;
-    while (g < 64 && Cm * g * 2 <= 256) g *= 2;
-    return g;
+// SE-MLP kernels: one workgroup of SE_T threads per image.  Every product walks its weight matrix along the contiguous
+// dimension (a wave per row, lanes along the row; column sums as per-wave partial rows reduced through LDS), so each phase
+// is one round of independent coalesced loads.  Strided per-thread walks made these kernels chains of dependent ~1 us L2
+// round trips (10 us forward, 19 us backward on eight workgroups).
+constexpr int SE_T = 1024, SE_W = SE_T / 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-__global__ __launch_bounds__(256) void ffm_se_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
-                                                      const float* __restrict__ w2, float* __restrict__ gate, int Co,
-                                                      int Cm) {
+// out[j] = sum_c w[j][c] * x[c]; LR lanes share a row (64 / LR rows per wave at a time), four row groups per pass so that
+// all of a pass's loads are in flight together; f(j, sum) consumes the result on the row's first lane
+template <int LR, typename F>
+__device__ __forceinline__ void se_rows(const float* __restrict__ w, const float* x, int rows, int cols, int wave,
+                                        int lane, F f) {
+    constexpr int RPW = 64 / LR, STEP = SE_W * RPW;  // rows per wave at a time, rows per workgroup at a time
+    const int g = lane / LR, q = lane % LR;
+    for (int j = wave * RPW + g; j < rows; j += 4 * STEP) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* wr[4];  // row index clamped, not branched on: a load under its own branch waits for the previous one
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wr[e] = w + (size_t)min(j + e * STEP, rows - 1) * cols;
+        for (int c = q; c < cols; c += LR) {
+            const float xv = x[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wr[e][c] * xv;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e];
+#pragma unroll
+            for (int o = LR / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (q == 0 && j + e * STEP < rows) f(j + e * STEP, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SE_T) void ffm_se_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                       const float* __restrict__ w2, float* __restrict__ gate, int Co,
+                                                       int Cm) {
     extern __shared__ float sm[];
     float* m = sm;        // [Co]
     float* r = sm + Co;   // [Cm]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < Co; c += 256) m[c] = pooled[(size_t)b * Co + c];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int c = tid; c < Co; c += SE_T) m[c] = pooled[(size_t)b * Co + c];
     __syncthreads();
-    const int G = se_group(Cm), per_pass = 256 / G;
-    for (int j0 = 0; j0 < Cm; j0 += per_pass) {
-        const int j = j0 + tid / G, q = tid % G;
-        float acc = 0.f;
-        if (j < Cm) {
-#pragma unroll 8
-            for (int c = q; c < Co; c += G) acc += w1[(size_t)j * Co + c] * m[c];  // unrolled: independent loads in flight
-        }
-        for (int o = G >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (j < Cm && q == 0) r[j] = fmaxf(acc, 0.f);
-    }
+    se_rows<64>(w1, m, Cm, Co, wave, lane, [&](int j, float v) { r[j] = fmaxf(v, 0.f); });
     __syncthreads();
-    for (int c = tid; c < Co; c += 256) {
-        const float* wr = w2 + (size_t)c * Cm;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four chains instead of one serial chain of Cm dependent loads
-        int j = 0;
-#pragma unroll 4
-        for (; j + 3 < Cm; j += 4) {
-            a0 += wr[j] * r[j];
-            a1 += wr[j + 1] * r[j + 1];
-            a2 += wr[j + 2] * r[j + 2];
-            a3 += wr[j + 3] * r[j + 3];
-        }
-        for (; j < Cm; ++j) a0 += wr[j] * r[j];
-        gate[(size_t)b * Co + c] = 1.f / (1.f + expf(-((a0 + a1) + (a2 + a3))));
-    }
+    auto out = [&](int c, float v) { gate[(size_t)b * Co + c] = 1.f / (1.f + expf(-v)); };
+    if (Cm <= 64)  // short rows: sixteen lanes per row, the whole second product is one round of loads
+        se_rows<16>(w2, r, Co, Cm, wave, lane, out);
+    else
+        se_rows<64>(w2, r, Co, Cm, wave, lane, out);
 }
 
 // out = relu(bn(z)) * (1 + gate)                                 rows of P pixels
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(256) void ffm_bwd_reduce_kernel(const float* __rest
 
 // SE-MLP backward + BN coefficient algebra, stage 1: one workgroup per image.  Writes the dz
 // coefficients a1 = 1 + gate, a2 = dm / P and this image's contributions to dw1, dw2, dbn_w, dbn_b.
-__global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
+__global__ __launch_bounds__(SE_T) void ffm_bwd_image_kernel(
     const float* __restrict__ sums, const float* __restrict__ pooled, const float* __restrict__ gate,
     const float* __restrict__ w1, const float* __restrict__ w2, int Co, int Cm, int P,
     float* __restrict__ dw1_part, float* __restrict__ dw2_part, float* __restrict__ dbn_part,
@@ -781,44 +793,54 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
     float* ds = a + Co;       // [Co]
     float* u = ds + Co;       // [Cm]
     float* du = u + Cm;       // [Cm]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < Co; c += 256) {
+    float* red = du + Cm;     // [SE_W][max(Co, Cm)] per-wave partial rows of the two column sums
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ldr = Co > Cm ? Co : Cm;
+    for (int c = tid; c < Co; c += SE_T) {
         const float av = gate[(size_t)b * Co + c];
         m[c] = pooled[(size_t)b * Co + c];
         a[c] = av;
         ds[c] = sums[((size_t)b * Co + c) * 5 + 0] * av * (1.f - av);
     }
     __syncthreads();
-    {   // u = W1 m ;  dr = W2^T ds : a group of G threads per hidden unit
-        const int G = se_group(Cm), per_pass = 256 / G;
-        for (int j0 = 0; j0 < Cm; j0 += per_pass) {
-            const int j = j0 + tid / G, q = tid % G;
-            float acc = 0.f, dr = 0.f;
-            if (j < Cm) {
+    se_rows<64>(w1, m, Cm, Co, wave, lane, [&](int j, float v) { u[j] = v; });  // u = W1 m
+    for (int j0 = 0; j0 < Cm; j0 += 64) {  // dr = W2^T ds: this wave's rows c of W2, lanes along j
+        const int j = j0 + lane;
+        float p0 = 0.f, p1 = 0.f;
+        if (j < Cm) {
+            int c = wave;
 #pragma unroll 8
-                for (int c = q; c < Co; c += G) {  // unrolled: the loads are independent, keep many in flight
-                    acc += w1[(size_t)j * Co + c] * m[c];
-                    dr += w2[(size_t)c * Cm + j] * ds[c];
-                }
+            for (; c + SE_W < Co; c += 2 * SE_W) {
+                p0 += w2[(size_t)c * Cm + j] * ds[c];
+                p1 += w2[(size_t)(c + SE_W) * Cm + j] * ds[c + SE_W];
             }
-            for (int o = G >> 1; o >= 1; o >>= 1) {
-                acc += __shfl_xor(acc, o, 64);
-                dr += __shfl_xor(dr, o, 64);
-            }
-            if (j < Cm && q == 0) {
-                u[j] = acc;
-                du[j] = acc > 0.f ? dr : 0.f;
-            }
+            if (c < Co) p0 += w2[(size_t)c * Cm + j] * ds[c];
+            red[wave * ldr + j] = p0 + p1;
         }
+    }
+    __syncthreads();
+    for (int j = tid; j < Cm; j += SE_T) {
+        float dr = 0.f;
+#pragma unroll
+        for (int w = 0; w < SE_W; ++w) dr += red[w * ldr + j];
+        du[j] = u[j] > 0.f ? dr : 0.f;
     }
     __syncthreads();
     float* d1 = dw1_part + (size_t)b * Co * Cm;
     float* d2 = dw2_part + (size_t)b * Co * Cm;
-    {   // dw2[c][j] = ds[c] relu(u[j]),  dw1[j][c] = du[j] m[c]: (row, col) advanced incrementally -- the flat-index form
-        // spent four emulated integer divisions per element
+    for (int c0 = 0; c0 < Co; c0 += 64) {  // dm = W1^T du: this wave's rows j of W1, lanes along c
+        const int c = c0 + lane;
+        float p = 0.f;
+        if (c < Co) {
+#pragma unroll 4
+            for (int j = wave; j < Cm; j += SE_W) p += w1[(size_t)j * Co + c] * du[j];
+            red[wave * ldr + c] = p;
+        }
+    }
+    {   // dw2[c][j] = ds[c] relu(u[j]),  dw1[j][c] = du[j] m[c]: (row, col) advanced incrementally, no integer division
         int r2 = tid / Cm, c2 = tid - r2 * Cm, r1 = tid / Co, c1 = tid - r1 * Co;
-        const int s2r = 256 / Cm, s2c = 256 - s2r * Cm, s1r = 256 / Co, s1c = 256 - s1r * Co;
-        for (int i = tid; i < Co * Cm; i += 256) {
+        const int s2r = SE_T / Cm, s2c = SE_T - s2r * Cm, s1r = SE_T / Co, s1c = SE_T - s1r * Co;
+        for (int i = tid; i < Co * Cm; i += SE_T) {
             d2[i] = ds[r2] * fmaxf(u[c2], 0.f);
             d1[i] = du[r1] * m[c1];
             r2 += s2r, c2 += s2c;
@@ -827,25 +849,26 @@ __global__ __launch_bounds__(256) void ffm_bwd_image_kernel(
             if (c1 >= Co) c1 -= Co, ++r1;
         }
     }
+    float s14[4] = {0.f, 0.f, 0.f, 0.f};  // this thread's first channel: its sums are fetched before the barrier
+    if (tid < Co) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s14[e] = sums[((size_t)b * Co + tid) * 5 + 1 + e];
+    }
+    __syncthreads();
     const float inv_p = 1.f / (float)P;
-    for (int c = tid; c < Co; c += 256) {
-        float dm0 = 0.f, dm1 = 0.f, dm2 = 0.f, dm3 = 0.f;  // a serial chain of Cm dependent L2 loads took 20 us per image
-        int j = 0;
-#pragma unroll 4
-        for (; j + 3 < Cm; j += 4) {
-            dm0 += w1[(size_t)j * Co + c] * du[j];
-            dm1 += w1[(size_t)(j + 1) * Co + c] * du[j + 1];
-            dm2 += w1[(size_t)(j + 2) * Co + c] * du[j + 2];
-            dm3 += w1[(size_t)(j + 3) * Co + c] * du[j + 3];
-        }
-        for (; j < Cm; ++j) dm0 += w1[(size_t)j * Co + c] * du[j];
-        const float dm = (dm0 + dm1) + (dm2 + dm3);
+    for (int c = tid; c < Co; c += SE_T) {
+        float dm = 0.f;
+#pragma unroll
+        for (int w = 0; w < SE_W; ++w) dm += red[w * ldr + c];
         const float a1 = 1.f + a[c], a2 = dm * inv_p;
-        const float* s = sums + ((size_t)b * Co + c) * 5;
+        if (c != tid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s14[e] = sums[((size_t)b * Co + c) * 5 + 1 + e];
+        }
         coef_a1[(size_t)b * Co + c] = a1;
         coef_a2[(size_t)b * Co + c] = a2;
-        dbn_part[((size_t)b * 2 + 0) * Co + c] = a1 * s[1] + a2 * s[3];  // sum_p dy
-        dbn_part[((size_t)b * 2 + 1) * Co + c] = a1 * s[2] + a2 * s[4];  // sum_p dy * xhat
+        dbn_part[((size_t)b * 2 + 0) * Co + c] = a1 * s14[0] + a2 * s14[2];  // sum_p dy
+        dbn_part[((size_t)b * 2 + 1) * Co + c] = a1 * s14[1] + a2 * s14[3];  // sum_p dy * xhat
     }
 }
 
@@ -950,7 +973,7 @@ static void ffm_fwd_tail(const FfmShape& s, double* stat_part, const float* bn_w
                        (long long)s.B * P, training, momentum, eps, run_mean, run_var, save_mean, save_invstd);
     hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w, bn_b,
                        pooled, s.Co, P);
-    hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(256), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
+    hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(SE_T), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
                        w2, gate, s.Co, s.Cm);
     const int cpr = ceil_div(P, 4096);
     hipLaunchKernelGGL(ffm_gate_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w,
@@ -1069,8 +1092,9 @@ static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const fl
     float* dbnp = reinterpret_cast<float*>(base + L.dbnp);
     hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
                        bn_w, bn_b, sums, s.Co, P);
-    hipLaunchKernelGGL(ffm_bwd_image_kernel, dim3(s.B), dim3(256), (size_t)(3 * s.Co + 2 * s.Cm) * sizeof(float), stream,
-                       sums, pooled, gate, w1, w2, s.Co, s.Cm, P, dw1p, dw2p, dbnp, a1, a2);
+    hipLaunchKernelGGL(ffm_bwd_image_kernel, dim3(s.B), dim3(SE_T),
+                       (size_t)(3 * s.Co + 2 * s.Cm + SE_W * (s.Co > s.Cm ? s.Co : s.Cm)) * sizeof(float), stream, sums,
+                       pooled, gate, w1, w2, s.Co, s.Cm, P, dw1p, dw2p, dbnp, a1, a2);
     hipLaunchKernelGGL(ffm_bwd_combine_kernel, dim3(ceil_div(s.Co * s.Cm, 256)), dim3(256), 0, stream, dw1p, dw2p, dbnp,
                        s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, mdy, mdyx);
     if (!dz_pass) return;  // the fused-upsample form computes dz inside the upsample-adjoint kernel
