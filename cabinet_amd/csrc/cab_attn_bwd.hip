@@ -485,7 +485,9 @@ __global__ void sum_parts_kernel(const float* __restrict__ part, float* __restri
     out[i] = s;
 }
 
-template <int KC, int VC>
+// DK = false: dk is NOT accumulated here (no q image, no dk registers) -- for Kc = 256 the 128 extra accumulators and the
+// 128 KB of q images do not fit; dk = scale * q dS is then a second product over the stored dS, like dq (launch_bwd_fast).
+template <int KC, int VC, bool DK>
 __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
     const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -494,8 +496,9 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* kt = smem;                    // [KC][32] raw k tile   (B operand of S)
     float* vt = kt + KC * 32;            // [VC][32] raw v tile   (B operand of dP)
-    float* img = vt + VC * 32;           // [4 waves][(KC+VC)*32] swizzled transposed q | g tiles
+    float* img = vt + VC * 32;           // [4 waves][(KC+VC)*32] swizzled transposed q | g tiles (DK; else g only)
     float* red = img;                    // reduction scratch aliases the images after the main loop
+    constexpr int IMGW = (DK ? KC + VC : VC) * 32, VOFF = DK ? KC : 0;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int nkt = (n + 31) >> 5, per_img = nkt * nsplit;
@@ -526,17 +529,17 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     }
     __syncthreads();
 
-    f32x16 dka[KB], dva[VB];
+    f32x16 dka[DK ? KB : 1], dva[VB];
 #pragma unroll
-    for (int cb = 0; cb < KB; ++cb)
+    for (int cb = 0; cb < (DK ? KB : 1); ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dka[cb][r] = 0.f;
 #pragma unroll
     for (int cb = 0; cb < VB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dva[cb][r] = 0.f;
-    float* qim = img + wave * ((KC + VC) * 32);
-    float* gim = qim + KC * 32;
+    float* qim = img + wave * IMGW;
+    float* gim = qim + (DK ? KC * 32 : 0);
 
     for (int t = t0; t < NT; t += tstep) {
         const int i0 = t * 32;
@@ -554,7 +557,9 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
         }
         // S chain (A = q registers, B = k tile in LDS); q row pairs go to the transposed image behind it
         chain_regA_ldsB<KC / 2>(s, qv, [&](int c2) { return kt[(2 * c2 + h) * 32 + li]; },
-                                [&](int c2) { qim[simg(2 * c2 + h, li)] = qv[c2]; });
+                                [&](int c2) {
+                                    if (DK) qim[simg(2 * c2 + h, li)] = qv[c2];
+                                });
         // dP chain (A = g registers); g rows to its image, q registers refilled with the next tile
         chain_regA_ldsB<VC / 2>(dp, gv, [&](int c2) { return vt[(2 * c2 + h) * 32 + li]; }, [&](int c2) {
             gim[simg(2 * c2 + h, li)] = gv[c2];
@@ -582,25 +587,28 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
                              for (int u = slot * (VC / 2) / (16 * VB); u < (slot + 1) * (VC / 2) / (16 * VB); ++u)
                                  gv[u] = bload(g_rs, voff_n, u * 2 * row_bytes);
                          });
-        product_ldsA<KB>(dka, [&](int cb, int r) { return qim[simg(cb * 32 + li, acc_row(r) + 4 * h)]; }, s,
-                         [&](int) {});
+        if constexpr (DK)
+            product_ldsA<KB>(dka, [&](int cb, int r) { return qim[simg(cb * 32 + li, acc_row(r) + 4 * h)]; }, s,
+                             [&](int) {});
     }
 
     __syncthreads();  // every wave is done with its images: reuse them as reduction scratch
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
+            if constexpr (DK) {
 #pragma unroll
-            for (int cb = 0; cb < KB; ++cb)
+                for (int cb = 0; cb < KB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int idx = (cb * 32 + acc_row(r) + 4 * h) * 32 + li;
-                    red[idx] = (w == 0) ? dka[cb][r] : red[idx] + dka[cb][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int idx = (cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                        red[idx] = (w == 0) ? dka[cb][r] : red[idx] + dka[cb][r];
+                    }
+            }
 #pragma unroll
             for (int cb = 0; cb < VB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int idx = (KC + cb * 32 + acc_row(r) + 4 * h) * 32 + li;
+                    const int idx = (VOFF + cb * 32 + acc_row(r) + 4 * h) * 32 + li;
                     red[idx] = (w == 0) ? dva[cb][r] : red[idx] + dva[cb][r];
                 }
         }
@@ -608,13 +616,15 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     }
     float* dk_out = dk + (size_t)split * B * KC * n;
     float* dv_out = dv + (size_t)split * B * VC * n;
-    for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
-        const int c = idx >> 5, j = idx & 31;
-        if (j0 + j < n) dk_out[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
+    if constexpr (DK) {
+        for (int idx = threadIdx.x; idx < KC * 32; idx += 256) {
+            const int c = idx >> 5, j = idx & 31;
+            if (j0 + j < n) dk_out[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
+        }
     }
     for (int idx = threadIdx.x; idx < VC * 32; idx += 256) {
         const int c = idx >> 5, j = idx & 31;
-        if (j0 + j < n) dv_out[v_base + (size_t)c * n + j0 + j] = red[KC * 32 + idx];
+        if (j0 + j < n) dv_out[v_base + (size_t)c * n + j0 + j] = red[VOFF * 32 + idx];
     }
 }
 
@@ -660,15 +670,39 @@ static void launch_dq_from_ds(const float* k, const float* kmean, const float* d
     }
 }
 
+// dk from the stored dS: dk[b][c][j] = scale * sum_i q[b][c][i] dS[b][i][j]  (A = Q as stored, B = dS row-major), the query
+// range cut into segments like the key range above.  Used where the dk accumulators do not fit the dk/dv kernel (Kc = 256).
+static void launch_dk_from_ds(const float* q, const float* ds, float scale, int B, int KC, int n, float* dk, float* slabs,
+                              hipStream_t stream) {
+    const int ks = dq_ksplit(n), seg = (n / ks + 3) & ~3;
+    SgJobs jobs{};
+    jobs.n = ks;
+    for (int i = 0; i < ks; ++i) {
+        const int i0 = i * seg, il = (i == ks - 1) ? n - i0 : seg;
+        SgJob& j = jobs.j[i];
+        j.seg[0] = {q + i0, ds + (size_t)i0 * n, il, n};
+        j.nseg = 1, j.lda = n, j.a_mmajor = 1, j.M = KC, j.P = n, j.dst = ks == 1 ? dk : slabs + (size_t)i * B * KC * n,
+        j.dst_rows = KC;
+        j.alpha = scale;
+        j.a_img_stride = (size_t)KC * n;  // A = the queries of image b
+    }
+    sg_gemm(jobs, B, stream);
+    if (ks > 1) {
+        const size_t cq = (size_t)B * KC * n;
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, slabs, dk, cq, ks);
+    }
+}
+
 // the stored-dS form needs 16-byte aligned rows of K and dS for the small GEMM's vector loads
 static bool use_ds_path(int n) { return (n & 3) == 0; }
 
-template <int KC, int VC>
+template <int KC, int VC, bool DK = true>  // DK = false requires the stored-dS form (n % 4 == 0)
 static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k, const float* v,
                                   const float* ctx, const float* lse, float scale, int B, int n, float* dq,
                                   float* dk, float* dv, float* delta, hipStream_t stream) {
     float* kmean = delta + align_up((size_t)B * n, 64);
     const bool dsp = use_ds_path(n);
+    if (!DK && !dsp) return hipErrorInvalidValue;
     if (dsp) {
         const int nb_delta = B * ((n + 63) / 64);
         hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 3) / 4), dim3(256), 0, stream, g, ctx, k, delta,
@@ -677,17 +711,18 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
         hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
     }
     const size_t lds_dq = (size_t)((KC + VC) * 32 + 4 * KC * 32 + KC * 32 + 256 + 64 + KC) * sizeof(float);
-    const size_t lds_kv = (size_t)((KC + VC) * 32 + 4 * (KC + VC) * 32) * sizeof(float);
-    auto k_dq = cab_attn_bwd_dq_fast_kernel<KC, VC>;
-    auto k_kv = cab_attn_bwd_dkdv_fast_kernel<KC, VC>;
+    const size_t lds_kv = (size_t)((KC + VC) * 32 + 4 * (DK ? KC + VC : VC) * 32) * sizeof(float);
+    auto k_kv = cab_attn_bwd_dkdv_fast_kernel<KC, VC, DK>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dq),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_kv);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_kv);
-        if (e != hipSuccess) return e;
+        if constexpr (DK) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_attn_bwd_dq_fast_kernel<KC, VC>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
     const int nsplit = bwd_nsplit(B, n);
@@ -695,22 +730,31 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
     float* part_v = part_k + (size_t)(nsplit > 1 ? nsplit : 0) * B * KC * n;
     float* ds = dsp ? part_v + (size_t)(nsplit > 1 ? nsplit : 0) * B * VC * n : nullptr;
     dim3 grid(((n + 31) / 32) * B * nsplit);
+    const size_t cq = (size_t)B * KC * n, cv = (size_t)B * VC * n;
+    if constexpr (DK) {
+        if (!dsp) {
+            auto k_dq = cab_attn_bwd_dq_fast_kernel<KC, VC>;
+            hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, nsplit == 1 ? dq : part_k,
+                               delta, n, scale, B, nsplit);
+            if (nsplit > 1)
+                hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dq,
+                                   cq, nsplit);
+        }
+    }
     if (nsplit == 1) {
-        if (!dsp)
-            hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale, B, 1);
         hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, ds, n, scale, B, 1);
     } else {
         // partial slabs live behind D_i and the mean key in the workspace: [nsplit][B][KC][n] then [nsplit][B][VC][n]
-        const size_t cq = (size_t)B * KC * n, cv = (size_t)B * VC * n;
-        if (!dsp) {
-            hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, part_k, delta, n, scale, B, nsplit);
-            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dq, cq, nsplit);
-        }
         hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, part_k, part_v, ds, n, scale, B, nsplit);
-        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dk, cq, nsplit);
+        if (DK)
+            hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dk, cq, nsplit);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cv + 255) / 256)), dim3(256), 0, stream, part_v, dv, cv, nsplit);
     }
-    if (dsp) launch_dq_from_ds(k, kmean, ds, scale, B, KC, n, dq, ds + (size_t)B * n * n, stream);
+    if (dsp) {
+        float* slabs = ds + (size_t)B * n * n;
+        launch_dq_from_ds(k, kmean, ds, scale, B, KC, n, dq, slabs, stream);
+        if (!DK) launch_dk_from_ds(q, ds, scale, B, KC, n, dk, slabs + (size_t)(dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * cq, stream);
+    }
     return hipGetLastError();
 }
 
@@ -752,10 +796,12 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
 
 size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
     size_t bytes = (align_up((size_t)B * n, 64) + align_up((size_t)B * Kc, 64)) * sizeof(float);  // D_i, mean key
-    const int nsplit = (Kc <= 128 && Kc + Vc <= 256) ? bwd_nsplit(B, n) : 1;
+    const bool fast = (Kc <= 128 && Kc + Vc <= 256) || (Kc == 256 && Vc == 128 && use_ds_path(n));
+    const int nsplit = fast ? bwd_nsplit(B, n) : 1;
     if (nsplit > 1) bytes += (size_t)nsplit * B * (Kc + Vc) * n * sizeof(float);  // partial dq|dk and dv slabs
-    if (use_ds_path(n))                                                            // dS, then the dq key-range slabs
-        bytes += ((size_t)B * n * n + (size_t)(dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * B * Kc * n) * sizeof(float);
+    if (use_ds_path(n))  // dS, then the key-range slabs of dq (and the query-range slabs of dk for Kc = 256)
+        bytes += ((size_t)B * n * n + (size_t)(Kc == 256 ? 2 : 1) * (dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * B * Kc * n) *
+                 sizeof(float);
     return align_up(bytes, 256);
 }
 
@@ -765,6 +811,8 @@ hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, 
     float* delta = static_cast<float*>(ws);
     if (Kc == 128 && Vc == 128)
         return launch_bwd_fast<128, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
+    if (Kc == 256 && Vc == 128 && use_ds_path(n))  // dk and dq both as products over the stored dS
+        return launch_bwd_fast<256, 128, false>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
     if (Kc == 256 && Vc == 128)
         return launch_bwd<256, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
     if (Kc == 64 && Vc == 64)

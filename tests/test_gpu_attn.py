@@ -52,7 +52,7 @@ def test_attn_bwd_golden(path):
 
 @pytest.mark.parametrize("B,Kc,Vc,n", [(1, 128, 128, 1), (1, 128, 128, 31), (2, 128, 128, 33), (3, 64, 64, 130),
                                        (4, 128, 128, 256), (1, 256, 128, 2048), (8, 128, 128, 1024),
-                                       (2, 128, 128, 2048)])
+                                       (2, 128, 128, 2048), (1, 256, 128, 66), (2, 256, 128, 1000)])
 def test_attn_autograd_vs_oracle(B, Kc, Vc, n):
     """cab_attention (autograd Function over the C ABI) vs the explicit-formula oracle, fp64 truth."""
     from cabinet_amd.functional import cab_attention
