@@ -156,7 +156,8 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
                     const int off = (i * 32 + acc_row(r)) * 32;  // compile-time: an immediate LDS offset
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        drow[p0 + wn * 64 + j * 32 + li] = acc[i][j][r] + ((1.f - lx[j]) * v0[j][off] + lx[j] * v1[j][off]);
+                        __builtin_nontemporal_store(acc[i][j][r] + ((1.f - lx[j]) * v0[j][off] + lx[j] * v1[j][off]),
+                                                    drow + p0 + wn * 64 + j * 32 + li);  // streamed: read back a kernel later
                 }
             }
             return;  // INTERIOR: every row and column of the tile exists, nothing left to store
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p = p0 + wn * 64 + j * 32 + li;
-                if (p < P) drow[p] = acc[i][j][r];
+                if (p < P) __builtin_nontemporal_store(acc[i][j][r], drow + p);  // streamed output (2 % on the big products)
             }
         }
     }
