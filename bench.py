@@ -26,22 +26,22 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # MIOpen user find-db / kernel cache recorded on an MI355X for this workload's convolution problems
 # (stock PyTorch-ROCm backbone).  Without it the first step on a fresh box spends ~75 s in MIOpen's
-# solver search; results are identical either way.
+# solver search; results are identical either way.  The committed copy is READ-ONLY: every process works on a private
+# copy in a fresh temporary directory (MIOpen appends to its user db), removed at exit.
 _MIOPEN_DB = os.path.join(ROOT, "cabinet_amd", "miopen_db")
 if os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
-    _db = _MIOPEN_DB
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or not os.access(_MIOPEN_DB, os.W_OK):
-        # one private copy per rank: 8 processes appending to one sqlite/text db is asking for lock contention
-        import shutil
-        import tempfile
-        _db = os.path.join(tempfile.gettempdir(), f"cabinet_miopen_db_{os.getuid()}_{os.environ.get('LOCAL_RANK', '0')}")
-        try:
-            shutil.copytree(_MIOPEN_DB, _db, dirs_exist_ok=True)
-        except OSError:
-            _db = None
-    if _db:
+    import atexit
+    import shutil
+    import tempfile
+    try:
+        _tmp = tempfile.mkdtemp(prefix="cabinet_miopen_")
+        _db = os.path.join(_tmp, "db")
+        shutil.copytree(_MIOPEN_DB, _db)
+        atexit.register(shutil.rmtree, _tmp, ignore_errors=True)
         os.environ["MIOPEN_USER_DB_PATH"] = _db
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_db, "cache"))
+    except OSError:
+        pass
 
 import torch  # noqa: E402
 
