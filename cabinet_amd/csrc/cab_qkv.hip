@@ -14,8 +14,8 @@
 // four full-resolution pyramid maps are never formed; the pyramid terms are (Kc x Kc) x (Kc x s^2) products on
 // the pooled bins (110 positions for sizes 1,3,6,8), done as ONE GEMM per branch over a block-expanded
 // operand, and come back as a 4-tap gather from LDS.  The three projections share one GEMM (stacked weights).
-//   fwd : G(x -> zq|zk|vv) as one 3-job launch, BN row statistics, BN finalize, plane pass (BN+ReLU, q, kk, pooled bins),
-//         G(pooled -> T_k, T_v) + G(kk -> k, vv -> v) as one 4-job launch, pyramid add              = 6 launches
+//   fwd : G(x -> zq|zk|vv) as one 3-job launch, BN statistics + finalize (one launch), plane pass (BN+ReLU, q, kk, pooled bins),
+//         G(pooled -> T_k, T_v) + G(kk -> k, vv -> v) as one 4-job launch, pyramid add              = 5 launches
 //   bwd : the adjoint chain in 7 launches, all deterministic (no atomics)
 // GEMMs are the job-batched exact-fp32 MFMA kernels of small_gemm.hip (64x64 tiles: the batch has only 8192 positions).
 #include "cab_qkv.hpp"
@@ -433,34 +433,78 @@ const char* qkv_unsupported(const QkvShape& s) {
     return nullptr;
 }
 
-// BN finalize for both projections in one launch: channels [0,Kc) -> query BN buffers, [Kc,2Kc) -> key BN buffers
-__global__ __launch_bounds__(64) void qk_bn_finalize_kernel(const double* __restrict__ stat_part, int B, int Kc, long long count,
-                                                            int training, float momentum, float eps, float* __restrict__ q_rm,
-                                                            float* __restrict__ q_rv, float* __restrict__ k_rm,
-                                                            float* __restrict__ k_rv, float* __restrict__ save_mean,
-                                                            float* __restrict__ save_invstd) {
-    const int c = blockIdx.x * 64 + threadIdx.x, C2 = 2 * Kc;
-    if (c >= C2) return;
+// BatchNorm statistics AND finalize of both projections in ONE launch: a workgroup per channel (channels [0,Kc) -> query BN
+// buffers, [Kc,2Kc) -> key BN buffers) walks the channel's B planes with QS_T threads (every thread's loads are independent:
+// one round trip for B*P = 8192 values), accumulates sum and sum of squares in double, and its first thread writes
+// save_mean / save_invstd and updates the running buffers.  It replaces the (b, c)-row pass + per-channel finalize pair:
+// one launch boundary and one dependent small kernel less on a chain whose every link is latency-bound.
+constexpr int QS_T = 512;
+__global__ __launch_bounds__(QS_T) void qk_bn_stats_kernel(const float* __restrict__ zqk, int B, int Kc, int P, int training,
+                                                           float momentum, float eps, float* __restrict__ q_rm,
+                                                           float* __restrict__ q_rv, float* __restrict__ k_rm,
+                                                           float* __restrict__ k_rv, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd) {
+    __shared__ double s_red[2][QS_T / 64];
+    const int c = blockIdx.x, C2 = 2 * Kc, tid = threadIdx.x;
     float* rm = c < Kc ? q_rm + c : k_rm + (c - Kc);
     float* rv = c < Kc ? q_rv + c : k_rv + (c - Kc);
     if (!training) {
-        save_mean[c] = *rm;
-        save_invstd[c] = 1.0f / sqrtf(*rv + eps);
+        if (tid == 0) {
+            save_mean[c] = *rm;
+            save_invstd[c] = 1.0f / sqrtf(*rv + eps);
+        }
         return;
     }
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < B; ++b) {
-        s1 += stat_part[(size_t)c * B + b];
-        s2 += stat_part[((size_t)C2 + c) * B + b];
+    if ((P & 3) == 0) {
+        const int P4 = P >> 2, total = B * P4;  // float4 slots of the channel over all images
+        for (int i0 = tid; i0 < total; i0 += 4 * QS_T) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per thread
+                const int i = min(i0 + u * QS_T, total - 1), b = i / P4, p4 = i - b * P4;
+                v[u] = *reinterpret_cast<const f32x4*>(zqk + ((size_t)b * C2 + c) * P + (size_t)p4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * QS_T < total) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double d = (double)v[u][e];
+                        s1 += d, s2 = fma(d, d, s2);
+                    }
+                }
+        }
+    } else {
+        for (int b = 0; b < B; ++b) {
+            const float* row = zqk + ((size_t)b * C2 + c) * P;
+            for (int p = tid; p < P; p += QS_T) {
+                const double d = (double)row[p];
+                s1 += d, s2 = fma(d, d, s2);
+            }
+        }
     }
-    const double mean = s1 / (double)count;
-    double var = s2 / (double)count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    const double unbiased = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
-    *rm = (float)((1.0 - (double)momentum) * (double)*rm + (double)momentum * mean);
-    *rv = (float)((1.0 - (double)momentum) * (double)*rv + (double)momentum * unbiased);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((tid & 63) == 0) s_red[0][tid >> 6] = s1, s_red[1][tid >> 6] = s2;
+    __syncthreads();
+    if (tid == 0) {
+        s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < QS_T / 64; ++w) s1 += s_red[0][w], s2 += s_red[1][w];
+        const double count = (double)B * (double)P;
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        save_mean[c] = (float)mean;
+        save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        *rm = (float)((1.0 - (double)momentum) * (double)*rm + (double)momentum * mean);
+        *rv = (float)((1.0 - (double)momentum) * (double)*rv + (double)momentum * unbiased);
+    }
 }
 
 struct FwdWs {
@@ -489,7 +533,7 @@ static SgJob sg_job(const float* a, int lda, int a_mmajor, const float* b, int k
     return sg_make(a, lda, a_mmajor, b, k, b_rows, M, P, dst, dst_rows);
 }
 
-// forward: 6 launches (was 11): [zq|zk|vv] GEMMs (one launch, weights read as stored), BN row statistics, BN finalize,
+// forward: 5 launches (was 11): [zq|zk|vv] GEMMs (one launch, weights read as stored), BN statistics + finalize,
 // plane pass (BN + ReLU, q, kk, pooled bins), [T_k, T_v, W0 kk, W0 vv] GEMMs (one launch), pyramid add
 hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, int training, float momentum, float eps,
                        const QkvSaved& sv, float* q, float* k, float* v, void* ws, hipStream_t stream) {
@@ -506,11 +550,8 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
         jobs.j[2] = sg_job(w.wv, s.C, 1, x, s.C, s.C, s.Vc, P, sv.vv, s.Vc);
         sg_gemm(jobs, s.B, stream);
     }
-    double* stat = reinterpret_cast<double*>(base + L.stat);
-    if (training) bn_rowstats(sv.zqk, stat, s.B, 2 * s.Kc, P, stream);
-    hipLaunchKernelGGL(qk_bn_finalize_kernel, dim3(ceil_div(2 * s.Kc, 64)), dim3(64), 0, stream, stat, s.B, s.Kc,
-                       (long long)s.B * P, training, momentum, eps, w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean,
-                       sv.invstd);
+    hipLaunchKernelGGL(qk_bn_stats_kernel, dim3(2 * s.Kc), dim3(QS_T), 0, stream, sv.zqk, s.B, s.Kc, P, training, momentum, eps,
+                       w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean, sv.invstd);
     hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
                        sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);
     {   // k, v = W_p[:, :Kc] . kk | vv (pyramid terms added below);  T_i = W_p[:, block i] . pooled_i on the bins of size i:
