@@ -155,7 +155,7 @@ def kernel_cases(batch, size):
     ctx, lse = Fh.attn_fwd_hip(q, k, v, scale)
     yield ("cab_attn_fwd (K1: affinity+softmax+aggregate)", lambda: Fh.attn_fwd_hip(q, k, v, scale), 2.0 * B * n * n * (Kc + Vc),
           4.0 * B * n * (2 * Kc + 2 * Vc) + 4.0 * B * n, "mfma")
-    yield ("cab_attn_bwd (K2: dq + dk/dv, S recomputed)", lambda: Fh.attn_bwd_hip(dctx, q, k, v, ctx, lse, scale), 2.0 * B * n * n * (3 * Kc + 2 * Vc),
+    yield ("cab_attn_bwd (K2: dk/dv + stored dS, dq = dS (K - mean K) as a small GEMM)", lambda: Fh.attn_bwd_hip(dctx, q, k, v, ctx, lse, scale), 2.0 * B * n * n * (3 * Kc + 2 * Vc),
           4.0 * B * n * (3 * Kc + 3 * Vc) * 2 + 8.0 * B * n, "mfma")
 
     Cs, Cc, Co, Cm = 128, 256, 256, 64
