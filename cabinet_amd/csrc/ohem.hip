@@ -20,7 +20,10 @@ namespace cabinet {
 
 // One workgroup per output row (b, oy).  The two source rows are lerped vertically into LDS once (coalesced
 // reads), so a pixel's C logits cost 2 LDS reads each instead of 4 scattered global loads.
-template <int CMAX>  // classes rounded up: the per-class loops are fully unrolled and predicated on c < C
+// CMAX: classes rounded up, the per-class loops are fully unrolled.  EXACT (C == CMAX: 8 and 19 classes have their own
+// instances) drops the `c < C` predicates: with a run-time C the compiler turns every class into its own uniform branch
+// (LDS read -> wait -> arithmetic, one class at a time); without them the 2 C LDS reads of a pixel are in flight together.
+template <int CMAX, bool EXACT>
 __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
                                                            int C, int Hl, int Wl, int H, int W, float rh, float rw,
                                                            float thresh, int ignore_lb, float* __restrict__ loss_px,
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
             float x[CMAX], mx = -INFINITY, xl = 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) {
+                if (EXACT || c < C) {
                     x[c] = (1.f - lx) * v[c * Wl + x0] + lx * v[c * Wl + x1];
                     mx = fmaxf(mx, x[c]);
                     if (c == (int)lb) xl = x[c];
@@ -61,8 +64,8 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
             float se = 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) se += expf(x[c] - mx);
-            loss = mx + logf(se) - xl;
+                if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);  // v_exp_f32: arguments <= 0, 1 ulp
+            loss = mx + fast_log2(se) * LN2_F - xl;
             // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): poison this
             // block's valid count so the caller's one host read sees it (a row holds far fewer than 2^20 pixels)
             my_valid += (lb < 0 || lb >= (long long)C) ? -(1 << 20) : 1;
@@ -98,19 +101,32 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
 // T[b][c][oy][xs] = sum_ox wx(ox, xs) * G_c(oy, ox),   G = coef * sel * (softmax - onehot)
 // One workgroup per (segment of SX source columns, output row): G of the output pixels the segment touches is
 // computed ONCE into LDS (one pixel per thread and pass), then every (c, xs) gathers its <= ~2/rw+2 terms.
-template <int CMAX>
-__global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
+// threads per workgroup of the x pass.  A 64-column segment touches ~540 output pixels and owns 512 (class, column) outputs,
+// so 256 threads leave a nearly empty third G pass -- yet 256 measured best (128: 189, 192: 162, 256: 147, 320: 163, 384: 174,
+// 512: 160, 576: 173 us): the kernel is bound by the latency of its dependent phases, and residency (7 workgroups per CU by
+// LDS) hides more of it than lane utilisation wins back.
+constexpr int OBX_T = 256;
+// FR > 0: W == FR * Wl with FR even and a power of two (the model's x8), known at compile time.  Then
+//   * the staged pixel window starts at ox_lo = FR xs0 - 3 FR / 2 (pixels outside the image are zeros in G), so the 2 FR
+//     pixels that column xs receives from are exactly the de-interleaved rows (phase d, group rel + 1) and (d, rel + 2):
+//     16 LDS reads at fixed phases and 16 FMAs with the closed-form triangle (d + 1/2)/FR, 1 - (d + 1/2)/FR (weight 1 where
+//     the clamped source index folds the window of the first / last column) -- no tap evaluation, no phase bookkeeping;
+//   * every i / FR, i % FR is a shift or a mask.
+// FR == 0 is the general resize ratio (taps evaluated per term).
+template <int CMAX, bool EXACT, int FR>
+__global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
                                                              const float* __restrict__ loss_px, int C, int Hl, int Wl,
                                                              int H, int W, float rh, float rw, float thresh,
-                                                             int ignore_lb, float coef, int SX, int nox_max, int R,
+                                                             int ignore_lb, float coef, int SX, int nox_max, int R_,
                                                              int gplane, float* __restrict__ T) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int R = FR ? FR : R_;
     const int b = blockIdx.z, oy = blockIdx.y, xs0 = blockIdx.x * SX, P = H * W;
     const int nxs = min(SX, Wl - xs0);
     // output pixels whose taps can touch [xs0, xs0 + nxs)
-    const int ox_lo = max(0, (int)floorf(((float)xs0 - 0.5f) / rw - 0.5f) - 1);
+    const int ox_lo = FR ? FR * xs0 - 3 * (FR / 2) : max(0, (int)floorf(((float)xs0 - 0.5f) / rw - 0.5f) - 1);
     const int ox_hi = min(W - 1, (int)ceilf(((float)(xs0 + nxs - 1) + 1.5f) / rw - 0.5f) + 1);
-    const int nox = min(ox_hi - ox_lo + 1, nox_max);
+    const int nox = FR ? min(FR * (nxs + 3), nox_max) : min(ox_hi - ox_lo + 1, nox_max);
     const int vx0 = max(xs0 - 2, 0), nvx = min(xs0 + nxs + 2, Wl) - vx0;  // staged source columns
     float* v = smem;                      // [C][SX + 4]
     // G[c] is stored de-interleaved by R = round(W / Wl): pixel i sits at (i % R) * gplane + i / R.  The gather
@@ -123,64 +139,86 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restr
     int y0, y1;
     float ly;
     bilinear_taps(oy, rh, Hl, y0, y1, ly);
-    for (int i = threadIdx.x; i < C * nvx; i += 256) {
-        const int c = i / nvx, q = i - c * nvx;
-        const float* p = low_b + (size_t)c * plane;
-        v[c * (SX + 4) + q] = (1.f - ly) * p[y0 * Wl + vx0 + q] + ly * p[y1 * Wl + vx0 + q];
+    {
+        const float inv_nvx = 1.f / (float)nvx;  // i / nvx for i < C * nvx <= a few thousand: exact via the reciprocal
+        for (int i = threadIdx.x; i < C * nvx; i += OBX_T) {
+            int c = (int)(((float)i + 0.5f) * inv_nvx);
+            const int q = i - c * nvx;
+            const float* p = low_b + (size_t)c * plane;
+            v[c * (SX + 4) + q] = (1.f - ly) * p[y0 * Wl + vx0 + q] + ly * p[y1 * Wl + vx0 + q];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nox; i += 256) {
+    for (int i = threadIdx.x; i < nox; i += OBX_T) {
         const int ox = ox_lo + i;
-        int x0, x1;
-        float lx;
-        bilinear_taps(ox, rw, Wl, x0, x1, lx);
-        const int gi = (i % R) * gplane + i / R;
-        const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
-        const long long lb = labels[pix];
-        const bool sel = lb != (long long)ignore_lb && loss_px[pix] > thresh;
+        const int gi = FR ? (i & (FR - 1)) * gplane + i / (FR ? FR : 1) : (i % R) * gplane + i / R;
+        const bool inimg = !FR || (ox >= 0 && ox < W);
+        int x0 = 0, x1 = 0;
+        float lx = 0.f;
+        bool sel = false;
+        long long lb = 0;
+        if (inimg) {
+            bilinear_taps(ox, rw, Wl, x0, x1, lx);
+            const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
+            lb = labels[pix];
+            sel = lb != (long long)ignore_lb && loss_px[pix] > thresh;
+        }
         // taps outside the staged window belong to a pixel no column of this segment receives from
         const bool inwin = x0 >= vx0 && x1 < vx0 + nvx;
         if (sel && inwin) {
             float x[CMAX], mx = -INFINITY;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) {
+                if (EXACT || c < C) {
                     x[c] = (1.f - lx) * v[c * (SX + 4) + x0 - vx0] + lx * v[c * (SX + 4) + x1 - vx0];
                     mx = fmaxf(mx, x[c]);
                 }
             float se = 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) {
-                    x[c] = expf(x[c] - mx);
+                if (EXACT || c < C) {
+                    x[c] = fast_exp2((x[c] - mx) * LOG2E_F);
                     se += x[c];
                 }
-            const float inv = coef / se;
+            const float inv = coef * __builtin_amdgcn_rcpf(se);  // se in [1, C]
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) G[c * gsize + gi] = x[c] * inv - (c == (int)lb ? coef : 0.f);
+                if (EXACT || c < C) G[c * gsize + gi] = x[c] * inv - (c == (int)lb ? coef : 0.f);
         } else {
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) G[c * gsize + gi] = 0.f;
+                if (EXACT || c < C) G[c * gsize + gi] = 0.f;
         }
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < C * nxs; it += 256) {
-        const int c = it / nxs, xs = xs0 + (it - c * nxs);
-        const int lo = max(ox_lo, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1) - ox_lo;
-        const int hi = min(ox_hi, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1) - ox_lo;
+    const float inv_nxs = 1.f / (float)nxs;
+    for (int it = threadIdx.x; it < C * nxs; it += OBX_T) {
+        const int c = (int)(((float)it + 0.5f) * inv_nxs), rel = it - c * nxs, xs = xs0 + rel;
         float acc = 0.f;
-        int ph = lo % R, q = lo / R;  // de-interleaved position of pixel i, advanced incrementally
         const float* Gc = G + c * gsize;
-        for (int i = lo; i <= min(hi, nox - 1); ++i) {
-            int x0, x1;
-            float lx;
-            bilinear_taps(ox_lo + i, rw, Wl, x0, x1, lx);
-            // (x1 == x0 at the clamped right edge: both taps are the same column, weight 1 in total)
-            const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
-            acc = fmaf(wx, Gc[ph * gplane + q], acc);
-            if (++ph == R) ph = 0, ++q;
+        if (FR) {
+            const float* g1 = Gc + rel + 1;  // phase d of the column's first FR pixels; its last FR pixels are one group on
+            const bool first = xs == 0, last = xs == Wl - 1;
+#pragma unroll
+            for (int d = 0; d < (FR ? FR : 1); ++d) {
+                const float t = ((float)d + 0.5f) / (float)(FR ? FR : 1);
+                const float w1 = first ? 1.f : t, w2 = last ? 1.f : 1.f - t;
+                acc = fmaf(w1, g1[d * gplane], acc);
+                acc = fmaf(w2, g1[d * gplane + 1], acc);
+            }
+        } else {
+            const int lo = max(ox_lo, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1) - ox_lo;
+            const int hi = min(ox_hi, (int)ceilf(((float)xs + 1.5f) / rw - 0.5f) + 1) - ox_lo;
+            int ph = lo % R, q = lo / R;  // de-interleaved position of pixel i, advanced incrementally
+            for (int i = lo; i <= min(hi, nox - 1); ++i) {
+                int x0, x1;
+                float lx;
+                bilinear_taps(ox_lo + i, rw, Wl, x0, x1, lx);
+                // (x1 == x0 at the clamped right edge: both taps are the same column, weight 1 in total)
+                const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+                acc = fmaf(wx, Gc[ph * gplane + q], acc);
+                if (++ph == R) ph = 0, ++q;
+            }
         }
         T[(((size_t)b * C + c) * H + oy) * Wl + xs] = acc;
     }
@@ -188,10 +226,24 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x_kernel(const float* __restr
 
 // dlow[b][c][ys][xs] = sum_oy wy(oy, ys) * T[b][c][oy][xs]
 __global__ __launch_bounds__(256) void ohem_up_bwd_y_kernel(const float* __restrict__ T, int planes, int Hl, int Wl, int H,
-                                                             float rh, float* __restrict__ dlow) {
+                                                             float rh, int fastR, float* __restrict__ dlow) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= planes * Hl * Wl) return;
     const int xs = idx % Wl, ys = (idx / Wl) % Hl, pl = idx / (Wl * Hl);
+    if (fastR) {  // H == fastR * Hl, fastR even: the same triangle as in the x pass
+        const int w0 = fastR * ys - (fastR >> 1), lo = max(w0, 0), hi = min(w0 + 2 * fastR - 1, H - 1);
+        const float invR = 1.f / (float)fastR;
+        const float* src = T + (size_t)pl * H * Wl + xs;
+        float acc = 0.f;
+        for (int oy = lo; oy <= hi; ++oy) {
+            const int d = oy - w0;
+            float wy = d < fastR ? ((float)d + 0.5f) * invR : 1.f - ((float)(d - fastR) + 0.5f) * invR;
+            if ((ys == 0 && d < fastR) || (ys == Hl - 1 && d >= fastR)) wy = 1.f;
+            acc = fmaf(wy, src[(size_t)oy * Wl], acc);
+        }
+        dlow[idx] = acc;
+        return;
+    }
     const int oy_lo = max(0, (int)floorf(((float)ys - 0.5f) / rh - 0.5f) - 1);
     const int oy_hi = min(H - 1, (int)ceilf(((float)ys + 1.5f) / rh - 0.5f) + 1);
     const float* src = T + (size_t)pl * H * Wl + xs;
@@ -210,14 +262,16 @@ int ohem_blocks(int B, int H, int W) { (void)W; return B * H; }  // one partial 
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
                            float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
                            hipStream_t stream) {
-#define OHEM_FWD(CM)                                                                                                   \
-    hipLaunchKernelGGL(ohem_up_fwd_kernel<CM>, dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float), stream, low, labels, \
-                       C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, loss_px, blk_sum,  \
-                       blk_cnt)
-    if (C <= 8) OHEM_FWD(8);
-    else if (C <= 16) OHEM_FWD(16);
-    else if (C <= 20) OHEM_FWD(20);
-    else OHEM_FWD(32);
+#define OHEM_FWD(CM, EX)                                                                                                \
+    hipLaunchKernelGGL((ohem_up_fwd_kernel<CM, EX>), dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float), stream, low,   \
+                       labels, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, loss_px,     \
+                       blk_sum, blk_cnt)
+    if (C == 8) OHEM_FWD(8, true);
+    else if (C == 19) OHEM_FWD(19, true);
+    else if (C < 8) OHEM_FWD(8, false);
+    else if (C <= 16) OHEM_FWD(16, false);
+    else if (C <= 20) OHEM_FWD(20, false);
+    else OHEM_FWD(32, false);
 #undef OHEM_FWD
     return hipGetLastError();
 }
@@ -253,17 +307,28 @@ hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const floa
     int SX, nox_max, R, gplane;
     size_t lds;
     ohem_segment(C, Wl, W, SX, nox_max, R, gplane, lds);
-#define OHEM_BWD(CM)                                                                                                     \
-    hipLaunchKernelGGL(ohem_up_bwd_x_kernel<CM>, dim3(ceil_div(Wl, SX), H, B), dim3(256), lds, stream, low, labels, loss_px, \
-                       C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, coef, SX, nox_max,   \
-                       R, gplane, T)
-    if (C <= 8) OHEM_BWD(8);
-    else if (C <= 16) OHEM_BWD(16);
-    else if (C <= 20) OHEM_BWD(20);
-    else OHEM_BWD(32);
+    const int fast_y = (Hl > 0 && H % Hl == 0 && ((H / Hl) & 1) == 0) ? H / Hl : 0;  // integer, even ratio: closed-form weights
+    const bool x8 = Wl > 0 && W == 8 * Wl && 8 * (SX + 3) <= nox_max && SX + 3 <= gplane;  // the model's x8 upsample
+#define OHEM_BWD(CM, EX)                                                                                                 \
+    do {                                                                                                                 \
+        if (x8)                                                                                                          \
+            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 8>), dim3(ceil_div(Wl, SX), H, B), dim3(OBX_T), lds, stream, \
+                               low, labels, loss_px, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, \
+                               ignore_lb, coef, SX, nox_max, R, gplane, T);                                               \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 0>), dim3(ceil_div(Wl, SX), H, B), dim3(OBX_T), lds, stream, \
+                               low, labels, loss_px, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, \
+                               ignore_lb, coef, SX, nox_max, R, gplane, T);                                               \
+    } while (0)
+    if (C == 8) OHEM_BWD(8, true);
+    else if (C == 19) OHEM_BWD(19, true);
+    else if (C < 8) OHEM_BWD(8, false);
+    else if (C <= 16) OHEM_BWD(16, false);
+    else if (C <= 20) OHEM_BWD(20, false);
+    else OHEM_BWD(32, false);
 #undef OHEM_BWD
     hipLaunchKernelGGL(ohem_up_bwd_y_kernel, dim3(ceil_div(B * C * Hl * Wl, 256)), dim3(256), 0, stream, T, B * C, Hl, Wl,
-                       H, (float)Hl / (float)H, dlow);
+                       H, (float)Hl / (float)H, fast_y, dlow);
     return hipGetLastError();
 }
 

@@ -20,6 +20,9 @@ TOL = 1e-3
     (1, 8, 8, 8, 64, 64, 0.0, 1.5, 64 * 64 // 16),                # higher threshold (fewer selected)
     (1, 8, 8, 8, 64, 64, 0.0, 50.0, 64 * 64 // 16),               # nothing above thresh -> composite top-k branch
     (1, 8, 8, 8, 64, 64, 1.0, 0.7, 10),                           # everything ignored -> 0 with grad
+    (1, 8, 16, 24, 64, 96, 0.1, 0.7, 64 * 96 // 16),              # x4: closed-form rows, general column pass
+    (2, 5, 10, 6, 20, 48, 0.0, 0.7, 2 * 20 * 48 // 16),           # x2 rows, x8 columns, 5 classes (predicated bucket of 8)
+    (1, 19, 16, 136, 128, 1088, 0.1, 0.7, 128 * 1088 // 16),      # x8, three column segments (64 + 64 + 8), 19 classes
 ])
 def test_fused_ohem_vs_oracle(B, C, Hl, Wl, H, W, ignore_frac, thresh, n_min):
     from cabinet_amd.loss import OhemCELoss

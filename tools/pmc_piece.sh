@@ -1,8 +1,12 @@
 #!/bin/bash
 # counters of ONE piece's kernels: bash tools/pmc_piece.sh <piece> "<counters>"   (counters only, no tracing domain)
+# <piece> is a piece of tools/trace_piece.py, or "group:<name>" for a bench.py kernel group (tools/run_kernels.py)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcp
-rocprofv3 --pmc $2 --output-format csv -d /tmp/pmcp -- python3 $GRAFT_REPO_ROOT/tools/trace_piece.py $1 4 > /tmp/pmcp.log 2>&1
+case "$1" in
+  group:*) rocprofv3 --pmc $2 --output-format csv -d /tmp/pmcp -- python3 $GRAFT_REPO_ROOT/tools/run_kernels.py 4 ${1#group:} > /tmp/pmcp.log 2>&1 ;;
+  *) rocprofv3 --pmc $2 --output-format csv -d /tmp/pmcp -- python3 $GRAFT_REPO_ROOT/tools/trace_piece.py $1 4 > /tmp/pmcp.log 2>&1 ;;
+esac
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob('/tmp/pmcp/**/*counter_collection.csv', recursive=True)
