@@ -12,6 +12,8 @@
 //           T[b][c][oy][xs] = sum_ox wx(ox,xs) G[b][c][oy][ox]    (G recomputed on the fly, never stored)
 //           dlow[b][c][ys][xs] = sum_oy wy(oy,ys) T[b][c][oy][xs]
 //         no atomics -> bitwise reproducible (PyTorch's own upsample backward uses atomicAdd).
+#include <stdint.h>
+
 #include "common.hpp"
 
 namespace cabinet {
@@ -95,6 +97,107 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
         const int nv = s_i[0][0] + s_i[0][1] + s_i[0][2] + s_i[0][3];
         blk_cnt[2 * blk] = nv < 0 ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
         blk_cnt[2 * blk + 1] = s_i[1][0] + s_i[1][1] + s_i[1][2] + s_i[1][3];
+    }
+}
+
+// The model's x8 resize (W == 8 Wl): a thread owns the eight output pixels [8g, 8g+8) of its row.  They read only the source
+// columns g-1, g, g+1 (clamped at the borders, which reproduces the clamped source index of align_corners=False), so the
+// 3 C staged values are fetched once for eight pixels instead of 2 C per pixel, the interpolation weights are the
+// constants (j + 4.5)/8 and (j - 3.5)/8, and labels / losses move as 16-byte vectors.
+template <int CMAX, bool EXACT>
+__global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
+                                                              int C, int Hl, int Wl, int H, int W, float rh, float thresh,
+                                                              int ignore_lb, float* __restrict__ loss_px,
+                                                              float* __restrict__ blk_sum, int* __restrict__ blk_cnt) {
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][Wl]
+    __shared__ float s_f[4];
+    __shared__ int s_i[2][4];
+    const int b = blockIdx.y, oy = blockIdx.x, P = H * W, nt = blockDim.x;
+    const size_t plane = (size_t)Hl * Wl;
+    const float* low_b = low + (size_t)b * C * plane;
+    int y0, y1;
+    float ly;
+    bilinear_taps(oy, rh, Hl, y0, y1, ly);
+    {
+        const float inv_wl = 1.f / (float)Wl;
+        for (int i = threadIdx.x; i < C * Wl; i += nt) {
+            const int c = (int)(((float)i + 0.5f) * inv_wl), xs = i - c * Wl;
+            const float* p = low_b + (size_t)c * plane;
+            v[i] = (1.f - ly) * p[y0 * Wl + xs] + ly * p[y1 * Wl + xs];
+        }
+    }
+    __syncthreads();
+    float my_sum = 0.f;
+    int my_valid = 0, my_above = 0;
+    for (int g = threadIdx.x; g < Wl; g += nt) {
+        const size_t pix = (size_t)b * P + (size_t)oy * W + 8 * g;  // 64-byte aligned labels, 32-byte aligned losses
+        long long lb[8];
+        {
+            const longlong2* lp = reinterpret_cast<const longlong2*>(labels + pix);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const longlong2 t = lp[u];
+                lb[2 * u] = t.x, lb[2 * u + 1] = t.y;
+            }
+        }
+        float xm[CMAX], xc[CMAX], xp[CMAX];
+        const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (EXACT || c < C) xm[c] = v[c * Wl + gm], xc[c] = v[c * Wl + g], xp[c] = v[c * Wl + gp];
+        float out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+            float loss = 0.f;
+            if (lb[j] != (long long)ignore_lb) {
+                float x[CMAX], mx = -INFINITY, xl = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (EXACT || c < C) {
+                        x[c] = j < 4 ? (1.f - t) * xm[c] + t * xc[c] : (1.f - t) * xc[c] + t * xp[c];
+                        mx = fmaxf(mx, x[c]);
+                        if (c == (int)lb[j]) xl = x[c];
+                    }
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);
+                loss = mx + fast_log2(se) * LN2_F - xl;
+                my_valid += (lb[j] < 0 || lb[j] >= (long long)C) ? -(1 << 20) : 1;  // see ohem_up_fwd_kernel
+                if (loss > thresh) {
+                    my_above += 1;
+                    my_sum += loss;
+                }
+            }
+            out[j] = loss;
+        }
+        f32x4* op = reinterpret_cast<f32x4*>(loss_px + pix);
+        op[0] = f32x4{out[0], out[1], out[2], out[3]};
+        op[1] = f32x4{out[4], out[5], out[6], out[7]};
+    }
+    // ordered block reduction
+    my_sum = wave_sum(my_sum);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        my_valid += __shfl_xor(my_valid, o, 64);
+        my_above += __shfl_xor(my_above, o, 64);
+    }
+    const int nw = (nt + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_f[threadIdx.x >> 6] = my_sum;
+        s_i[0][threadIdx.x >> 6] = my_valid;
+        s_i[1][threadIdx.x >> 6] = my_above;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        float fs = 0.f;
+        int nv = 0, na = 0;
+        for (int w = 0; w < nw; ++w) fs += s_f[w], nv += s_i[0][w], na += s_i[1][w];
+        blk_sum[blk] = fs;
+        blk_cnt[2 * blk] = nv < 0 ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
+        blk_cnt[2 * blk + 1] = na;
     }
 }
 
@@ -262,10 +365,21 @@ int ohem_blocks(int B, int H, int W) { (void)W; return B * H; }  // one partial 
 hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
                            float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
                            hipStream_t stream) {
+    // the x8 form needs 16-byte aligned label / loss rows (W % 8 == 0 holds) and one thread per source column
+    const bool x8 = Wl > 0 && W == 8 * Wl && (reinterpret_cast<uintptr_t>(labels) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(loss_px) & 15) == 0;
+    const int nt8 = Wl >= 256 ? 256 : ((Wl + 63) / 64) * 64;
 #define OHEM_FWD(CM, EX)                                                                                                \
-    hipLaunchKernelGGL((ohem_up_fwd_kernel<CM, EX>), dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float), stream, low,   \
-                       labels, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, ignore_lb, loss_px,     \
-                       blk_sum, blk_cnt)
+    do {                                                                                                                \
+        if (x8)                                                                                                         \
+            hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX>), dim3(H, B), dim3(nt8), (size_t)C * Wl * sizeof(float),  \
+                               stream, low, labels, C, Hl, Wl, H, W, (float)Hl / (float)H, thresh, ignore_lb, loss_px,  \
+                               blk_sum, blk_cnt);                                                                       \
+        else                                                                                                            \
+            hipLaunchKernelGGL((ohem_up_fwd_kernel<CM, EX>), dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float),     \
+                               stream, low, labels, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, \
+                               ignore_lb, loss_px, blk_sum, blk_cnt);                                                   \
+    } while (0)
     if (C == 8) OHEM_FWD(8, true);
     else if (C == 19) OHEM_FWD(19, true);
     else if (C < 8) OHEM_FWD(8, false);
