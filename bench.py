@@ -80,7 +80,7 @@ def time_kernel(fn, iters, warm=3, reps=5):
     if os.environ.get("CABINET_BENCH_EAGER_KERNELS") != "1":
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 for _ in range(reps):
                     fn()
             graph.replay()

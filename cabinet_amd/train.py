@@ -23,6 +23,12 @@ from .loss import OhemCELoss, ohem_upsampled_pair
 from .models.cabinet import CABiNet
 from .models.constants import DEFAULT_IGNORE_LABEL, DEFAULT_SCORE_THRESHOLD, MOBILENETV3_CFGS, OHEM_DIVISOR
 
+# hipGraph captures use the THREAD-LOCAL error mode: with a process group alive, RCCL's watchdog thread polls the events of
+# finished collectives (hipEventQuery); under the default global mode such a call from ANY thread while a capture is open
+# is an error that terminates the process ("operation not permitted when stream is capturing", seen once in nine runs of
+# tools/host_overhead.py).  Thread-local mode confines the check to the capturing thread, which is what is meant here.
+_CAPTURE_MODE = "thread_local"
+
 
 def build_model(mode="large", n_classes=8, device="cpu", seed=0, gamma=None, freeze_unused=True):
     """Random-init CABiNet (model seed as in BASELINE.md); ``gamma`` overrides CAB's zero-init scale so
@@ -137,7 +143,7 @@ class GraphedTrainStep:
         size = tuple(im.shape[2:])
         torch.cuda.synchronize()
         self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd):
+        with torch.cuda.graph(self.g_fwd, capture_error_mode=_CAPTURE_MODE):
             low, low16 = self.net.forward_lowres(self.s_im)
             self.pa = self.crit_p._fused_launch(low, self.s_lb, size)
             self.pb = self.crit_16._fused_launch(low16, self.s_lb, size)
@@ -153,7 +159,7 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: capture batch does not take the OHEM 'n_min above thresh' branch; "
                                "capture on a representative batch")
         self.g_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), capture_error_mode=_CAPTURE_MODE):
             loss = self.crit_p._fused_finish(self.pa, host[0]) + self.crit_16._fused_finish(self.pb, host[1])
             loss.backward()
             if self.optimizer is not None:
@@ -336,7 +342,7 @@ class GraphedDDPStep:
         self.backup = [b.clone() for b in self.buffers]
         torch.cuda.synchronize()
         gA, gB1, gB2, gC = (torch.cuda.CUDAGraph() for _ in range(4))
-        with torch.cuda.graph(gA):
+        with torch.cuda.graph(gA, capture_error_mode=_CAPTURE_MODE):
             self._zero()
             self.fused, _, self.boundary = self._forward(self.s_im, self.s_lb)
             if self.fused is None:
@@ -348,14 +354,14 @@ class GraphedDDPStep:
         torch._foreach_copy_(self.buffers, self.backup)
         if not all(GraphedTrainStep._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
             raise RuntimeError("GraphedDDPStep: capture batch does not take the OHEM 'n_min above thresh' branch")
-        with torch.cuda.graph(gB1, pool=gA.pool()):
+        with torch.cuda.graph(gB1, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
             loss = self.crit_p._fused_finish(self.fused[0], host[0]) + self.crit_16._fused_finish(self.fused[1], host[1])
             self._backward_decoder(loss, self.boundary)
             self.s_loss = loss.detach()
-        with torch.cuda.graph(gB2, pool=gA.pool()):
+        with torch.cuda.graph(gB2, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
             self._backward_encoders(self.boundary)
         if self.optimizer is not None:
-            with torch.cuda.graph(gC, pool=gA.pool()):
+            with torch.cuda.graph(gC, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
                 self.optimizer.step()
         else:
             gC = None

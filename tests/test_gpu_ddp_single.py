@@ -88,3 +88,35 @@ def test_graphed_ddp_step_world1_matches_graphed_single():
             assert err <= 2e-3 * den + 1e-5 * sa[k].numel() ** 0.5, (k, err, den)
     finally:
         dist.destroy_process_group()
+
+
+def test_graph_capture_with_live_rccl_watchdog():
+    """RCCL's watchdog thread polls the events of finished collectives; under torch's default (global) capture error mode
+    such a hipEventQuery while ANY capture is open terminates the process ("operation not permitted when stream is
+    capturing" -- tools/stress_capture_with_pg.py global reproduces it within a few captures).  Every capture of this
+    package uses cabinet_amd.train._CAPTURE_MODE; 100 captures with collectives in flight before each must survive."""
+    from cabinet_amd.train import _CAPTURE_MODE
+
+    assert _CAPTURE_MODE == "thread_local"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if dist.is_initialized():
+        pytest.skip("process group already active")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0,
+                            device_id=torch.device("cuda", 0))
+    try:
+        x = torch.randn(1 << 18, device="cuda")
+        y = torch.zeros(1 << 10, device="cuda")
+        for _ in range(100):
+            for _ in range(8):
+                dist.all_reduce(x, async_op=True)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                for _ in range(20):
+                    y.add_(1.0)
+            g.replay()
+        torch.cuda.synchronize()
+        assert float(y[0]) == 100 * 20  # a capture records, only the replay executes
+    finally:
+        dist.destroy_process_group()
