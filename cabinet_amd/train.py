@@ -212,17 +212,21 @@ class GraphedDDPStep:
     the node's host cores.  Here the step is cut where the model cuts itself: the decoder (``conv_out, ffm, ab``: 23 MB of
     gradients) is back-propagated first, the encoders (``mobile, sb``: 13 MB, two thirds of the backward time) second:
 
-        graph A    zero the gradient buckets, forward, OHEM forward kernels + statistics
+        graph A    forward, OHEM forward kernels + statistics
         host       one read-back (OHEM branch), as in GraphedTrainStep
-        graph B1   loss, backward of the decoder down to the two boundary tensors (sb output, mobile output)
+        graph B1   loss, backward of the decoder down to the two boundary tensors (sb output, mobile output), gradients packed
+                   into the decoder's flat buckets (one multi-tensor copy)
         RCCL       all-reduce(AVG) of the decoder buckets, asynchronous on RCCL's stream        <- overlaps graph B2
-        graph B2   backward of the encoders from the boundary gradients
+        graph B2   backward of the encoders from the boundary gradients, packed into the encoder buckets
         RCCL       all-reduce of the encoder buckets (the only exposed communication: 13 MB over xGMI), join
         graph C    optimizer step
 
     Collectives are ordinary eager calls between replays (nothing of RCCL is captured), always the same buckets in the
     same order on every rank, also on a rank that falls back to the eager path for this step (rare OHEM branch).
-    Gradients are views into flat fp32 buckets (no copy in or out); BatchNorm statistics and OHEM stay per rank.
+    Autograd writes each gradient into its own tensor (``.grad`` is None during backward, so nothing is accumulated); one
+    ``torch._foreach_copy_`` per segment packs them into the flat fp32 buckets, and ``.grad`` then IS the bucket view the
+    all-reduce averages and the optimizer reads.  (Pre-zeroed bucket views as ``.grad`` made autograd run one in-place add
+    per parameter: ~180 extra launches per step.)  BatchNorm statistics and OHEM stay per rank.
     ``use_graphs=False`` (default on CPU tensors) runs the identical schedule eagerly -- that is what the gloo tests drive."""
 
     DECODER = ("conv_out", "ffm", "ab")
@@ -249,18 +253,21 @@ class GraphedDDPStep:
                     (dec if name in self.DECODER else enc).append(p)
         self.dec_params = dec
         cap = int(bucket_mb * 2 ** 20)
-        self.segments = []
+        self.segments, self.seg_views = [], []
         for params in (list(reversed(dec)), list(reversed(enc))):  # ~ gradient arrival order inside each half
             flats = []
+            views = []
             for plan in plan_buckets([p.numel() * 4 for p in params], cap, cap, 2 ** 18):
                 group = [params[i] for i in plan]
                 flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=dev)
                 off = 0
                 for p in group:
-                    p.grad = flat[off:off + p.numel()].view_as(p)
+                    views.append((p, flat[off:off + p.numel()].view_as(p)))
+                    p.grad = views[-1][1]
                     off += p.numel()
                 flats.append(flat)
             self.segments.append(flats)
+            self.seg_views.append(views)
         if broadcast_parameters and self.world > 1:
             with torch.no_grad():
                 for t in list(net.parameters()) + list(net.buffers()):
@@ -269,10 +276,26 @@ class GraphedDDPStep:
         self.fallbacks = self._calls = 0
 
     # ---- the pieces of one step (run eagerly, or recorded once and replayed) ----
-    def _zero(self):
-        for flats in self.segments:
-            for f in flats:
-                f.zero_()
+    def _clear(self):
+        """``.grad = None`` on every parameter: autograd then stores each gradient instead of adding it to a zeroed view."""
+        for views in self.seg_views:
+            for p, _ in views:
+                p.grad = None
+
+    def _pack(self, seg):
+        """Gradients of one segment -> its flat buckets (one multi-tensor copy); ``.grad`` becomes the bucket view.
+        A parameter autograd did not reach (or a loss that does not depend on the network) contributes zeros."""
+        dst, src = [], []
+        for p, view in self.seg_views[seg]:
+            g = p.grad
+            if g is None:
+                view.zero_()
+            elif g is not view:
+                dst.append(view)
+                src.append(g)
+            p.grad = view
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def _forward(self, im, lb):
         """-> (fused preps | None, loss | None, boundary tensors)"""
@@ -321,15 +344,17 @@ class GraphedDDPStep:
                 f.div_(self.world)
 
     def _eager_step(self, im, lb):
-        self._zero()
+        self._clear()
         fused, loss, boundary = self._forward(im, lb)
         if fused is not None:
             host = fused[2].tolist()
             loss = self.crit_p._fused_finish(fused[0], host[0]) + self.crit_16._fused_finish(fused[1], host[1])
         ran = self._backward_decoder(loss, boundary)
+        self._pack(0)
         works = self._reduce(0)
         if ran:
             self._backward_encoders(boundary)
+        self._pack(1)
         works += self._reduce(1)
         self._join(works)
         if self.optimizer is not None:
@@ -342,8 +367,8 @@ class GraphedDDPStep:
         self.backup = [b.clone() for b in self.buffers]
         torch.cuda.synchronize()
         gA, gB1, gB2, gC = (torch.cuda.CUDAGraph() for _ in range(4))
+        self._clear()
         with torch.cuda.graph(gA, capture_error_mode=_CAPTURE_MODE):
-            self._zero()
             self.fused, _, self.boundary = self._forward(self.s_im, self.s_lb)
             if self.fused is None:
                 raise RuntimeError("GraphedDDPStep with graphs needs the fused OHEM head")
@@ -357,9 +382,11 @@ class GraphedDDPStep:
         with torch.cuda.graph(gB1, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
             loss = self.crit_p._fused_finish(self.fused[0], host[0]) + self.crit_16._fused_finish(self.fused[1], host[1])
             self._backward_decoder(loss, self.boundary)
+            self._pack(0)
             self.s_loss = loss.detach()
         with torch.cuda.graph(gB2, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
             self._backward_encoders(self.boundary)
+            self._pack(1)
         if self.optimizer is not None:
             with torch.cuda.graph(gC, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
                 self.optimizer.step()
