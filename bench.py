@@ -280,8 +280,10 @@ def kernel_cases(batch, size):
 _NOTES = {
     "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
     "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
-    "cab_qkv_fwd": "6 dependent launches of <= 25 us each on 8192 positions: latency / small-tile MFMA bound",
+    "cab_qkv_fwd": "5 dependent launches of <= 21 us each on 8192 positions: latency / small-tile MFMA bound",
     "cab_qkv_bwd": "7 dependent launches on 8192 positions: latency / small-tile MFMA bound",
+    "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
+                    "and the dq key-range slabs: it replaces recomputing S and dP for dq (4.3 GFLOP)",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
     "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
     "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
