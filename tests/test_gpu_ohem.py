@@ -23,6 +23,8 @@ TOL = 1e-3
     (1, 8, 16, 24, 64, 96, 0.1, 0.7, 64 * 96 // 16),              # x4: closed-form rows, general column pass
     (2, 5, 10, 6, 20, 48, 0.0, 0.7, 2 * 20 * 48 // 16),           # x2 rows, x8 columns, 5 classes (predicated bucket of 8)
     (1, 19, 16, 136, 128, 1088, 0.1, 0.7, 128 * 1088 // 16),      # x8, three column segments (64 + 64 + 8), 19 classes
+    (1, 8, 8, 8, 48, 48, 0.0, 0.7, 48 * 48 // 16),                # x6: an even ratio whose reciprocal is inexact in fp32
+    (1, 8, 1, 1, 8, 8, 0.0, 0.7, 4),                              # one source pixel: every weight is 1 (both borders at once)
 ])
 def test_fused_ohem_vs_oracle(B, C, Hl, Wl, H, W, ignore_frac, thresh, n_min):
     from cabinet_amd.loss import OhemCELoss
