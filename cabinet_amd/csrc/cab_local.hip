@@ -74,6 +74,7 @@ __device__ __forceinline__ void wg_sum2d(double a, double b, double* red, double
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
 // ------------------------------------------------------------------------------------------ forward
+template <bool ONEPLANE>  // see cab_local_bwd_kernel
 __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.H * a.W, N = a.B * n, c = blockIdx.x, tid = threadIdx.x;
@@ -82,19 +83,24 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     float* bufB = smem + NP;
     double* red = reinterpret_cast<double*>(smem + ((2 * NP + 1) & ~1));
     float xr[LOC_EPT], v[LOC_EPT];
-    int pe[LOC_EPT];
+    int pe[ONEPLANE ? 1 : LOC_EPT];
+    const int pe0 = ONEPLANE ? (tid / a.W + 1) * WP + (tid % a.W) + 1 : 0;
+    auto PE = [&](int kk) { return ONEPLANE ? kk * PP + pe0 : pe[kk]; };
     for (int i = tid; i < 2 * NP; i += LOC_T) smem[i] = 0.f;  // pad cells stay zero for the whole kernel
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < LOC_EPT; ++k) {
         const int e = k * LOC_T + tid;
         xr[k] = 0.f;
-        pe[k] = WP + 1;
+        if (!ONEPLANE) pe[k] = WP + 1;
         if (e < N) {
-            const int b = e / n, p = e - b * n, y = p / a.W;
-            pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
+            const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
+            if (!ONEPLANE) {
+                const int y = p / a.W;
+                pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
+            }
             xr[k] = a.x[((size_t)b * a.C + c) * n + p];
-            bufA[pe[k]] = xr[k];
+            bufA[PE(k)] = xr[k];
         }
     }
     __syncthreads();
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) w[j] = a.st[s].w[c * 9 + j];
 #pragma unroll
-        for (int k = 0; k < LOC_EPT; ++k) v[k] = (k * LOC_T + tid < N) ? stencil_fwd(in, pe[k], WP, w) : 0.f;
+        for (int k = 0; k < LOC_EPT; ++k) v[k] = (k * LOC_T + tid < N) ? stencil_fwd(in, PE(k), WP, w) : 0.f;
         float mean, invstd;
         if (a.training) {  // batch statistics of this channel: one pass, sums in double (see wg_sum)
             double s1 = 0.0, s2 = 0.0;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
             __syncthreads();  // every stencil read of `in` is done (wg_sum2d syncs only in training mode)
 #pragma unroll
             for (int k = 0; k < LOC_EPT; ++k)
-                if (k * LOC_T + tid < N) ob[pe[k]] = v[k];
+                if (k * LOC_T + tid < N) ob[PE(k)] = v[k];
             __syncthreads();
             float* t = in;
             in = ob;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     for (int k = 0; k < LOC_EPT; ++k) {
         const int e = k * LOC_T + tid;
         if (e < N) {
-            const int b = e / n, p = e - b * n;
+            const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
             const size_t gi = ((size_t)b * a.C + c) * n + p;
             float o = xr[k] * (1.f + sigmoidf(v[k]));
             if (a.glob) o = fmaf(gam, a.glob[gi], o);
@@ -161,6 +167,9 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------- backward
+// ONEPLANE: H * W == LOC_T (the model's 32 x 32 map): element k of a thread is pixel `tid` of image k, so the padded LDS
+// index of every element is one per-thread constant plus k * PP -- the eight-entry index array leaves the register file.
+template <bool ONEPLANE>
 __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.H * a.W, N = a.B * n, c = blockIdx.x, tid = threadIdx.x;
@@ -172,21 +181,23 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
     double* red = reinterpret_cast<double*>(smem + ((4 * NP + 1) & ~1));  // [2][LOC_T/64] doubles, then [9][LOC_T/64] floats
     float* red9 = reinterpret_cast<float*>(red + 2 * (LOC_T / 64));
 
-    float xr[LOC_EPT], xh[3][LOC_EPT], yv[LOC_EPT], g[LOC_EPT];
-    int pe[LOC_EPT];
+    float xh[3][LOC_EPT], yv[LOC_EPT], g[LOC_EPT];  // x itself stays in bufX (LDS) only: 8 registers less per lane
+    int pe[ONEPLANE ? 1 : LOC_EPT];
+    const int pe0 = ONEPLANE ? (tid / a.W + 1) * WP + (tid % a.W) + 1 : 0;
+    auto PE = [&](int kk) { return ONEPLANE ? kk * PP + pe0 : pe[kk]; };
     for (int i = tid; i < 4 * NP; i += LOC_T) smem[i] = 0.f;  // pad cells stay zero for the whole kernel
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < LOC_EPT; ++k) {
         const int e = k * LOC_T + tid;
-        xr[k] = 0.f, pe[k] = WP + 1, g[k] = 0.f;
+        if (!ONEPLANE) pe[k] = WP + 1;
+        g[k] = 0.f;
         if (e < N) {
-            const int b = e / n, p = e - b * n, y = p / a.W;
-            pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
+            const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n, y = p / a.W;
+            if (!ONEPLANE) pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
             const size_t gi = ((size_t)b * a.C + c) * n + p;
-            xr[k] = a.x[gi];
             g[k] = a.dout[gi];
-            bufX[pe[k]] = xr[k];
+            bufX[PE(k)] = a.x[gi];
         }
     }
     __syncthreads();
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
             const float bw_s = a.st[s].bn_w[c], bb_s = a.st[s].bn_b[c];
 #pragma unroll
             for (int k = 0; k < LOC_EPT; ++k) {
-                const float z = (k * LOC_T + tid < N) ? stencil_fwd(in, pe[k], WP, w9) : 0.f;
+                const float z = (k * LOC_T + tid < N) ? stencil_fwd(in, PE(k), WP, w9) : 0.f;
                 xh[s][k] = (z - mean_s) * invstd_s;
                 yv[k] = fmaxf(fmaf(xh[s][k], bw_s, bb_s), 0.f);
                 if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 36 LDS reads in flight, not 72 (register budget)
@@ -213,14 +224,16 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
             if (s < 2) {
 #pragma unroll
                 for (int k = 0; k < LOC_EPT; ++k)
-                    if (k * LOC_T + tid < N) outs[s][pe[k]] = yv[k];
+                    if (k * LOC_T + tid < N) outs[s][PE(k)] = yv[k];
                 __syncthreads();
                 in = outs[s];
             }
         }
     }
     // ---- block output: out = gamma*glob + x*(1 + sigmoid(y3)) ----
-    float dxd[LOC_EPT], dy[LOC_EPT];
+    // the direct term of dx, g (1 + sigmoid(y3)), goes to a.dx now and the stencil term is added to it at the very end by the
+    // same thread: eight more registers that do not have to live through the three backward stages
+    float dy[LOC_EPT];
     {
         const float gam = a.glob ? a.gamma[0] : 0.f;
         float dg = 0.f;
@@ -228,13 +241,15 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
         for (int k = 0; k < LOC_EPT; ++k) {
             const int e = k * LOC_T + tid;
             const float sg = sigmoidf(yv[k]);
-            dxd[k] = g[k] * (1.f + sg);
-            dy[k] = (yv[k] > 0.f) ? g[k] * xr[k] * sg * (1.f - sg) : 0.f;  // through the ReLU of stage 3
-            if (a.glob && e < N) {
-                const int b = e / n, p = e - b * n;
+            dy[k] = (yv[k] > 0.f) ? g[k] * bufX[PE(k)] * sg * (1.f - sg) : 0.f;  // through the ReLU of stage 3
+            if (e < N) {
+                const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
                 const size_t gi = ((size_t)b * a.C + c) * n + p;
-                dg += g[k] * a.glob[gi];
-                a.dglob[gi] = gam * g[k];
+                a.dx[gi] = g[k] * (1.f + sg);
+                if (a.glob) {
+                    dg += g[k] * a.glob[gi];
+                    a.dglob[gi] = gam * g[k];
+                }
             }
         }
         if (a.glob) {
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
         for (int k = 0; k < LOC_EPT; ++k) {
             const bool ok = k * LOC_T + tid < N;
             dz[k] = ok ? gi_ * (dy[k] - m1 - xh[s][k] * m2) : 0.f;
-            if (ok) bufG[pe[k]] = dz[k];
+            if (ok) bufG[PE(k)] = dz[k];
         }
         __syncthreads();
         // weight gradient: dW[ky][kx] = sum_e dz[e] * in_s[e shifted], in_s = x, y1, y2 (zero-padded: no border tests)
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) pw[ky * 3 + kx] += dz[k] * ins[pe[k] + (ky - 1) * WP + (kx - 1)];
+                for (int kx = 0; kx < 3; ++kx) pw[ky * 3 + kx] += dz[k] * ins[PE(k) + (ky - 1) * WP + (kx - 1)];
             if (k & 1) __builtin_amdgcn_sched_barrier(0);  // two elements' 18 LDS reads in flight, not all 72 (register budget)
         }
 #pragma unroll
@@ -297,21 +312,21 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
         for (int j = 0; j < 9; ++j) w9[j] = a.st[s].w[c * 9 + j];
 #pragma unroll
         for (int k = 0; k < LOC_EPT; ++k) {
-            din[k] = (k * LOC_T + tid < N) ? stencil_bwd(bufG, pe[k], WP, w9) : 0.f;
+            din[k] = (k * LOC_T + tid < N) ? stencil_bwd(bufG, PE(k), WP, w9) : 0.f;
             if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // bufG and red9 are free again
         if (s > 0) {
             const float* yprev = (s == 1) ? bufY1 : bufY2;
 #pragma unroll
-            for (int k = 0; k < LOC_EPT; ++k) dy[k] = (k * LOC_T + tid < N && yprev[pe[k]] > 0.f) ? din[k] : 0.f;
+            for (int k = 0; k < LOC_EPT; ++k) dy[k] = (k * LOC_T + tid < N && yprev[PE(k)] > 0.f) ? din[k] : 0.f;
         } else {
 #pragma unroll
             for (int k = 0; k < LOC_EPT; ++k) {
                 const int e = k * LOC_T + tid;
                 if (e < N) {
-                    const int b = e / n, p = e - b * n;
-                    a.dx[((size_t)b * a.C + c) * n + p] = dxd[k] + din[k];
+                    const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
+                    a.dx[((size_t)b * a.C + c) * n + p] += din[k];
                 }
             }
         }
@@ -331,12 +346,18 @@ hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream) {
     const size_t lds = local_lds_fwd(a.B, a.H, a.W);
     static size_t attr = 0;
     if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_fwd_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_fwd_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_fwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr = lds;
     }
-    hipLaunchKernelGGL(cab_local_fwd_kernel, dim3(a.C), dim3(LOC_T), lds, stream, a);
+    if (a.H * a.W == LOC_T)
+        hipLaunchKernelGGL(cab_local_fwd_kernel<true>, dim3(a.C), dim3(LOC_T), lds, stream, a);
+    else
+        hipLaunchKernelGGL(cab_local_fwd_kernel<false>, dim3(a.C), dim3(LOC_T), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -344,12 +365,18 @@ hipError_t cab_local_bwd_run(const LocalArgs& a, hipStream_t stream) {
     const size_t lds = local_lds_bwd(a.B, a.H, a.W);
     static size_t attr = 0;
     if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_bwd_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_bwd_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_bwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr = lds;
     }
-    hipLaunchKernelGGL(cab_local_bwd_kernel, dim3(a.C), dim3(LOC_T), lds, stream, a);
+    if (a.H * a.W == LOC_T)
+        hipLaunchKernelGGL(cab_local_bwd_kernel<true>, dim3(a.C), dim3(LOC_T), lds, stream, a);
+    else
+        hipLaunchKernelGGL(cab_local_bwd_kernel<false>, dim3(a.C), dim3(LOC_T), lds, stream, a);
     return hipGetLastError();
 }
 
