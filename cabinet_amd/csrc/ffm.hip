@@ -161,32 +161,24 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
                 }
             }
             return;  // INTERIOR: every row and column of the tile exists, nothing left to store
-        } else {
-            int o00[2], o01[2], o10[2], o11[2];
-            float w00[2], w01[2], w10[2], w11[2];
+        }
+    }
+    // general geometry (UP == 2): four gathers per output from the L2-resident low-resolution map.  Like the row form the
+    // term is added in the store loop below, one value at a time: adding it to the accumulators in place made the compiler
+    // copy all of them out of the AGPR half of the file (256 VGPRs and 492 .. 1200 bytes of scratch per lane).
+    int o00[2] = {0, 0}, o01[2] = {0, 0}, o10[2] = {0, 0}, o11[2] = {0, 0};
+    float w00[2] = {0.f, 0.f}, w01[2] = {0.f, 0.f}, w10[2] = {0.f, 0.f}, w11[2] = {0.f, 0.f};
+    if (UP == 2) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int p = min(p0 + wn * 64 + j * 32 + li, P - 1);
-                const int oy = p / a.W, ox = p - oy * a.W;
-                int y0, y1, x0, x1;
-                float ly, lx;
-                bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
-                bilinear_taps(ox, a.rw, a.Wl, x0, x1, lx);
-                o00[j] = y0 * a.Wl + x0, o01[j] = y0 * a.Wl + x1, o10[j] = y1 * a.Wl + x0, o11[j] = y1 * a.Wl + x1;
-                w00[j] = (1.f - ly) * (1.f - lx), w01[j] = (1.f - ly) * lx, w10[j] = ly * (1.f - lx), w11[j] = ly * lx;
-            }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = min(m0 + wm * (WM * 32) + i * 32 + acc_row(r) + 4 * h, M - 1);
-                    const float* src = a.up_src + ((size_t)b * M + m) * plane;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j][r] += w00[j] * src[o00[j]] + w01[j] * src[o01[j]] + w10[j] * src[o10[j]] +
-                                        w11[j] * src[o11[j]];
-                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 32 gathers in flight, not 256 (register budget)
-                }
+        for (int j = 0; j < 2; ++j) {
+            const int p = min(p0 + wn * 64 + j * 32 + li, P - 1);
+            const int oy = p / a.W, ox = p - oy * a.W;
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
+            bilinear_taps(ox, a.rw, a.Wl, x0, x1, lx);
+            o00[j] = y0 * a.Wl + x0, o01[j] = y0 * a.Wl + x1, o10[j] = y1 * a.Wl + x0, o11[j] = y1 * a.Wl + x1;
+            w00[j] = (1.f - ly) * (1.f - lx), w01[j] = (1.f - ly) * lx, w10[j] = ly * (1.f - lx), w11[j] = ly * lx;
         }
     }
 
@@ -199,10 +191,14 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
             if (m >= M) continue;
             float* drow = (m < a.M0) ? a.dst0 + ((size_t)b * a.M0 + m) * P
                                      : a.dst1 + ((size_t)b * (M - a.M0) + (m - a.M0)) * P;
+            const float* src = UP == 2 ? a.up_src + ((size_t)b * M + m) * ((size_t)a.Hl * a.Wl) : nullptr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int p = p0 + wn * 64 + j * 32 + li;
-                if (p < P) __builtin_nontemporal_store(acc[i][j][r], drow + p);  // streamed output (2 % on the big products)
+                float val = acc[i][j][r];
+                if (UP == 2)
+                    val += w00[j] * src[o00[j]] + w01[j] * src[o01[j]] + w10[j] * src[o10[j]] + w11[j] * src[o11[j]];
+                if (p < P) __builtin_nontemporal_store(val, drow + p);  // streamed output (2 % on the big products)
             }
         }
     }
