@@ -74,7 +74,7 @@ __device__ __forceinline__ void wg_sum2d(double a, double b, double* red, double
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
 // ------------------------------------------------------------------------------------------ forward
-template <bool ONEPLANE>  // see cab_local_bwd_kernel
+template <int NPL>  // see cab_local_bwd_kernel
 __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.H * a.W, N = a.B * n, c = blockIdx.x, tid = threadIdx.x;
@@ -83,9 +83,16 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     float* bufB = smem + NP;
     double* red = reinterpret_cast<double*>(smem + ((2 * NP + 1) & ~1));
     float xr[LOC_EPT], v[LOC_EPT];
-    int pe[ONEPLANE ? 1 : LOC_EPT];
-    const int pe0 = ONEPLANE ? (tid / a.W + 1) * WP + (tid % a.W) + 1 : 0;
-    auto PE = [&](int kk) { return ONEPLANE ? kk * PP + pe0 : pe[kk]; };
+    constexpr bool ONEPLANE = NPL > 0;
+    int pe[ONEPLANE ? 1 : LOC_EPT], pe0[ONEPLANE ? NPL : 1];
+    if (ONEPLANE) {
+#pragma unroll
+        for (int j = 0; j < (ONEPLANE ? NPL : 1); ++j) {
+            const int p = j * LOC_T + tid, y = p / a.W;
+            pe0[j] = (y + 1) * WP + (p - y * a.W) + 1;
+        }
+    }
+    auto PE = [&](int kk) { return ONEPLANE ? (kk / (ONEPLANE ? NPL : 1)) * PP + pe0[kk % (ONEPLANE ? NPL : 1)] : pe[kk]; };
     for (int i = tid; i < 2 * NP; i += LOC_T) smem[i] = 0.f;  // pad cells stay zero for the whole kernel
     __syncthreads();
 #pragma unroll
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
         xr[k] = 0.f;
         if (!ONEPLANE) pe[k] = WP + 1;
         if (e < N) {
-            const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
+            const int b = ONEPLANE ? k / (ONEPLANE ? NPL : 1) : e / n, p = ONEPLANE ? (k % (ONEPLANE ? NPL : 1)) * LOC_T + tid : e - b * n;
             if (!ONEPLANE) {
                 const int y = p / a.W;
                 pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
     for (int k = 0; k < LOC_EPT; ++k) {
         const int e = k * LOC_T + tid;
         if (e < N) {
-            const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
+            const int b = ONEPLANE ? k / (ONEPLANE ? NPL : 1) : e / n, p = ONEPLANE ? (k % (ONEPLANE ? NPL : 1)) * LOC_T + tid : e - b * n;
             const size_t gi = ((size_t)b * a.C + c) * n + p;
             float o = xr[k] * (1.f + sigmoidf(v[k]));
             if (a.glob) o = fmaf(gam, a.glob[gi], o);
@@ -167,9 +174,11 @@ __global__ __launch_bounds__(LOC_T) void cab_local_fwd_kernel(LocalArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------- backward
-// ONEPLANE: H * W == LOC_T (the model's 32 x 32 map): element k of a thread is pixel `tid` of image k, so the padded LDS
-// index of every element is one per-thread constant plus k * PP -- the eight-entry index array leaves the register file.
-template <bool ONEPLANE>
+// NPL > 0: H * W == NPL * LOC_T (NPL = 1: the model's 32 x 32 map; 2: the 64 x 32 map of BASELINE config 5): element k of a
+// thread is pixel (k % NPL) * LOC_T + tid of image k / NPL, so the padded LDS index of every element is one of NPL per-thread
+// constants plus (k / NPL) * PP -- the eight-entry index array leaves the register file, and so does every per-element
+// division.  NPL == 0 is the general shape.
+template <int NPL>
 __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.H * a.W, N = a.B * n, c = blockIdx.x, tid = threadIdx.x;
@@ -182,9 +191,16 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
     float* red9 = reinterpret_cast<float*>(red + 2 * (LOC_T / 64));
 
     float xh[3][LOC_EPT], yv[LOC_EPT], g[LOC_EPT];  // x itself stays in bufX (LDS) only: 8 registers less per lane
-    int pe[ONEPLANE ? 1 : LOC_EPT];
-    const int pe0 = ONEPLANE ? (tid / a.W + 1) * WP + (tid % a.W) + 1 : 0;
-    auto PE = [&](int kk) { return ONEPLANE ? kk * PP + pe0 : pe[kk]; };
+    constexpr bool ONEPLANE = NPL > 0;
+    int pe[ONEPLANE ? 1 : LOC_EPT], pe0[ONEPLANE ? NPL : 1];
+    if (ONEPLANE) {
+#pragma unroll
+        for (int j = 0; j < (ONEPLANE ? NPL : 1); ++j) {
+            const int p = j * LOC_T + tid, y = p / a.W;
+            pe0[j] = (y + 1) * WP + (p - y * a.W) + 1;
+        }
+    }
+    auto PE = [&](int kk) { return ONEPLANE ? (kk / (ONEPLANE ? NPL : 1)) * PP + pe0[kk % (ONEPLANE ? NPL : 1)] : pe[kk]; };
     for (int i = tid; i < 4 * NP; i += LOC_T) smem[i] = 0.f;  // pad cells stay zero for the whole kernel
     __syncthreads();
 #pragma unroll
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
         if (!ONEPLANE) pe[k] = WP + 1;
         g[k] = 0.f;
         if (e < N) {
-            const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n, y = p / a.W;
+            const int b = ONEPLANE ? k / (ONEPLANE ? NPL : 1) : e / n, p = ONEPLANE ? (k % (ONEPLANE ? NPL : 1)) * LOC_T + tid : e - b * n, y = p / a.W;
             if (!ONEPLANE) pe[k] = b * PP + (y + 1) * WP + (p - y * a.W) + 1;
             const size_t gi = ((size_t)b * a.C + c) * n + p;
             g[k] = a.dout[gi];
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
             const float sg = sigmoidf(yv[k]);
             dy[k] = (yv[k] > 0.f) ? g[k] * bufX[PE(k)] * sg * (1.f - sg) : 0.f;  // through the ReLU of stage 3
             if (e < N) {
-                const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
+                const int b = ONEPLANE ? k / (ONEPLANE ? NPL : 1) : e / n, p = ONEPLANE ? (k % (ONEPLANE ? NPL : 1)) * LOC_T + tid : e - b * n;
                 const size_t gi = ((size_t)b * a.C + c) * n + p;
                 a.dx[gi] = g[k] * (1.f + sg);
                 if (a.glob) {
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(LOC_T) void cab_local_bwd_kernel(LocalArgs a) {
             for (int k = 0; k < LOC_EPT; ++k) {
                 const int e = k * LOC_T + tid;
                 if (e < N) {
-                    const int b = ONEPLANE ? k : e / n, p = ONEPLANE ? tid : e - b * n;
+                    const int b = ONEPLANE ? k / (ONEPLANE ? NPL : 1) : e / n, p = ONEPLANE ? (k % (ONEPLANE ? NPL : 1)) * LOC_T + tid : e - b * n;
                     a.dx[((size_t)b * a.C + c) * n + p] += din[k];
                 }
             }
@@ -346,18 +362,17 @@ hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream) {
     const size_t lds = local_lds_fwd(a.B, a.H, a.W);
     static size_t attr = 0;
     if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_fwd_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_fwd_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(cab_local_fwd_kernel<0>),
+                              reinterpret_cast<const void*>(cab_local_fwd_kernel<1>),
+                              reinterpret_cast<const void*>(cab_local_fwd_kernel<2>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         attr = lds;
     }
-    if (a.H * a.W == LOC_T)
-        hipLaunchKernelGGL(cab_local_fwd_kernel<true>, dim3(a.C), dim3(LOC_T), lds, stream, a);
-    else
-        hipLaunchKernelGGL(cab_local_fwd_kernel<false>, dim3(a.C), dim3(LOC_T), lds, stream, a);
+    const int n = a.H * a.W;
+    auto kernel = n == LOC_T ? cab_local_fwd_kernel<1> : n == 2 * LOC_T ? cab_local_fwd_kernel<2> : cab_local_fwd_kernel<0>;
+    hipLaunchKernelGGL(kernel, dim3(a.C), dim3(LOC_T), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -365,18 +380,17 @@ hipError_t cab_local_bwd_run(const LocalArgs& a, hipStream_t stream) {
     const size_t lds = local_lds_bwd(a.B, a.H, a.W);
     static size_t attr = 0;
     if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_bwd_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_local_bwd_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(cab_local_bwd_kernel<0>),
+                              reinterpret_cast<const void*>(cab_local_bwd_kernel<1>),
+                              reinterpret_cast<const void*>(cab_local_bwd_kernel<2>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         attr = lds;
     }
-    if (a.H * a.W == LOC_T)
-        hipLaunchKernelGGL(cab_local_bwd_kernel<true>, dim3(a.C), dim3(LOC_T), lds, stream, a);
-    else
-        hipLaunchKernelGGL(cab_local_bwd_kernel<false>, dim3(a.C), dim3(LOC_T), lds, stream, a);
+    const int n = a.H * a.W;
+    auto kernel = n == LOC_T ? cab_local_bwd_kernel<1> : n == 2 * LOC_T ? cab_local_bwd_kernel<2> : cab_local_bwd_kernel<0>;
+    hipLaunchKernelGGL(kernel, dim3(a.C), dim3(LOC_T), lds, stream, a);
     return hipGetLastError();
 }
 
