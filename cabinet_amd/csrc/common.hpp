@@ -80,5 +80,9 @@ __device__ __forceinline__ int xcd_chunked_tile(int block, int total) {
 #define LOG2E_F 1.4426950408889634f
 #define LN2_F 0.6931471805599453f
 
+// floor(i / d) for 0 <= i < 2^21 and d >= 1, given inv = 1.f / d.  Exact: (i + 1/2) / d is at least 1/(2d) away from an integer,
+// the fp32 error of the product is below (i / d) * 2^-22.  An integer division by a run-time value is ~40 emulated instructions.
+__device__ __forceinline__ int idiv_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

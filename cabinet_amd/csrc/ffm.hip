@@ -412,6 +412,9 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
     const int oy_lo = max(0, (int)floorf(((float)ys_lo - 0.5f) / rh - 0.5f) - 1);
     const int oy_hi = min(min(H - 1, (int)ceilf(((float)ys_hi + 1.5f) / rh - 0.5f) + 1), oy_lo + max_rows - 1);
     const int nrows = oy_hi - oy_lo + 1, n_in = nrows * W, nys = ys_hi - ys_lo + 1, tid = threadIdx.x;
+    // every index split below is a division by a run-time width (~40 emulated instructions each; they were half of this
+    // kernel's 1035 VALU instructions per wave, on a pass that should be HBM-bound): exact reciprocal forms instead
+    const float inv_W = 1.f / (float)W, inv_Wl = 1.f / (float)Wl, inv_mr = 1.f / (float)max_rows, inv_XT = 1.f / (float)XT;
     if (FUSED) {
         const int c = pl % d.C;
         const float mu = d.mean[c], is = d.invstd[c], gw = d.bn_w[c], gb = d.bn_b[c];
@@ -436,14 +439,14 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = body(zv[e], gv[e]);
                 *reinterpret_cast<f32x4*>(rows + i) = o;
-                const int r = i / W;
+                const int r = idiv_small(i, inv_W);
                 if (r >= own_lo && r <= own_hi) *reinterpret_cast<f32x4*>(dzs + i) = o;
             }
         } else {
             for (int i = tid; i < n_in; i += 256) {
                 const float o = body(zs[i], gs[i]);
                 rows[i] = o;
-                const int r = i / W;
+                const int r = idiv_small(i, inv_W);
                 if (r >= own_lo && r <= own_hi) dzs[i] = o;
             }
         }
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
         }
     }
     for (int i = tid; i < nys * max_rows; i += 256) {
-        const int yi = i / max_rows, r = i - yi * max_rows, ys = ys_lo + yi;
+        const int yi = idiv_small(i, inv_mr), r = i - yi * max_rows, ys = ys_lo + yi;
         float wgt = 0.f;
         if (r < nrows) {
             int y0, y1;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
         wyt[i] = wgt;
     }
     for (int i = tid; i < Wl * XT; i += 256) {
-        const int xs = i / XT, t = i - xs * XT;
+        const int xs = idiv_small(i, inv_XT), t = i - xs * XT;
         const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1), ox = b_lo + t;
         float wgt = 0.f;
         if (ox < W) {
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
     __syncthreads();
     // separable: vertical taps first (weights depend on the row only), then horizontal
     for (int o = tid; o < nys * W; o += 256) {
-        const int yi = o / W, ox = o - yi * W, rr = yr[yi];
+        const int yi = idiv_small(o, inv_W), ox = o - yi * W, rr = yr[yi];
         const float* wv = wyt + yi * max_rows;
         float acc = 0.f;
         for (int r = rr & 0xffff; r <= (rr >> 16); ++r) acc += wv[r] * rows[r * W + ox];
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
     }
     __syncthreads();
     for (int o = tid; o < nys * Wl; o += 256) {
-        const int yi = o / Wl, xs = o - yi * Wl, b_lo = xlo[xs];
+        const int yi = idiv_small(o, inv_Wl), xs = o - yi * Wl, b_lo = xlo[xs];
         const float* wh = wxw + xs * XT;
         const float* tr = tcol + yi * W;
         float acc = 0.f;
