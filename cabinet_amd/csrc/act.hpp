@@ -8,7 +8,10 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2 };
 
 __device__ __forceinline__ float act_fwd(float u, int act) {
     if (act == ACT_RELU) return fmaxf(u, 0.f);
-    if (act == ACT_HSWISH) return u * fminf(fmaxf(u + 3.f, 0.f), 6.f) / 6.f;  // mobilenetv3.py:48-50,63-65
+    // mobilenetv3.py:48-50,63-65.  The division by six is a multiplication by the rounded reciprocal (<= 1 ulp from the
+    // quotient): an IEEE fp32 division is ~10 instructions, and it made the BatchNorm+HardSwish apply pass spend 25 VALU
+    // instructions per element (VALU pipes 50 % busy on a pass that should be waiting for HBM only)
+    if (act == ACT_HSWISH) return u * fminf(fmaxf(u + 3.f, 0.f), 6.f) * (1.f / 6.f);
     return u;
 }
 __device__ __forceinline__ float act_grad(float u, int act) {
@@ -16,8 +19,8 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     if (act == ACT_HSWISH) {
         // d/du [u * relu6(u+3)/6] with relu6' = 1 on the open interval (0,6), as ATen's hardtanh backward
         const float t = u + 3.f;
-        const float inner = (t > 0.f && t < 6.f) ? u / 6.f : 0.f;
-        return fminf(fmaxf(t, 0.f), 6.f) / 6.f + inner;
+        const float inner = (t > 0.f && t < 6.f) ? u * (1.f / 6.f) : 0.f;
+        return fminf(fmaxf(t, 0.f), 6.f) * (1.f / 6.f) + inner;
     }
     return 1.f;
 }
