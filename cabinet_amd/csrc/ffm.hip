@@ -630,14 +630,43 @@ void bn_finalize(const double* stat_part, int ntiles, int C, int nch, long long 
                        momentum, eps, running_mean, running_var, save_mean, save_invstd);
 }
 
-// pooled[b][c] = mean_p relu(bn(z[b][c][p]))        one workgroup per (b,c) row
-__global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__ z, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd,
+// pooled[b][c] = mean_p relu(bn(z[b][c][p]))        one workgroup per (b,c) row.
+// The BatchNorm finalize is folded in: every row reduces its channel's B double partials itself (2 B scalar loads), the
+// image-0 row also writes save_mean / save_invstd and updates the running buffers -- it was a 5 us launch of its own.
+struct BnFin {
+    const double* stat_part;  // [2][C][B] sums and sums of squares per (channel, image); unused in eval mode
+    int B, training;
+    long long count;
+    float momentum, eps;
+    float *run_mean, *run_var, *save_mean, *save_invstd;
+};
+__global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__ z, BnFin fin,
                                                         const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                                         float* __restrict__ pooled, int C, int P) {
     __shared__ float s_red[4];
-    const int row = blockIdx.x, c = row % C;
-    const float sc = bn_w[c] * invstd[c], sh = bn_b[c] - mean[c] * sc;
+    const int row = blockIdx.x, c = row % C, b = row / C;
+    float mu, inv;
+    if (!fin.training) {
+        mu = fin.run_mean[c], inv = 1.0f / sqrtf(fin.run_var[c] + fin.eps);
+        if (b == 0 && threadIdx.x == 0) fin.save_mean[c] = mu, fin.save_invstd[c] = inv;
+    } else {
+        double s1 = 0.0, s2 = 0.0;
+        for (int bb = 0; bb < fin.B; ++bb) {
+            s1 += fin.stat_part[(size_t)c * fin.B + bb];
+            s2 += fin.stat_part[((size_t)C + c) * fin.B + bb];
+        }
+        const double mean = s1 / (double)fin.count;
+        double var = s2 / (double)fin.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mu = (float)mean, inv = (float)(1.0 / sqrt(var + (double)fin.eps));
+        if (b == 0 && threadIdx.x == 0) {
+            fin.save_mean[c] = mu, fin.save_invstd[c] = inv;
+            const double unbiased = fin.count > 1 ? var * ((double)fin.count / (double)(fin.count - 1)) : var;
+            fin.run_mean[c] = (float)((1.0 - (double)fin.momentum) * (double)fin.run_mean[c] + (double)fin.momentum * mean);
+            fin.run_var[c] = (float)((1.0 - (double)fin.momentum) * (double)fin.run_var[c] + (double)fin.momentum * unbiased);
+        }
+    }
+    const float sc = bn_w[c] * inv, sh = bn_b[c] - mu * sc;
     const float* zr = z + (size_t)row * P;
     float acc = 0.f;
     if ((P & 3) == 0) {
@@ -969,10 +998,8 @@ static void ffm_fwd_tail(const FfmShape& s, double* stat_part, const float* bn_w
     const int P = s.H * s.W;
     if (training)
         hipLaunchKernelGGL(bn_rowstats_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, stat_part, s.B, s.Co, P);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(s.Co), dim3(256), 0, stream, stat_part, s.B, s.Co,
-                       (long long)s.B * P, training, momentum, eps, run_mean, run_var, save_mean, save_invstd);
-    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, save_mean, save_invstd, bn_w, bn_b,
-                       pooled, s.Co, P);
+    const BnFin fin{stat_part, s.B, training, (long long)s.B * P, momentum, eps, run_mean, run_var, save_mean, save_invstd};
+    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, fin, bn_w, bn_b, pooled, s.Co, P);
     hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(SE_T), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
                        w2, gate, s.Co, s.Cm);
     const int cpr = ceil_div(P, 4096);
