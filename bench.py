@@ -346,14 +346,13 @@ def main():
                           weight_decay=5e-4)
     graphed = not args.no_graph
     crit = make_criteria(args.batch, args.size, args.size, dev)
-    reducer = step_nopt = None
+    reducer = None
     if graphed and ddp:
         # hipGraph segments with the bucket all-reduces issued between them: the decoder's 23 MB reduce while the encoders
         # back-propagate (cabinet_amd/train.py::GraphedDDPStep); no per-kernel Python on any rank's host
         step = reducer = GraphedDDPStep(net, crit, optimizer=opt, always_reduce=True)
     elif graphed:  # the step replayed from two hipGraphs around its one host read (cabinet_amd/train.py)
         step = GraphedTrainStep(net, crit, optimizer=opt)
-        step_nopt = GraphedTrainStep(net, crit, optimizer=None)
     else:
         reducer = BucketedGradReducer(net, always_reduce=True) if ddp else None
         step = TrainStep(net, crit, reducer=reducer, optimizer=opt)
@@ -389,26 +388,21 @@ def main():
     log(f"timed region {dt:.3f}s -> {world * args.batch * args.steps / dt:.2f} images/s")
     # SURVEY.md section 8(d) words the metric as forward + 2x OHEM-CE + backward; `value` above also contains the gradient
     # all-reduce and the SGD step (conservative).  The same K steps without the optimizer, reported next to it:
-    if step_nopt is None:
-        if isinstance(step, GraphedDDPStep):
-            gC, step.graphs = step.graphs[3], step.graphs[:3] + (None,)  # same graphs, optimizer segment skipped
-        else:
-            step.optimizer = None
-        runner = step
-    else:
-        runner = step_nopt
-        for _ in range(2):
-            runner(im, lb)  # eager warm-up + capture (outside the timed region)
+    def set_optimizer(o):  # the optimizer step is not part of any captured graph: same step, segment skipped
+        step.optimizer = o
+        if hasattr(step, "opt_seg"):
+            step.opt_seg.optimizer = o
+        if hasattr(step, "eager"):
+            step.eager.optimizer = o
+
+    set_optimizer(None)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner(im, lb)
+        step(im, lb)
     sync()
     dt_nopt = time.perf_counter() - t0
-    if step_nopt is None and isinstance(step, GraphedDDPStep):
-        step.graphs = step.graphs[:3] + (gC,)
-    elif step_nopt is None:
-        step.optimizer = opt
+    set_optimizer(opt)
     if ddp:
         t = torch.tensor([dt_nopt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -443,7 +437,7 @@ def main():
         }
     # ---- per-kernel rooflines and CPU baseline: rank 0, outside the timed region -----------------
     if rank == 0 and not args.no_kernel_roofline:
-        del step, step_nopt, runner, opt
+        del step, opt
         torch.cuda.empty_cache()
         ks = kernel_rooflines(args.batch, args.size, args.kernel_iters)
         log("kernel rooflines measured")

@@ -14,12 +14,14 @@
 // bit-identical): the same algebraic value with the coherent term and the large common-mode partial sums removed
 // (dq error vs fp64 5e-6 -> 4e-7, below the autograd formulation's 1e-6).  mean_j(k_j) comes from a tiny pre-kernel.
 //
-// Two main kernels, no atomics, bitwise deterministic:
-//   K2a  dq   : workgroup = 32 queries, 4 waves split the keys     (+ writes D_i)
-//   K2b  dk,dv: workgroup = 32 keys,    4 waves split the queries
-// Each recomputes S and dP for its tiles (2n^2(4Kc+3Vc) executed vs 2n^2(3Kc+2Vc)
-// algorithmic) -- the price of not summing dq across workgroups with float atomics
-// (1.3 TB/s chip-wide on MI355X would bound the pass at ~100 us for config 3).
+// Default form (n % 4 == 0 and B*n*n*4 <= DS_MAX_BYTES), no atomics, bitwise deterministic -- S and dP are computed ONCE:
+//   prep      D_i = sum_c g ctx, and the mean key                                            (attn_bwd_prep_kernel)
+//   dk, dv    workgroup = 32 keys, 4 waves split the queries; S = Q^T K, dP = G^T V, dV += G P, dK += Q dS;
+//             it also STORES dS (B*n*n floats, rows of 128 contiguous bytes)                  (cab_attn_bwd_dkdv_fast_kernel)
+//   dq        = scale * dS (K - mean K)^T as a small-GEMM product over the stored dS         (sg_gemm + sum_parts)
+// executed = algorithmic FLOPs, 2 n^2 (3Kc + 2Vc) per image.  Fallback forms that recompute S and dP for dq instead of
+// storing dS (2 n^2 (4Kc + 3Vc) executed): ragged n and dS above DS_MAX_BYTES (cab_attn_bwd_dq_fast_kernel), and the
+// generic chunk-staged pair cab_attn_bwd_dq_kernel / cab_attn_bwd_dkdv_kernel for (Kc, Vc) = (256, 128) in those cases.
 //
 // Layout trick shared with the forward kernel: the tile index that is NOT contracted
 // sits on the lane, so every accumulator is directly the B operand of the next product
@@ -693,15 +695,18 @@ static void launch_dk_from_ds(const float* q, const float* ds, float scale, int 
     }
 }
 
-// the stored-dS form needs 16-byte aligned rows of K and dS for the small GEMM's vector loads
-static bool use_ds_path(int n) { return (n & 3) == 0; }
+// the stored-dS form needs 16-byte aligned rows of K and dS for the small GEMM's vector loads -- and B*n*n floats of
+// workspace: above DS_MAX_BYTES (n = 8704, the un-tiled UAVid validation frame, is 303 MB per image; n = 16k would be 1 GB
+// per image) the recompute kernels are used instead, whose workspace is O(B*n) as in round 1
+static constexpr size_t DS_MAX_BYTES = (size_t)512 << 20;
+static bool use_ds_path(int B, int n) { return (n & 3) == 0 && (size_t)B * n * n * sizeof(float) <= DS_MAX_BYTES; }
 
 template <int KC, int VC, bool DK = true>  // DK = false requires the stored-dS form (n % 4 == 0)
 static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k, const float* v,
                                   const float* ctx, const float* lse, float scale, int B, int n, float* dq,
                                   float* dk, float* dv, float* delta, hipStream_t stream) {
     float* kmean = delta + align_up((size_t)B * n, 64);
-    const bool dsp = use_ds_path(n);
+    const bool dsp = use_ds_path(B, n);
     if (!DK && !dsp) return hipErrorInvalidValue;
     if (dsp) {
         const int nb_delta = B * ((n + 63) / 64);
@@ -713,17 +718,12 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
     const size_t lds_dq = (size_t)((KC + VC) * 32 + 4 * KC * 32 + KC * 32 + 256 + 64 + KC) * sizeof(float);
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 4 * (DK ? KC + VC : VC) * 32) * sizeof(float);
     auto k_kv = cab_attn_bwd_dkdv_fast_kernel<KC, VC, DK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_kv);
-        if (e != hipSuccess) return e;
-        if constexpr (DK) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(cab_attn_bwd_dq_fast_kernel<KC, VC>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-            if (e != hipSuccess) return e;
-        }
-        attr_done = true;
+    static lds_attr_mask mask_kv{0}, mask_dq{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_kv), lds_kv, mask_kv); e != hipSuccess) return e;
+    if constexpr (DK) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cab_attn_bwd_dq_fast_kernel<KC, VC>), lds_dq, mask_dq);
+            e != hipSuccess)
+            return e;
     }
     const int nsplit = bwd_nsplit(B, n);
     float* part_k = kmean + align_up((size_t)B * KC, 64);
@@ -763,7 +763,7 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
                              const float* lse, float scale, int B, int n, float* dq, float* dk, float* dv,
                              float* delta, hipStream_t stream) {
     float* kmean = delta + align_up((size_t)B * n, 64);
-    const bool dsp = use_ds_path(n);
+    const bool dsp = use_ds_path(B, n);
     if (dsp) {
         const int nb_delta = B * ((n + 63) / 64);
         hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 3) / 4), dim3(256), 0, stream, g, ctx, k, delta,
@@ -775,16 +775,9 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 8 * TCHUNK + (KC + VC) * 32) * sizeof(float);
     auto k_dq = cab_attn_bwd_dq_kernel<KC, VC>;
     auto k_kv = cab_attn_bwd_dkdv_kernel<KC, VC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dq),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_kv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_kv);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static lds_attr_mask mask_dq{0}, mask_kv{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_dq), lds_dq, mask_dq); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_kv), lds_kv, mask_kv); e != hipSuccess) return e;
     dim3 grid((n + 31) / 32, 1, B);
     float* ds = dsp ? kmean + align_up((size_t)B * KC, 64) : nullptr;
     if (!dsp)
@@ -796,10 +789,10 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
 
 size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
     size_t bytes = (align_up((size_t)B * n, 64) + align_up((size_t)B * Kc, 64)) * sizeof(float);  // D_i, mean key
-    const bool fast = (Kc <= 128 && Kc + Vc <= 256) || (Kc == 256 && Vc == 128 && use_ds_path(n));
+    const bool fast = (Kc <= 128 && Kc + Vc <= 256) || (Kc == 256 && Vc == 128 && use_ds_path(B, n));
     const int nsplit = fast ? bwd_nsplit(B, n) : 1;
     if (nsplit > 1) bytes += (size_t)nsplit * B * (Kc + Vc) * n * sizeof(float);  // partial dq|dk and dv slabs
-    if (use_ds_path(n))  // dS, then the key-range slabs of dq (and the query-range slabs of dk for Kc = 256)
+    if (use_ds_path(B, n))  // dS, then the key-range slabs of dq (and the query-range slabs of dk for Kc = 256)
         bytes += ((size_t)B * n * n + (size_t)(Kc == 256 ? 2 : 1) * (dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * B * Kc * n) *
                  sizeof(float);
     return align_up(bytes, 256);
@@ -811,7 +804,7 @@ hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, 
     float* delta = static_cast<float*>(ws);
     if (Kc == 128 && Vc == 128)
         return launch_bwd_fast<128, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
-    if (Kc == 256 && Vc == 128 && use_ds_path(n))  // dk and dq both as products over the stored dS
+    if (Kc == 256 && Vc == 128 && use_ds_path(B, n))  // dk and dq both as products over the stored dS
         return launch_bwd_fast<256, 128, false>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);
     if (Kc == 256 && Vc == 128)
         return launch_bwd<256, 128>(dctx, q, k, v, ctx, lse, scale, B, n, dq, dk, dv, delta, stream);

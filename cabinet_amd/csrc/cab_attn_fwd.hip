@@ -341,13 +341,8 @@ static hipError_t launch_fwd(const float* q, const float* k, const float* v, flo
     const size_t lds = (size_t)(4 * VC * 33 + 3 * 128) * sizeof(float);
     auto kern = cab_attn_fwd_kernel<KC, VC>;
     const dim3 block(256);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static lds_attr_mask attr_mask{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_mask); e != hipSuccess) return e;
     dim3 grid(((n + 31) / 32) * kvsplit * B);
     if (kvsplit == 1) {
         hipLaunchKernelGGL(kern, grid, block, lds, stream, q, k, v, ctx, lse, n, scale * LOG2E_F, 1, B);

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libcabinet_hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stddef.h>
 
@@ -83,6 +84,22 @@ __device__ __forceinline__ int xcd_chunked_tile(int block, int total) {
 // floor(i / d) for 0 <= i < 2^21 and d >= 1, given inv = 1.f / d.  Exact: (i + 1/2) / d is at least 1/(2d) away from an integer,
 // the fp32 error of the product is below (i / d) * 2^-22.  An integer division by a run-time value is ~40 emulated instructions.
 __device__ __forceinline__ int idiv_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process-global "done" flag leaves a
+// second GPU of the same process without it.  One bit per device ordinal; the call is idempotent, so two threads racing
+// through the first launch on a device both set it and nothing is lost (no lock, no process-global bool).
+
+typedef std::atomic<unsigned long long> lds_attr_mask;
+static inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, lds_attr_mask& mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && ((mask.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && tracked) mask.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+}
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

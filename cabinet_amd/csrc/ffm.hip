@@ -208,12 +208,8 @@ template <int WM, bool INTERIOR, int UP>
 static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
     constexpr int MT = 128 * WM;
     const size_t lds = (size_t)(2 * GK_BK * MT + 2 * GK_BK * GK_NT) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR, UP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static lds_attr_mask attr_mask{0};
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR, UP>), lds, attr_mask);
     dim3 grid(ceil_div(a.P, GK_NT), ceil_div(a.M, MT), B);
     hipLaunchKernelGGL((gemm_kmajor_kernel<WM, INTERIOR, UP>), grid, dim3(512), lds, stream, a);
 }
@@ -1142,16 +1138,9 @@ hipError_t dw_product(const float* dzv, const float* xs, int B, int Co, int Cx, 
     const int nsplit = dw_nsplit(total_chunks, ceil_div(Co, G3_T) * ceil_div(Cx, G3_T));
     const int cps = ceil_div(total_chunks, nsplit);
     const size_t lds = (size_t)(4 * G3_T * G3_STR) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static lds_attr_mask mask_int{0}, mask_gen{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dw_kernel<true>), lds, mask_int); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_dw_kernel<false>), lds, mask_gen); e != hipSuccess) return e;
     const bool interior = (P % G3_BK) == 0 && (Co % G3_T) == 0 && (Cx % G3_T) == 0;
     const dim3 grid(ceil_div(Co, G3_T) * ceil_div(Cx, G3_T) * nsplit);
     if (interior)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
                                                            float* __restrict__ blk_sum, int* __restrict__ blk_cnt) {
     extern __shared__ __attribute__((aligned(16))) float v[];  // [C][Wl]
     __shared__ float s_f[4];
-    __shared__ int s_i[2][4];
+    __shared__ int s_i[3][4];
     const int b = blockIdx.y, oy = blockIdx.x, P = H * W;
     const size_t plane = (size_t)Hl * Wl;
     const float* low_b = low + (size_t)b * C * plane;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
     }
     __syncthreads();
     float my_sum = 0.f;
-    int my_valid = 0, my_above = 0;
+    int my_valid = 0, my_above = 0, my_bad = 0;
     for (int ox = threadIdx.x; ox < W; ox += 256) {
         const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
         const long long lb = labels[pix];
@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
             for (int c = 0; c < CMAX; ++c)
                 if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);  // v_exp_f32: arguments <= 0, 1 ulp
             loss = mx + fast_log2(se) * LN2_F - xl;
-            // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): poison this
-            // block's valid count so the caller's one host read sees it (a row holds far fewer than 2^20 pixels)
-            my_valid += (lb < 0 || lb >= (long long)C) ? -(1 << 20) : 1;
+            // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): a separate flag,
+            // OR-reduced over the block, poisons the block's valid count so the caller's one host read sees it (an
+            // arithmetic sentinel summed over a wide row could wrap)
+            my_valid += 1;
+            my_bad |= (lb < 0 || lb >= (long long)C) ? 1 : 0;
             if (loss > thresh) {
                 my_above += 1;
                 my_sum += loss;
@@ -84,18 +86,21 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
     for (int o = 32; o >= 1; o >>= 1) {
         my_valid += __shfl_xor(my_valid, o, 64);
         my_above += __shfl_xor(my_above, o, 64);
+        my_bad |= __shfl_xor(my_bad, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         s_f[threadIdx.x >> 6] = my_sum;
         s_i[0][threadIdx.x >> 6] = my_valid;
         s_i[1][threadIdx.x >> 6] = my_above;
+        s_i[2][threadIdx.x >> 6] = my_bad;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
         blk_sum[blk] = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
         const int nv = s_i[0][0] + s_i[0][1] + s_i[0][2] + s_i[0][3];
-        blk_cnt[2 * blk] = nv < 0 ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
+        const int bad = s_i[2][0] | s_i[2][1] | s_i[2][2] | s_i[2][3];
+        blk_cnt[2 * blk] = bad ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
         blk_cnt[2 * blk + 1] = s_i[1][0] + s_i[1][1] + s_i[1][2] + s_i[1][3];
     }
 }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __rest
                                                               float* __restrict__ blk_sum, int* __restrict__ blk_cnt) {
     extern __shared__ __attribute__((aligned(16))) float v[];  // [C][Wl]
     __shared__ float s_f[4];
-    __shared__ int s_i[2][4];
+    __shared__ int s_i[3][4];
     const int b = blockIdx.y, oy = blockIdx.x, P = H * W, nt = blockDim.x;
     const size_t plane = (size_t)Hl * Wl;
     const float* low_b = low + (size_t)b * C * plane;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __rest
     }
     __syncthreads();
     float my_sum = 0.f;
-    int my_valid = 0, my_above = 0;
+    int my_valid = 0, my_above = 0, my_bad = 0;
     for (int g = threadIdx.x; g < Wl; g += nt) {
         const size_t pix = (size_t)b * P + (size_t)oy * W + 8 * g;  // 64-byte aligned labels, 32-byte aligned losses
         long long lb[8];
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __rest
                 for (int c = 0; c < CMAX; ++c)
                     if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);
                 loss = mx + fast_log2(se) * LN2_F - xl;
-                my_valid += (lb[j] < 0 || lb[j] >= (long long)C) ? -(1 << 20) : 1;  // see ohem_up_fwd_kernel
+                my_valid += 1;
+                my_bad |= (lb[j] < 0 || lb[j] >= (long long)C) ? 1 : 0;  // see ohem_up_fwd_kernel
                 if (loss > thresh) {
                     my_above += 1;
                     my_sum += loss;
@@ -182,21 +188,23 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __rest
     for (int o = 32; o >= 1; o >>= 1) {
         my_valid += __shfl_xor(my_valid, o, 64);
         my_above += __shfl_xor(my_above, o, 64);
+        my_bad |= __shfl_xor(my_bad, o, 64);
     }
     const int nw = (nt + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
         s_f[threadIdx.x >> 6] = my_sum;
         s_i[0][threadIdx.x >> 6] = my_valid;
         s_i[1][threadIdx.x >> 6] = my_above;
+        s_i[2][threadIdx.x >> 6] = my_bad;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
         float fs = 0.f;
-        int nv = 0, na = 0;
-        for (int w = 0; w < nw; ++w) fs += s_f[w], nv += s_i[0][w], na += s_i[1][w];
+        int nv = 0, na = 0, bad = 0;
+        for (int w = 0; w < nw; ++w) fs += s_f[w], nv += s_i[0][w], na += s_i[1][w], bad |= s_i[2][w];
         blk_sum[blk] = fs;
-        blk_cnt[2 * blk] = nv < 0 ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
+        blk_cnt[2 * blk] = bad ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
         blk_cnt[2 * blk + 1] = na;
     }
 }

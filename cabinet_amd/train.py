@@ -55,9 +55,11 @@ class TrainStep:
     """fwd + 2x OHEM-CE + bwd (+ gradient all-reduce when a reducer is given), with the reference's accumulation
     contract: call it once per micro-batch; every ``accum_steps``-th call reduces and steps the optimizer."""
 
-    def __init__(self, net, criteria, reducer=None, optimizer=None, autocast=False, fused_loss=None, accum_steps=1):
+    def __init__(self, net, criteria, reducer=None, optimizer=None, autocast=False, fused_loss=None, accum_steps=1,
+                 before_optimizer=None):
         self.net, (self.crit_p, self.crit_16) = net, criteria
         self.reducer, self.optimizer, self.autocast = reducer, optimizer, autocast
+        self.before_optimizer = before_optimizer  # e.g. gradient clipping (train.py:411-427), after the reduction
         # fused_loss: run the two final x8 upsamples inside the OHEM-CE kernels (device tensors only);
         # default = on whenever the model lives on a GPU
         self.fused_loss = fused_loss
@@ -77,6 +79,8 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.finish()
         if self.optimizer is not None:
+            if self.before_optimizer is not None:
+                self.before_optimizer()
             self.optimizer.step()
         self._micro = 0
 
@@ -109,6 +113,17 @@ class TrainStep:
         return loss.detach()
 
 
+def _check_static_shapes(step, im, lb):
+    """A replayed graph reads the static input tensors it was captured on: ``copy_`` would silently BROADCAST a trailing
+    batch of one image over the captured batch (and fail opaquely on other sizes)."""
+    if tuple(im.shape) != tuple(step.s_im.shape) or tuple(lb.shape) != tuple(step.s_lb.shape) or \
+            im.dtype != step.s_im.dtype or lb.dtype != step.s_lb.dtype:
+        raise RuntimeError(f"{type(step).__name__}: batch {tuple(im.shape)} {im.dtype} / {tuple(lb.shape)} {lb.dtype} does "
+                           f"not match the captured {tuple(step.s_im.shape)} {step.s_im.dtype} / {tuple(step.s_lb.shape)} "
+                           f"{step.s_lb.dtype}; run ragged trailing batches through TrainStep (or drop_last, as the "
+                           f"reference's loader does, train.py:248-256)")
+
+
 class _BufferSnapshot:
     """Save / restore a module's buffers (BatchNorm running statistics and counters) with one multi-tensor copy per dtype.
     ``torch._foreach_copy_`` only takes its fused path when every tensor of the list has the same dtype; the buffers of a
@@ -130,6 +145,55 @@ class _BufferSnapshot:
             torch._foreach_copy_(bufs, bak)
 
 
+def _hyper_snapshot(optimizer):
+    """Every scalar hyper-parameter of every param group (what torch's optimizers pass to their kernels BY VALUE)."""
+    return [{k: (v if isinstance(v, (int, float, bool, type(None), str)) else repr(v)) for k, v in g.items() if k != "params"}
+            for g in optimizer.param_groups]
+
+
+class _OptimizerSegment:
+    """How a graphed step runs ``optimizer.step()``.
+
+    Default: EAGERLY, after the backward graph (a foreach SGD is a handful of launches).  torch's optimizers pass lr,
+    weight decay and momentum to their kernels as host scalars, and a Python-side schedule (the reference's
+    ``Optimizer.step`` sets ``pg['lr']`` by warm-up + poly decay and counts ``self.it`` every step,
+    src/utils/optimizer.py:141-155) runs in the interpreter: a captured ``step()`` would replay the capture-time values
+    for ever.  ``before`` (e.g. gradient clipping, train.py:411-427) runs between backward and the step.
+    ``capture=True`` records the step into its own hipGraph for a plain torch optimizer with constant hyper-parameters;
+    the param-group scalars are snapshotted at capture and a replay with changed values RAISES instead of silently
+    stepping with the old ones.  A wrapper object whose ``step`` does host-side work must not be captured."""
+
+    def __init__(self, optimizer, capture=False, before=None):
+        self.optimizer, self.capture, self.before = optimizer, bool(capture), before
+        self.graph = self.snapshot = None
+        if self.capture and optimizer is not None and not isinstance(optimizer, torch.optim.Optimizer):
+            raise RuntimeError("capture_optimizer=True needs a plain torch.optim.Optimizer: a wrapper's Python-side "
+                               "schedule (warm-up, decay, step counter) would be frozen at its capture-time values")
+
+    def record(self, pool):
+        if self.optimizer is None or not self.capture:
+            return
+        if self.before is not None:
+            raise RuntimeError("capture_optimizer=True cannot run a `before_optimizer` callback between the graphs")
+        self.snapshot = _hyper_snapshot(self.optimizer)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            self.optimizer.step()
+
+    def run(self):
+        if self.optimizer is None:
+            return
+        if self.graph is None:
+            if self.before is not None:
+                self.before()
+            self.optimizer.step()
+            return
+        if _hyper_snapshot(self.optimizer) != self.snapshot:
+            raise RuntimeError("optimizer hyper-parameters changed after the optimizer step was captured in a hipGraph "
+                               "(they are baked into the captured kernels); use capture_optimizer=False with schedulers")
+        self.graph.replay()
+
+
 class GraphedTrainStep:
     """TrainStep replayed from two hipGraphs around the step's ONE host read (single process, fused loss).
 
@@ -138,7 +202,8 @@ class GraphedTrainStep:
 
         graph A   forward of the network + the OHEM forward kernels of both heads + their reduced statistics
         host      reads the 2 x (n_valid, n_above) counts and decides the OHEM branch      (the step's one sync)
-        graph B   OHEM 'at least n_min pixels above thresh' branch, loss, backward, optimizer step
+        graph B   OHEM 'at least n_min pixels above thresh' branch, loss, backward
+        eager     optimizer.step() (see _OptimizerSegment: schedules and clipping are host-side; opt-in graph for constant lr)
 
     and replayed with three host calls.  Nothing data-dependent is baked into a kernel argument (n_above is a device
     scalar in the loss).  If the host read says a head needs the rare top-n_min branch (or has no valid pixel), the step
@@ -146,10 +211,11 @@ class GraphedTrainStep:
     Inputs are copied into static tensors; the returned loss is a static device tensor (read it before the next step).
     Data-parallel runs keep the eager TrainStep: its reducer launches collectives from autograd hooks."""
 
-    def __init__(self, net, criteria, optimizer=None, warmup=2):
+    def __init__(self, net, criteria, optimizer=None, warmup=2, capture_optimizer=False, before_optimizer=None):
         self.net, (self.crit_p, self.crit_16) = net, criteria
         self.optimizer, self.warmup = optimizer, warmup
-        self.eager = TrainStep(net, criteria, optimizer=optimizer)
+        self.opt_seg = _OptimizerSegment(optimizer, capture_optimizer, before_optimizer)
+        self.eager = TrainStep(net, criteria, optimizer=optimizer, before_optimizer=before_optimizer)
         self.g_fwd = self.g_bwd = None
         self.fallbacks = self._calls = 0
 
@@ -182,9 +248,9 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), capture_error_mode=_CAPTURE_MODE):
             loss = self.crit_p._fused_finish(self.pa, host[0]) + self.crit_16._fused_finish(self.pb, host[1])
             loss.backward()
-            if self.optimizer is not None:
-                self.optimizer.step()
             self.s_loss = loss.detach()
+        self.opt_seg.record(self.g_fwd.pool())
+        self.s_grads = [(p, p.grad) for p in self.net.parameters() if p.grad is not None]
         torch.cuda.synchronize()
 
     @staticmethod
@@ -204,23 +270,28 @@ class GraphedTrainStep:
             if self._calls >= max(1, self.warmup):
                 self._capture(im, lb)
             return loss
+        _check_static_shapes(self, im, lb)
         self.s_im.copy_(im, non_blocking=True)
         self.s_lb.copy_(lb, non_blocking=True)
         self.snap.save()
         self.g_fwd.replay()
         host = self.s_stats.tolist()  # the step's one host sync
         if all(self._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
+            for p, g in self.s_grads:  # a caller's zero_grad(set_to_none=True) must not detach the graphs' gradient tensors
+                p.grad = g
             self.g_bwd.replay()
+            self.opt_seg.run()
             return self.s_loss
         # rare branch (late training: fewer than n_min hard pixels): undo graph A's BatchNorm side effects, run eagerly
         self.fallbacks += 1
         self.snap.restore()
-        grads = [p.grad for p in self.net.parameters()]
         loss = self.eager(im, lb)
-        for p, g in zip(self.net.parameters(), grads):  # keep the static gradient tensors the graphs write to
-            if g is not None and p.grad is not None and p.grad is not g:
+        for p, g in self.s_grads:  # keep the static gradient tensors the graphs write to; a step without gradient = zeros
+            if p.grad is None:
+                g.zero_()
+            elif p.grad is not g:
                 g.copy_(p.grad)
-                p.grad = g
+            p.grad = g
         return loss
 
 
@@ -230,16 +301,20 @@ class GraphedDDPStep:
     The eager reducer (cabinet_amd.ddp.BucketedGradReducer) launches collectives from autograd hooks, which keeps the
     whole ~1,100-launch Python / autograd enqueue path (13 ms per step at config 3) on every rank's host -- 8 ranks share
     the node's host cores.  Here the step is cut where the model cuts itself: the decoder (``conv_out, ffm, ab``: 23 MB of
-    gradients) is back-propagated first, the encoders (``mobile, sb``: 13 MB, two thirds of the backward time) second:
+    gradients) is back-propagated first, then the backbone (``mobile``: 12.6 MB), and the spatial branch LAST (``sb``: 0.36 MB
+    of gradients but several milliseconds of backward on the 512^2 .. 128^2 maps -- north_star: "all-reduce ... overlapped with
+    the backward of the spatial branch"):
 
         graph A    forward, OHEM forward kernels + statistics
         host       one read-back (OHEM branch), as in GraphedTrainStep
         graph B1   loss, backward of the decoder down to the two boundary tensors (sb output, mobile output), gradients packed
                    into the decoder's flat buckets (one multi-tensor copy)
-        RCCL       all-reduce(AVG) of the decoder buckets, asynchronous on RCCL's stream        <- overlaps graph B2
-        graph B2   backward of the encoders from the boundary gradients, packed into the encoder buckets
-        RCCL       all-reduce of the encoder buckets (the only exposed communication: 13 MB over xGMI), join
-        graph C    optimizer step
+        RCCL       all-reduce(AVG) of the decoder buckets, asynchronous on RCCL's stream        <- overlaps graphs B2, B3
+        graph B2   backward of the backbone from its boundary gradient, packed into the backbone buckets
+        RCCL       all-reduce of the backbone buckets                                           <- overlaps graph B3
+        graph B3   backward of the spatial branch, packed into its (single, < 0.5 MB) bucket
+        RCCL       all-reduce of that bucket -- the only exposed communication; join
+        eager      optimizer step (_OptimizerSegment: host-side schedules / clipping; opt-in graph for constant lr)
 
     Collectives are ordinary eager calls between replays (nothing of RCCL is captured), always the same buckets in the
     same order on every rank, also on a rank that falls back to the eager path for this step (rare OHEM branch).
@@ -250,9 +325,10 @@ class GraphedDDPStep:
     ``use_graphs=False`` (default on CPU tensors) runs the identical schedule eagerly -- that is what the gloo tests drive."""
 
     DECODER = ("conv_out", "ffm", "ab")
+    LAST = ("sb",)  # back-propagated last: its backward hides the backbone's all-reduce
 
     def __init__(self, net, criteria, optimizer=None, process_group=None, bucket_mb=8.0, warmup=2, use_graphs=None,
-                 always_reduce=False, broadcast_parameters=True):
+                 always_reduce=False, broadcast_parameters=True, capture_optimizer=False, before_optimizer=None):
         import torch.distributed as dist
 
         from .ddp import plan_buckets
@@ -264,17 +340,18 @@ class GraphedDDPStep:
         self.always_reduce = always_reduce
         self.net, (self.crit_p, self.crit_16) = net, criteria
         self.optimizer, self.warmup = optimizer, warmup
+        self.opt_seg = _OptimizerSegment(optimizer, capture_optimizer, before_optimizer)
         dev = next(net.parameters()).device
         self.use_graphs = (dev.type == "cuda") if use_graphs is None else bool(use_graphs)
-        dec, enc = [], []
+        dec, mid, last = [], [], []
         for name, child in net.named_children():
             for p in child.parameters():
                 if p.requires_grad:
-                    (dec if name in self.DECODER else enc).append(p)
+                    (dec if name in self.DECODER else last if name in self.LAST else mid).append(p)
         self.dec_params = dec
         cap = int(bucket_mb * 2 ** 20)
         self.segments, self.seg_views = [], []
-        for params in (list(reversed(dec)), list(reversed(enc))):  # ~ gradient arrival order inside each half
+        for params in (list(reversed(dec)), list(reversed(mid)), list(reversed(last))):  # ~ arrival order inside each part
             flats = []
             views = []
             for plan in plan_buckets([p.numel() * 4 for p in params], cap, cap, 2 ** 18):
@@ -318,7 +395,7 @@ class GraphedDDPStep:
             torch._foreach_copy_(dst, src)
 
     def _forward(self, im, lb):
-        """-> (fused preps | None, loss | None, boundary tensors)"""
+        """-> (fused preps | None, loss | None, boundary tensors [sb output, mobile output])"""
         boundary = []
         if im.is_cuda:
             low, low16 = self.net.forward_lowres(im, boundary)
@@ -348,8 +425,9 @@ class GraphedDDPStep:
             warnings.simplefilter("ignore")
             return t.grad
 
-    def _backward_encoders(self, boundary):
-        torch.autograd.backward(boundary, [self._grad_of(t) for t in boundary])
+    def _backward_from(self, t, retain=False):
+        """Back-propagate one encoder from its boundary tensor (the autograd graphs of ``mobile`` and ``sb`` are disjoint)."""
+        torch.autograd.backward([t], [self._grad_of(t)], retain_graph=retain)
 
     def _reduce(self, seg):
         if self.world == 1 and not self.always_reduce:
@@ -372,20 +450,30 @@ class GraphedDDPStep:
         ran = self._backward_decoder(loss, boundary)
         self._pack(0)
         works = self._reduce(0)
+        feat_sb, mob = boundary
         if ran:
-            self._backward_encoders(boundary)
+            self._backward_from(mob)
         self._pack(1)
         works += self._reduce(1)
+        if ran:
+            self._backward_from(feat_sb)
+        self._pack(2)
+        works += self._reduce(2)
         self._join(works)
-        if self.optimizer is not None:
-            self.optimizer.step()
+        self._optimizer_step_eager()
         return loss.detach()
+
+    def _optimizer_step_eager(self):
+        if self.optimizer is not None:
+            if self.opt_seg.before is not None:
+                self.opt_seg.before()
+            self.optimizer.step()
 
     def _capture(self, im, lb):
         self.s_im, self.s_lb = im.clone(), lb.clone()
         self.snap = _BufferSnapshot(self.net)
         torch.cuda.synchronize()
-        gA, gB1, gB2, gC = (torch.cuda.CUDAGraph() for _ in range(4))
+        gA, gB1, gB2, gB3 = (torch.cuda.CUDAGraph() for _ in range(4))
         self._clear()
         with torch.cuda.graph(gA, capture_error_mode=_CAPTURE_MODE):
             self.fused, _, self.boundary = self._forward(self.s_im, self.s_lb)
@@ -398,21 +486,21 @@ class GraphedDDPStep:
         self.snap.restore()
         if not all(GraphedTrainStep._selected_branch(c, h) for c, h in zip((self.crit_p, self.crit_16), host)):
             raise RuntimeError("GraphedDDPStep: capture batch does not take the OHEM 'n_min above thresh' branch")
+        feat_sb, mob = self.boundary
         with torch.cuda.graph(gB1, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
             loss = self.crit_p._fused_finish(self.fused[0], host[0]) + self.crit_16._fused_finish(self.fused[1], host[1])
             self._backward_decoder(loss, self.boundary)
             self._pack(0)
             self.s_loss = loss.detach()
         with torch.cuda.graph(gB2, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
-            self._backward_encoders(self.boundary)
+            self._backward_from(mob)
             self._pack(1)
-        if self.optimizer is not None:
-            with torch.cuda.graph(gC, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
-                self.optimizer.step()
-        else:
-            gC = None
+        with torch.cuda.graph(gB3, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
+            self._backward_from(feat_sb)
+            self._pack(2)
+        self.opt_seg.record(gA.pool())
         torch.cuda.synchronize()
-        self.graphs = (gA, gB1, gB2, gC)
+        self.graphs = (gA, gB1, gB2, gB3)
 
     def __call__(self, im, lb):
         if not self.use_graphs:
@@ -423,7 +511,8 @@ class GraphedDDPStep:
             if self._calls >= max(1, self.warmup):
                 self._capture(im, lb)
             return loss
-        gA, gB1, gB2, gC = self.graphs
+        gA, gB1, gB2, gB3 = self.graphs
+        _check_static_shapes(self, im, lb)
         self.s_im.copy_(im, non_blocking=True)
         self.s_lb.copy_(lb, non_blocking=True)
         self.snap.save()
@@ -433,13 +522,17 @@ class GraphedDDPStep:
             self.fallbacks += 1       # same collectives, same order, issued by the eager path
             self.snap.restore()
             return self._eager_step(im, lb)
+        for views in self.seg_views:  # a caller's zero_grad(set_to_none=True) must not detach the bucket views
+            for p, view in views:
+                p.grad = view
         gB1.replay()
         works = self._reduce(0)       # RCCL's stream waits for graph B1, the host goes on to launch B2
         gB2.replay()
-        works += self._reduce(1)
+        works += self._reduce(1)      # the backbone's buckets travel under the spatial branch's backward
+        gB3.replay()
+        works += self._reduce(2)      # < 0.5 MB: the only exposed communication
         self._join(works)
-        if gC is not None:
-            gC.replay()
+        self.opt_seg.run()
         return self.s_loss
 
     @property

@@ -194,11 +194,21 @@ def _conv_bn_relu(w, x, key, training, stride, pad):
                       key + ".bn", training))
 
 
-def attention_branch_forward(w, x, training, pre=""):
+def _tap(taps, name, t):
+    """Record an intermediate (and keep its gradient) for the in-situ parity tables; no-op without a dict."""
+    if taps is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        taps[name] = t
+    return t
+
+
+def attention_branch_forward(w, x, training, pre="", taps=None):
     """AttentionBranch.forward, cabinet.py:75-94."""
     feat = F.relu(_bn(w, F.conv2d(x, w[pre + "conva.0.weight"], None, 1, 1),
                       pre + "conva.1", training))
-    feat = cab_forward(w, feat, training, pre + "a2block.")
+    _tap(taps, "cab.x", feat)
+    feat = _tap(taps, "cab.y", cab_forward(w, feat, training, pre + "a2block."))
     low = F.conv2d(feat, w[pre + "convb.weight"], w[pre + "convb.bias"])
     fused = F.conv2d(torch.cat([x, feat], 1), w[pre + "b1.weight"], None, 1, 1)
     fused = F.relu(_bn(w, fused, pre + "b2", training))
@@ -206,20 +216,24 @@ def attention_branch_forward(w, x, training, pre=""):
     return low, high
 
 
-def cabinet_forward(w, x, mode, training):
-    """CABiNet.forward, cabinet.py:207-247.  Returns (final_logit, high_res_logit_up)."""
+def cabinet_forward(w, x, mode, training, taps=None):
+    """CABiNet.forward, cabinet.py:207-247.  Returns (final_logit, high_res_logit_up).
+    ``taps`` (a dict) receives the tensors either side of the CAB, the FFM and the two loss heads, with their gradients
+    retained -- the quantities the in-situ parity tests compare with what the HIP model saw at the same places."""
     hh, ww = x.shape[2:]
     sb = _conv_bn_relu(w, x, "sb.conv1", training, 2, 3)  # cabinet.py:111-114,126-129
     sb = _conv_bn_relu(w, sb, "sb.conv2", training, 2, 1)
     sb = _conv_bn_relu(w, sb, "sb.conv3", training, 2, 1)
     sb = _conv_bn_relu(w, sb, "sb.conv_out", training, 1, 0)
-    mob = _mobilenet(w, x, mode, training)
-    low, high = attention_branch_forward(w, mob, training, "ab.")
+    _tap(taps, "ffm.fsp", sb)
+    mob = _tap(taps, "mob", _mobilenet(w, x, mode, training))
+    low, high = attention_branch_forward(w, mob, training, "ab.", taps)
+    _tap(taps, "ffm.low", low)
     low_up = _bilinear(low, sb.shape[2:])
-    high_up = _bilinear(high, sb.shape[2:])
-    fuse = ffm_forward(w, sb, low_up, training, "ffm.")
+    high_up = _tap(taps, "head16.low", _bilinear(high, sb.shape[2:]))
+    fuse = _tap(taps, "ffm.y", ffm_forward(w, sb, low_up, training, "ffm."))
     final = _conv_bn_relu(w, fuse, "conv_out.conv", training, 1, 1)
-    final = F.conv2d(final, w["conv_out.conv_out.weight"])
+    final = _tap(taps, "head.low", F.conv2d(final, w["conv_out.conv_out.weight"]))
     return _bilinear(final, (hh, ww)), _bilinear(high_up, (hh, ww))
 
 
@@ -238,9 +252,9 @@ def ohem_ce(logits, labels, thresh, n_min, ignore_lb=255):
     return picked.mean()
 
 
-def train_step(w, x, labels, mode, thresh=0.7, ohem_divisor=16, ignore_lb=255):
+def train_step(w, x, labels, mode, thresh=0.7, ohem_divisor=16, ignore_lb=255, taps=None):
     """fwd + 2x OHEM-CE + bwd in fp32 (train.py:329-349,429-441 without autocast)."""
-    out, out16 = cabinet_forward(w, x, mode, training=True)
+    out, out16 = cabinet_forward(w, x, mode, training=True, taps=taps)
     b, _, hh, ww = x.shape
     n_min = max(1, b * hh * ww // ohem_divisor)
     loss = ohem_ce(out, labels, thresh, n_min, ignore_lb) + \

@@ -1,0 +1,129 @@
+"""In-situ capture for the GPU parity tests: what the REAL model feeds the hot path, and what comes back.
+
+``instrument(net)`` wraps, on this one model instance, the three places the section-8 hot path is entered --
+``ab.a2block`` (the CAB: K6 -> K1/K2 -> conv1x1 -> K5), ``ffm.forward_upsampled`` (the fused-upsample FFM) and the two
+low-resolution logits that enter the fused OHEM heads -- and records, with tensor hooks, every input, output and the
+gradients that the model's own backward sends through them.  ``replay_*`` then runs the fp64 (or fp32) CPU oracle ON EXACTLY
+THOSE TENSORS, so that an operator's own error is separated from whatever noise its inputs already carry (ReLU-mask flips
+upstream, MIOpen's convolutions): the comparison is operator-in / operator-out, in the model, at the size the model runs.
+
+Reference spans replayed: src/models/cab.py:131-162,182-184,213-216; src/models/cabinet.py:142-153 (+ :228-230);
+src/utils/loss.py:38-80 with cabinet.py:240-245.
+"""
+import torch
+
+from oracle import model_ref
+
+
+def instrument(net):
+    cap = {}
+
+    def keep(name, t):
+        cap[name] = t.detach().clone()
+        if t.requires_grad:
+            t.register_hook(lambda g, n=name: cap.__setitem__("d." + n, g.detach().clone()))
+        return t
+
+    cab, cab_fwd = net.ab.a2block, net.ab.a2block.forward
+    ffm_up, lowres = net.ffm.forward_upsampled, net.forward_lowres
+
+    def cab_forward(x):
+        keep("cab.x", x)
+        return keep("cab.y", cab_fwd(x))
+
+    def ffm_forward_upsampled(fsp, low):
+        keep("ffm.fsp", fsp)
+        keep("ffm.low", low)
+        return keep("ffm.y", ffm_up(fsp, low))
+
+    def forward_lowres(x, boundary=None):
+        final, high_up = lowres(x, boundary)
+        return keep("head.low", final), keep("head16.low", high_up)
+
+    cab.forward = cab_forward
+    net.ffm.forward_upsampled = ffm_forward_upsampled
+    net.forward_lowres = forward_lowres
+
+    def mobile_hook(module, args, out):
+        keep("mob", out)
+
+    net.mobile.register_forward_hook(mobile_hook)
+    return cap
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    den = float(b.norm())
+    return float((a - b).norm()) / den if den > 0 else float((a - b).norm())
+
+
+def _sub_state(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def replay_cab(sd, x, g, dtype):
+    """CAB oracle on a captured (input, output gradient): -> out, dx, {param: grad}  (keys relative to ab.a2block.)."""
+    w = model_ref.Weights(_sub_state(sd, "ab.a2block."), dtype=dtype)
+    xo = x.detach().cpu().to(dtype).requires_grad_(True)
+    y = model_ref.cab_forward(w, xo, True)
+    y.backward(g.detach().cpu().to(dtype))
+    return y.detach(), xo.grad, w.grads()
+
+
+def replay_ffm(sd, fsp, low, g, dtype):
+    """FFM(fsp, bilinear(low)) oracle: -> out, dfsp, dlow, {param: grad}  (keys relative to ffm.)."""
+    w = model_ref.Weights(_sub_state(sd, "ffm."), dtype=dtype)
+    fo = fsp.detach().cpu().to(dtype).requires_grad_(True)
+    lo = low.detach().cpu().to(dtype).requires_grad_(True)
+    y = model_ref.ffm_forward(w, fo, model_ref._bilinear(lo, fo.shape[2:]), True)
+    y.backward(g.detach().cpu().to(dtype))
+    return y.detach(), fo.grad, lo.grad, w.grads()
+
+
+def replay_head(low, labels, size, n_min, dtype, thresh=0.7):
+    """One loss head: OHEM-CE of the x8 bilinear upsample of the low-resolution logits: -> loss, dlow."""
+    lo = low.detach().cpu().to(dtype).requires_grad_(True)
+    loss = model_ref.ohem_ce(model_ref._bilinear(lo, size), labels.cpu(), thresh, n_min)
+    loss.backward()
+    return float(loss.detach()), lo.grad
+
+
+def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True):
+    """Every output, input gradient and parameter gradient of the three hot-path entries, as the model produced them,
+    against the fp64 oracle replayed on the model's own captured tensors.  rows: name -> {gpu_vs_f64[, cpu32_vs_f64], norm}"""
+    rows = {}
+
+    def put(name, gpu, f64, f32=None):
+        r = dict(gpu_vs_f64=rel(gpu, f64), norm=float(f64.double().norm()), numel=f64.numel())
+        if f32 is not None:
+            r["cpu32_vs_f64"] = rel(f32, f64)
+        rows[name] = r
+
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    dts = (torch.float64, torch.float32) if with_fp32 else (torch.float64,)
+    # ---- CAB
+    res = {dt: replay_cab(sd, cap["cab.x"], cap["d.cab.y"], dt) for dt in dts}
+    y64, dx64, g64 = res[torch.float64]
+    y32, dx32, g32 = res.get(torch.float32, (None, None, {}))
+    put("cab.out", cap["cab.y"], y64, y32)
+    put("cab.dx", cap["d.cab.x"], dx64, dx32)
+    for k, v in g64.items():
+        put("ab.a2block." + k, grads["ab.a2block." + k], v, g32.get(k))
+    # ---- FFM (fused upsample)
+    res = {dt: replay_ffm(sd, cap["ffm.fsp"], cap["ffm.low"], cap["d.ffm.y"], dt) for dt in dts}
+    y64, df64, dl64, g64 = res[torch.float64]
+    y32, df32, dl32, g32 = res.get(torch.float32, (None, None, None, {}))
+    put("ffm.out", cap["ffm.y"], y64, y32)
+    put("ffm.dfsp", cap["d.ffm.fsp"], df64, df32)
+    put("ffm.dlow", cap["d.ffm.low"], dl64, dl32)
+    for k, v in g64.items():
+        put("ffm." + k, grads["ffm." + k], v, g32.get(k))
+    del res
+    # ---- the two fused OHEM heads (upstream gradient of each is exactly 1: loss = head + head16)
+    losses = {}
+    for name in ("head", "head16"):
+        l64, d64 = replay_head(cap[name + ".low"], labels, size, n_min, torch.float64)
+        l32, d32 = replay_head(cap[name + ".low"], labels, size, n_min, torch.float32) if with_fp32 else (None, None)
+        put(name + ".dlow", cap["d." + name + ".low"], d64, d32)
+        losses[name] = (l64, l32)
+    return rows, losses

@@ -21,7 +21,34 @@ import pytest
 import torch
 
 from conftest import assert_close
+from insitu import instrument, rel
 from parity_rules import TOL, ALLOW_FACTOR, gradient_table, host_memory_gb, judge_gradients, load_allowlist, rel_pair, write_table
+
+TAPS = ("mob", "cab.x", "cab.y", "ffm.fsp", "ffm.low", "ffm.y", "head.low", "head16.low")
+
+
+def _tap_copies(taps):
+    """Detached copies of the oracle's tapped tensors and their gradients (the autograd graph can then be freed)."""
+    out = {}
+    for k, t in taps.items():
+        out[k] = t.detach().clone()
+        if t.grad is not None:
+            out["d." + k] = t.grad.detach().clone()
+    return out
+
+
+def _hip_cab_on(sd, x, g):
+    """The HIP CAB alone (K6 -> K1/K2 -> conv1x1 -> K5) on given input / output gradient: -> out, dx, parameter gradients."""
+    from cabinet_amd.models.cab import ContextAggregationBlock
+
+    cab = ContextAggregationBlock(256, 128)
+    cab.load_state_dict({k[len("ab.a2block."):]: v for k, v in sd.items() if k.startswith("ab.a2block.")})
+    cab = cab.cuda().train()
+    xd = x.float().cuda().requires_grad_(True)
+    y = cab(xd)
+    y.backward(g.float().cuda())
+    torch.cuda.synchronize()
+    return y.detach().cpu(), xd.grad.cpu(), {"ab.a2block." + k: p.grad.cpu() for k, p in cab.named_parameters()}
 
 pytestmark = pytest.mark.gpu
 
@@ -46,9 +73,11 @@ def _full_step(mode, batch, height, width, ncls, tag):
         out, out16 = probe(im.cuda())  # materialised full-resolution logits (the step itself never builds them)
     out, out16 = out.cpu(), out16.cpu()
     del probe
+    cap = instrument(net)  # what the model feeds the hot path and what comes back, in place (tests/insitu.py)
     step = TrainStep(net, make_criteria(batch, height, width, "cuda"))
     loss = float(step(im.cuda(), lb.cuda()))
     torch.cuda.synchronize()
+    cap = {k: v.cpu() for k, v in cap.items()}
     grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
     bufs_gpu = {k: v.detach().cpu() for k, v in net.state_dict().items() if "running_" in k}
     net = net.cpu()
@@ -57,24 +86,41 @@ def _full_step(mode, batch, height, width, ncls, tag):
     torch.cuda.empty_cache()
 
     w32 = model_ref.Weights(sd)
-    out_ref, out16_ref, loss_ref = model_ref.train_step(w32, im, lb, mode)
+    taps32 = {}
+    out_ref, out16_ref, loss_ref = model_ref.train_step(w32, im, lb, mode, taps=taps32)
+    taps32 = _tap_copies(taps32)
     e, d = rel_pair(out, out_ref)
     e16, d16 = rel_pair(out16, out16_ref)
     ref32 = {k: v.clone() for k, v in w32.grads().items()}
     bufs_ref = {k: v.clone() for k, v in w32.buffers().items()}
     del w32, out_ref, out16_ref, out, out16
     w64 = model_ref.Weights(sd, dtype=torch.float64)
-    _, _, loss64 = model_ref.train_step(w64, im.double(), lb, mode)
+    taps64 = {}
+    _, _, loss64 = model_ref.train_step(w64, im.double(), lb, mode, taps=taps64)
+    taps64 = _tap_copies(taps64)
     ref64 = w64.grads()
     rows = gradient_table(net, ref32, ref64)
     failures, listed = judge_gradients(rows, load_allowlist()[tag])
     worst = sorted(((r["gpu_vs_f64"], k) for k, r in rows.items() if not r["analytic_zero"]), reverse=True)[:10]
+    # Where the gradient noise enters: distance from the fp64 model of every tensor either side of the
+    # hot path, for the HIP model and for the fp32 CPU reference ...
+    chain = {}
+    for name in TAPS:
+        for k in (name, "d." + name):
+            chain[k] = dict(gpu_vs_f64=rel(cap[k], taps64[k]), ref32_vs_f64=rel(taps32[k], taps64[k]))
+    # ... and the HIP CAB run on the fp64 MODEL's own input and incoming gradient (rounded to fp32): its parameter gradients
+    # against the fp64 model's.  Small here + large in `tensors` = the operator is exact and its inputs carry the noise.
+    y, dx, gcab = _hip_cab_on(sd, taps64["cab.x"], taps64["d.cab.y"])
+    cross = {"cab.out": rel(y, taps64["cab.y"]), "cab.dx": rel(dx, taps64["d.cab.x"])}
+    cross.update({k: rel(v, ref64[k]) for k, v in gcab.items() if float(ref64[k].norm()) > 1e-9})
+    del taps32, taps64
     write_table(f"parity_{tag}.json", dict(
         config=dict(mode=mode, batch=batch, height=height, width=width, n_classes=ncls, gamma=0.5, model_seed=0,
                     data_seed=1),
         logits_rel=e / d, logits16_rel=e16 / d16, loss_gpu=loss, loss_ref32=float(loss_ref), loss_f64=float(loss64),
         tolerance=TOL, allow_factor=ALLOW_FACTOR, rule=load_allowlist()[tag],
-        past_1e3_within_bound=listed, failures=[k for k, _ in failures], worst_vs_f64=worst, tensors=rows))
+        past_1e3_within_bound=listed, failures=[k for k, _ in failures], worst_vs_f64=worst,
+        chain_either_side_of_the_hot_path=chain, hip_cab_on_fp64_model_inputs=cross, tensors=rows))
     assert e <= TOL * d, f"final_logit rel {e / d:.3e}"
     assert e16 <= TOL * d16, f"high_res_logit_up rel {e16 / d16:.3e}"
     assert abs(loss - float(loss_ref)) <= TOL * abs(float(loss_ref)), (loss, float(loss_ref))
