@@ -12,7 +12,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcabinet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
@@ -71,8 +71,10 @@ SIGNATURES = {
     "cabinet_dwconv_bwd_workspace_bytes": (_SZ, [_INT] * 6),
     "cabinet_dwconv_bwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
     "cabinet_cab_local_supported": (_INT, [_INT] * 4),
-    "cabinet_cab_local_fwd": (_INT, [_PTR] * 3 + [_PTR] * 5 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR]),
-    "cabinet_cab_local_bwd": (_INT, [_PTR] * 4 + [_PTR] * 3 + [_PTR] * 2 + [_INT] * 5 + [_PTR] * 3 + [_PTR] * 3 + [_PTR]),
+    "cabinet_cab_local_fwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_cab_local_bwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_cab_local_fwd": (_INT, [_PTR] * 3 + [_PTR] * 5 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
+    "cabinet_cab_local_bwd": (_INT, [_PTR] * 4 + [_PTR] * 3 + [_PTR] * 2 + [_INT] * 5 + [_PTR] * 3 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
 }
 
 _lock = threading.Lock()

@@ -361,16 +361,12 @@ bool local_shape_supported(int B, int H, int W) {
 
 hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream) {
     const size_t lds = local_lds_fwd(a.B, a.H, a.W);
-    static size_t attr = 0;
-    if (lds > attr) {
-        for (const void* f : {reinterpret_cast<const void*>(cab_local_fwd_kernel<0>),
-                              reinterpret_cast<const void*>(cab_local_fwd_kernel<1>),
-                              reinterpret_cast<const void*>(cab_local_fwd_kernel<2>)}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        attr = lds;
-    }
+    // the attribute is per device and a smaller later value would shrink it: always ask for the kernel family's maximum
+    static lds_attr_mask attr_mask[3] = {{0}, {0}, {0}};
+    const void* fns[3] = {reinterpret_cast<const void*>(cab_local_fwd_kernel<0>), reinterpret_cast<const void*>(cab_local_fwd_kernel<1>),
+                          reinterpret_cast<const void*>(cab_local_fwd_kernel<2>)};
+    for (int i = 0; i < 3; ++i)
+        if (hipError_t e = ensure_dynamic_lds(fns[i], 160 * 1024, attr_mask[i]); e != hipSuccess) return e;
     const int n = a.H * a.W;
     auto kernel = n == LOC_T ? cab_local_fwd_kernel<1> : n == 2 * LOC_T ? cab_local_fwd_kernel<2> : cab_local_fwd_kernel<0>;
     hipLaunchKernelGGL(kernel, dim3(a.C), dim3(LOC_T), lds, stream, a);
@@ -379,16 +375,12 @@ hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream) {
 
 hipError_t cab_local_bwd_run(const LocalArgs& a, hipStream_t stream) {
     const size_t lds = local_lds_bwd(a.B, a.H, a.W);
-    static size_t attr = 0;
-    if (lds > attr) {
-        for (const void* f : {reinterpret_cast<const void*>(cab_local_bwd_kernel<0>),
-                              reinterpret_cast<const void*>(cab_local_bwd_kernel<1>),
-                              reinterpret_cast<const void*>(cab_local_bwd_kernel<2>)}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        attr = lds;
-    }
+    // the attribute is per device and a smaller later value would shrink it: always ask for the kernel family's maximum
+    static lds_attr_mask attr_mask[3] = {{0}, {0}, {0}};
+    const void* fns[3] = {reinterpret_cast<const void*>(cab_local_bwd_kernel<0>), reinterpret_cast<const void*>(cab_local_bwd_kernel<1>),
+                          reinterpret_cast<const void*>(cab_local_bwd_kernel<2>)};
+    for (int i = 0; i < 3; ++i)
+        if (hipError_t e = ensure_dynamic_lds(fns[i], 160 * 1024, attr_mask[i]); e != hipSuccess) return e;
     const int n = a.H * a.W;
     auto kernel = n == LOC_T ? cab_local_bwd_kernel<1> : n == 2 * LOC_T ? cab_local_bwd_kernel<2> : cab_local_bwd_kernel<0>;
     hipLaunchKernelGGL(kernel, dim3(a.C), dim3(LOC_T), lds, stream, a);

@@ -32,8 +32,15 @@ struct LocalArgs {
     float* dgamma_part;    // bwd, (C) partial sums of <dout, glob>, nullable
 };
 
+// resident form (cab_local.hip): one workgroup per channel, B*H*W <= 8192
 bool local_shape_supported(int B, int H, int W);
 hipError_t cab_local_fwd_run(const LocalArgs& a, hipStream_t stream);
 hipError_t cab_local_bwd_run(const LocalArgs& a, hipStream_t stream);
+// tiled form (cab_local_tiled.hip): any B*H*W, B*nT workgroups per channel, two-phase BatchNorm reductions, workspace
+bool local_tiled_supported(int B, int H, int W);
+size_t local_tiled_fwd_workspace(int B, int C, int H, int W);
+size_t local_tiled_bwd_workspace(int B, int C, int H, int W);
+hipError_t cab_local_tiled_fwd_run(const LocalArgs& a, void* ws, hipStream_t stream);
+hipError_t cab_local_tiled_bwd_run(const LocalArgs& a, void* ws, hipStream_t stream);
 
 }  // namespace cabinet

@@ -353,26 +353,45 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
 }
 
 // ------------------------------------------------------ CAB local branch + block output
+// two forms behind one entry point: the channel-resident kernel (B*H*W <= 8192, no workspace) and the tiled
+// multi-workgroup-per-channel form for everything larger (cab_local_tiled.hip)
 static int check_local(int B, int C, int H, int W) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(CABINET_ERR_INVALID_ARG, "cab_local: non-positive dimension");
-    if (!cabinet::local_shape_supported(B, H, W))
-        return fail(CABINET_ERR_UNSUPPORTED, "cab_local: B*H*W = %lld exceeds the 8192 elements one channel may occupy",
-                    (long long)B * H * W);
+    if (C > 65535) return fail(CABINET_ERR_UNSUPPORTED, "cab_local: C = %d exceeds the grid's 65535 channels", C);
+    if (!cabinet::local_shape_supported(B, H, W) && !cabinet::local_tiled_supported(B, H, W))
+        return fail(CABINET_ERR_UNSUPPORTED, "cab_local: %d x %d x %d planes fit neither the resident nor the tiled form", B, H, W);
     return CABINET_OK;
 }
 
 int cabinet_cab_local_supported(int B, int C, int H, int W) {
-    return B > 0 && C > 0 && H > 0 && W > 0 && cabinet::local_shape_supported(B, H, W) ? 1 : 0;
+    return B > 0 && C > 0 && C <= 65535 && H > 0 && W > 0 &&
+                   (cabinet::local_shape_supported(B, H, W) || cabinet::local_tiled_supported(B, H, W))
+               ? 1
+               : 0;
+}
+
+size_t cabinet_cab_local_fwd_workspace_bytes(int B, int C, int H, int W) {
+    if (!cabinet_cab_local_supported(B, C, H, W) || cabinet::local_shape_supported(B, H, W)) return 0;
+    return cabinet::local_tiled_fwd_workspace(B, C, H, W);
+}
+
+size_t cabinet_cab_local_bwd_workspace_bytes(int B, int C, int H, int W) {
+    if (!cabinet_cab_local_supported(B, C, H, W) || cabinet::local_shape_supported(B, H, W)) return 0;
+    return cabinet::local_tiled_bwd_workspace(B, C, H, W);
 }
 
 int cabinet_cab_local_fwd(const float* x, const float* glob, const float* gamma, const float* const* dw_w,
                           const float* const* bn_weight, const float* const* bn_bias, float* const* running_mean,
                           float* const* running_var, int B, int C, int H, int W, int training, float momentum,
-                          float eps, float* out, float* save_mean, float* save_invstd, cabinet_stream_t stream) {
+                          float eps, float* out, float* save_mean, float* save_invstd, void* workspace,
+                          size_t workspace_bytes, cabinet_stream_t stream) {
     if (int rc = check_local(B, C, H, W)) return rc;
     if (!x || !out || !save_mean || !save_invstd || !dw_w || !bn_weight || !bn_bias || !running_mean || !running_var)
         return fail(CABINET_ERR_INVALID_ARG, "cab_local_fwd: null tensor pointer");
     if (glob && !gamma) return fail(CABINET_ERR_INVALID_ARG, "cab_local_fwd: glob given without gamma");
+    const size_t need = cabinet_cab_local_fwd_workspace_bytes(B, C, H, W);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "cab_local_fwd: workspace %zu < %zu", workspace_bytes, need);
     cabinet::LocalArgs a{};
     a.x = x, a.glob = glob, a.gamma = gamma;
     for (int s = 0; s < 3; ++s) {
@@ -383,6 +402,7 @@ int cabinet_cab_local_fwd(const float* x, const float* glob, const float* gamma,
     }
     a.B = B, a.C = C, a.H = H, a.W = W, a.training = training, a.momentum = momentum, a.eps = eps;
     a.out = out, a.save_mean = save_mean, a.save_invstd = save_invstd;
+    if (need) return hip_status(cabinet::cab_local_tiled_fwd_run(a, workspace, static_cast<hipStream_t>(stream)), "cab_local_fwd launch");
     return hip_status(cabinet::cab_local_fwd_run(a, static_cast<hipStream_t>(stream)), "cab_local_fwd launch");
 }
 
@@ -390,13 +410,16 @@ int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, 
                           const float* const* dw_w, const float* const* bn_weight, const float* const* bn_bias,
                           const float* save_mean, const float* save_invstd, int B, int C, int H, int W, int training,
                           float* dx, float* dglob, float* dgamma_part, float* const* ddw_w, float* const* dbn_weight,
-                          float* const* dbn_bias, cabinet_stream_t stream) {
+                          float* const* dbn_bias, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
     if (int rc = check_local(B, C, H, W)) return rc;
     if (!dout || !x || !dx || !save_mean || !save_invstd || !dw_w || !bn_weight || !bn_bias || !ddw_w || !dbn_weight ||
         !dbn_bias)
         return fail(CABINET_ERR_INVALID_ARG, "cab_local_bwd: null tensor pointer");
     if (glob && (!gamma || !dglob || !dgamma_part))
         return fail(CABINET_ERR_INVALID_ARG, "cab_local_bwd: glob given without gamma / dglob / dgamma_part");
+    const size_t need = cabinet_cab_local_bwd_workspace_bytes(B, C, H, W);
+    if (need && (!workspace || workspace_bytes < need))
+        return fail(CABINET_ERR_WORKSPACE, "cab_local_bwd: workspace %zu < %zu", workspace_bytes, need);
     cabinet::LocalArgs a{};
     a.x = x, a.glob = glob, a.gamma = gamma, a.dout = dout;
     for (int s = 0; s < 3; ++s) {
@@ -408,6 +431,7 @@ int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, 
     a.B = B, a.C = C, a.H = H, a.W = W, a.training = training;
     a.save_mean = const_cast<float*>(save_mean), a.save_invstd = const_cast<float*>(save_invstd);
     a.dx = dx, a.dglob = dglob, a.dgamma_part = dgamma_part;
+    if (need) return hip_status(cabinet::cab_local_tiled_bwd_run(a, workspace, static_cast<hipStream_t>(stream)), "cab_local_bwd launch");
     return hip_status(cabinet::cab_local_bwd_run(a, static_cast<hipStream_t>(stream)), "cab_local_bwd launch");
 }
 

@@ -13,9 +13,10 @@ ONE dispatch rule for every operator here:
   * device tensor, shape inside the kernel family's coverage (each family exports ``*_supported``): the hand-written
     HIP kernels run; a missing / mismatching library or a failing launch raises RuntimeError -- nothing is caught and
     retried on another path;
-  * device tensor, shape outside the coverage (attention channel pairs other than (128,128) (256,128) (64,64); the local
-    branch above 8192 positions per channel; producers with channel counts that are not multiples of 16; depthwise
-    kernels other than 3 / 5): the module's composite ATen forward, on the device -- the reference API accepts any
+  * device tensor, shape outside the coverage (attention channel pairs other than (128,128) (256,128) (64,64); producers
+    with channel counts that are not multiples of 16; depthwise kernels other than 3 / 5; the local branch only for planes
+    wider than its LDS tile, > ~1800 columns -- every B*H*W is served: channel-resident kernel up to 8192 positions per
+    channel, tiled multi-workgroup form above): the module's composite ATen forward, on the device -- the reference API accepts any
     channel count, so must this one;
   * host (CPU) tensors: the composite ATen forward, so modules stay usable for checkpoint surgery, EMA copies and CPU
     unit tests, exactly like any nn.Module.
@@ -413,10 +414,12 @@ def cab_local_fwd_hip(x, glob, gamma, dw_w, bn_w, bn_b, run_mean, run_var, train
     out = torch.empty_like(x)
     mean = torch.empty((3, C), dtype=torch.float32, device=x.device)
     invstd = torch.empty((3, C), dtype=torch.float32, device=x.device)
+    ws, nbytes = _workspace(lib.cabinet_cab_local_fwd_workspace_bytes(B, C, H, W), x.device)  # 0 for the resident form
     with torch.cuda.device(x.device):
         rc = lib.cabinet_cab_local_fwd(_ptr(x), _ptr(glob), _ptr(gamma), _ptr3(dw_w), _ptr3(bn_w), _ptr3(bn_b),
                                        _ptr3(run_mean), _ptr3(run_var), B, C, H, W, int(training), float(momentum),
-                                       float(eps), _ptr(out), _ptr(mean), _ptr(invstd), _stream_handle(x.device))
+                                       float(eps), _ptr(out), _ptr(mean), _ptr(invstd), _ptr(ws), nbytes,
+                                       _stream_handle(x.device))
     _lib.check(rc, "cabinet_cab_local_fwd")
     return out, mean, invstd
 
@@ -430,11 +433,12 @@ def cab_local_bwd_hip(g, x, glob, gamma, dw_w, bn_w, bn_b, mean, invstd, trainin
     ddw = [torch.empty_like(w) for w in dw_w]
     dbw = [torch.empty_like(w) for w in bn_w]
     dbb = [torch.empty_like(w) for w in bn_b]
+    ws, nbytes = _workspace(lib.cabinet_cab_local_bwd_workspace_bytes(B, C, H, W), x.device)
     with torch.cuda.device(x.device):
         rc = lib.cabinet_cab_local_bwd(_ptr(g), _ptr(x), _ptr(glob), _ptr(gamma), _ptr3(dw_w), _ptr3(bn_w),
                                        _ptr3(bn_b), _ptr(mean), _ptr(invstd), B, C, H, W, int(training), _ptr(dx),
                                        _ptr(dglob), _ptr(dgamma_part), _ptr3(ddw), _ptr3(dbw), _ptr3(dbb),
-                                       _stream_handle(x.device))
+                                       _ptr(ws), nbytes, _stream_handle(x.device))
     _lib.check(rc, "cabinet_cab_local_bwd")
     return dx, dglob, dgamma_part, ddw, dbw, dbb
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CABINET_ABI_VERSION 2
+#define CABINET_ABI_VERSION 3
 
 #define CABINET_OK 0
 #define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
@@ -169,11 +169,15 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
                         float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
- * CAB local branch + block output, one kernel each way.
+ * CAB local branch + block output.
  * Replaces src/models/cab.py:175-184 (LocalAttention.forward: three DWConv = depthwise 3x3 conv (cab.py:36-45)
  * + BatchNorm2d + ReLU, sigmoid gate, x + x*mask) and, when `glob` is given, cab.py:213-216
  * (ContextAggregationBlock.forward: gamma * global + local).
- *   x, glob, out, dout, dx, dglob : (B,C,H,W);  B*H*W <= 8192 (one channel lives in the LDS of one CU)
+ *   x, glob, out, dout, dx, dglob : (B,C,H,W).  Two forms behind the same entry points:
+ *     B*H*W <= 8192  : one kernel each way, one channel lives in the LDS of one CU, no workspace (..._workspace_bytes = 0)
+ *     anything larger: (e.g. B = 16 at 1024^2, or the un-tiled 4096x2160 validation frame of src/scripts/train.py:444-456,
+ *                      n = 8704) tiled form, B * ceil(H / rows) workgroups per channel, BatchNorm batch statistics as
+ *                      two-phase ordered reductions: 4 launches forward, 8 backward, workspace from ..._workspace_bytes
  *   dw_w[s] (C,9) depthwise weights (C,1,3,3), bn_weight[s] / bn_bias[s] / running_mean[s] / running_var[s] (C),
  *   s = 0..2: HOST arrays of three DEVICE pointers (the three DWConv stages own separate parameter tensors)
  *   gamma : device scalar (cab.py:208); glob == NULL  ->  out = x * (1 + sigmoid(mask)) only (gamma, dglob and
@@ -185,19 +189,22 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
  *         dgamma_part (C) = per-channel <dout, glob> (caller sums it: d gamma), ddw_w[s] (C,9),
  *         dbn_weight[s], dbn_bias[s] (C).  Deterministic (no atomics).
  * ------------------------------------------------------------------------- */
-int cabinet_cab_local_supported(int B, int C, int H, int W);   /* 1 if the shape fits, else 0 */
+int cabinet_cab_local_supported(int B, int C, int H, int W);   /* 1 if one of the two forms serves the shape, else 0 */
+size_t cabinet_cab_local_fwd_workspace_bytes(int B, int C, int H, int W);   /* 0 for the channel-resident form */
+size_t cabinet_cab_local_bwd_workspace_bytes(int B, int C, int H, int W);
 int cabinet_cab_local_fwd(const float* x, const float* glob, const float* gamma,
                           const float* const* dw_w, const float* const* bn_weight, const float* const* bn_bias,
                           float* const* running_mean, float* const* running_var,
                           int B, int C, int H, int W, int training, float momentum, float eps,
-                          float* out, float* save_mean, float* save_invstd, cabinet_stream_t stream);
+                          float* out, float* save_mean, float* save_invstd,
+                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 int cabinet_cab_local_bwd(const float* dout, const float* x, const float* glob, const float* gamma,
                           const float* const* dw_w, const float* const* bn_weight, const float* const* bn_bias,
                           const float* save_mean, const float* save_invstd,
                           int B, int C, int H, int W, int training,
                           float* dx, float* dglob, float* dgamma_part,
                           float* const* ddw_w, float* const* dbn_weight, float* const* dbn_bias,
-                          cabinet_stream_t stream);
+                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * q/k/v producers of the CAB global branch (1x1 projections + BatchNorm + ReLU + pyramid pooling).

@@ -67,7 +67,7 @@ def _insitu(mode, batch, height, width, ncls, tag):
         tensors=rows))
     assert abs(float(loss) - loss64) <= 1e-5 * abs(loss64), (float(loss), loss64)
     assert not bad, {k: {n: (f"{v:.2e}" if isinstance(v, float) else v) for n, v in r.items()} for k, r in bad.items()}
-    assert len(rows) == 2 + 18 + 3 + 5 + 2, sorted(rows)
+    assert len(rows) == 2 + 20 + 3 + 5 + 2, sorted(rows)
 
 
 @pytest.mark.timeout(1800)

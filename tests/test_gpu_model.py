@@ -265,11 +265,84 @@ def test_graphed_train_step_equals_eager():
         assert_close(sb[k].double(), sa[k].double(), 2e-3, k, atol=1e-5)
 
 
+class _WarmupPolyOptimizer:
+    """The shape of the reference's optimizer wrapper (src/utils/optimizer.py:141-155): ``step()`` computes the learning
+    rate on the HOST from its own step counter (linear warm-up, then polynomial decay), writes it into the param groups and
+    only then steps SGD."""
+
+    def __init__(self, params, lr0=2e-2, warmup_steps=2, max_iter=10, power=0.9):
+        self.opt = torch.optim.SGD(params, lr=lr0, momentum=0.9, weight_decay=5e-4)
+        self.lr0, self.warmup_steps, self.max_iter, self.power, self.it = lr0, warmup_steps, max_iter, power, 0
+        self.lrs = []
+
+    def step(self):
+        if self.it < self.warmup_steps:
+            lr = self.lr0 * (self.it + 1) / (self.warmup_steps + 1)
+        else:
+            lr = self.lr0 * (1 - (self.it - self.warmup_steps) / (self.max_iter - self.warmup_steps)) ** self.power
+        for pg in self.opt.param_groups:
+            pg["lr"] = lr
+        self.lrs.append(lr)
+        self.opt.step()
+        self.it += 1
+
+
+def test_graphed_step_follows_a_host_side_lr_schedule_and_clipping():
+    """a captured ``optimizer.step()`` bakes lr / weight decay / momentum into the graph and freezes a
+    Python-side schedule at its capture-time value.  The graphed steps therefore run the optimizer (and an optional
+    gradient-clipping callback, reference train.py:411-427) EAGERLY after the backward graph: six steps of warm-up + poly decay
+    through GraphedTrainStep equal the eager TrainStep, learning rates included; capturing the optimizer is opt-in, refuses a
+    wrapper object, and raises when a hyper-parameter has moved since capture."""
+    from cabinet_amd.train import GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
+
+    batches = [synthetic_batch(2, 256, 256, 8, "cuda", seed=40 + i) for i in range(6)]
+    res = []
+    for graphed in (False, True):
+        net = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = _WarmupPolyOptimizer(params)
+        norms = []
+
+        def clip(params=params, norms=norms):
+            norms.append(float(torch.nn.utils.clip_grad_norm_(params, 1.0)))
+
+        crit = make_criteria(2, 256, 256, "cuda")
+        step = (GraphedTrainStep(net, crit, optimizer=opt, warmup=2, before_optimizer=clip) if graphed
+                else TrainStep(net, crit, optimizer=opt, before_optimizer=clip))
+        losses = [float(step(*b)) for b in batches]
+        if graphed:
+            assert step.g_bwd is not None and step.fallbacks == 0 and step.opt_seg.graph is None
+        res.append((losses, opt.lrs, norms, {k: v.clone() for k, v in net.state_dict().items()}))
+    (la, lra, na, sa), (lb_, lrb, nb, sb) = res
+    assert lra == lrb and len(set(lra)) == 6          # six different learning rates reached the kernels on both paths
+    assert len(na) == len(nb) == 6
+    for x, y in zip(la + na, lb_ + nb):
+        assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (la, lb_, na, nb)
+    for k in sa:
+        assert_close(sb[k].double(), sa[k].double(), 2e-3, k, atol=1e-5)
+    # opt-in capture: plain torch optimizer only, and a changed hyper-parameter raises instead of being ignored
+    net = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
+    with pytest.raises(RuntimeError, match="wrapper"):
+        GraphedTrainStep(net, make_criteria(2, 256, 256, "cuda"), optimizer=_WarmupPolyOptimizer(params), capture_optimizer=True)
+    sgd = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-2, momentum=0.9)
+    step = GraphedTrainStep(net, make_criteria(2, 256, 256, "cuda"), optimizer=sgd, warmup=1, capture_optimizer=True)
+    for b in batches[:3]:
+        step(*b)
+    assert step.opt_seg.graph is not None
+    sgd.param_groups[0]["lr"] = 5e-3
+    with pytest.raises(RuntimeError, match="hyper-parameters changed"):
+        step(*batches[3])
+    # a batch of another shape is refused (copy_ into the static input would broadcast a single image over the batch)
+    with pytest.raises(RuntimeError, match="does not match the captured"):
+        step(batches[0][0][:1], batches[0][1][:1])
+
+
 def test_one_dispatch_rule_for_shapes_outside_kernel_coverage():
     """Device tensors with shapes no kernel family covers take the composite ATen forward ON THE DEVICE (never an error,
-    never the host): ContextAggregationBlock(96, 48) -- attention pair (48,48), producers with 48 channels -- and the
-    un-tiled UAVid validation frame's CAB grid (1 x 256 x 68 x 128 = 8704 positions > K5's 8192) where attention and the
-    producers still run the HIP kernels.  Both agree with the functional oracle (reference cab.py:192-216)."""
+    never the host): ContextAggregationBlock(96, 48) -- attention pair (48,48), producers with 48 channels.  The un-tiled
+    UAVid validation frame's CAB grid (1 x 256 x 68 x 128 = 8704 positions, reference train.py:444-456) is INSIDE the coverage
+    since round 3 (K5's tiled form): attention, producers and the local branch all run the HIP kernels.  Both agree with the
+    functional oracle (reference cab.py:192-216)."""
     from cabinet_amd import _lib
     from cabinet_amd.functional import cab_attention, cab_attention_supported, cab_local_supported
     from cabinet_amd.models.cab import ContextAggregationBlock
@@ -305,6 +378,6 @@ def test_one_dispatch_rule_for_shapes_outside_kernel_coverage():
         return xd
 
     run(96, 48, 2, 12, 10, 4)        # everything composite (48 channels)
-    xd = run(256, 128, 1, 68, 128, 5)  # n = 8704: K5 composite, K6 + K1/K2 native
-    assert not cab_local_supported(xd) and "libcabinet_hip.so" in open("/proc/self/maps").read()
+    xd = run(256, 128, 1, 68, 128, 5)  # n = 8704: K5 tiled form, K6 + K1/K2 native
+    assert cab_local_supported(xd) and "libcabinet_hip.so" in open("/proc/self/maps").read()
     assert _lib.load().cabinet_cab_attn_supported(128, 128) == 1
