@@ -210,8 +210,8 @@ def attention_branch_forward(w, x, training, pre="", taps=None):
     _tap(taps, "cab.x", feat)
     feat = _tap(taps, "cab.y", cab_forward(w, feat, training, pre + "a2block."))
     low = F.conv2d(feat, w[pre + "convb.weight"], w[pre + "convb.bias"])
-    fused = F.conv2d(torch.cat([x, feat], 1), w[pre + "b1.weight"], None, 1, 1)
-    fused = F.relu(_bn(w, fused, pre + "b2", training))
+    fused = _tap(taps, "ab.b1o", F.conv2d(torch.cat([x, feat], 1), w[pre + "b1.weight"], None, 1, 1))
+    fused = _tap(taps, "ab.r", F.relu(_bn(w, fused, pre + "b2", training)))
     high = F.conv2d(fused, w[pre + "b4.weight"], w[pre + "b4.bias"])
     return low, high
 

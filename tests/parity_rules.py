@@ -2,25 +2,28 @@
 
 What fp32 can and cannot promise for the gradients of this network (measured):
 
-* every hand-written operator reproduces its fp64 oracle to 1e-7 .. 5e-6 on the tensors the model feeds it
-  (tools/diag_*.py, the operator tests);
+* every hand-written operator reproduces its fp64 oracle to 1e-7 .. 5e-6 ON THE TENSORS THE MODEL FEEDS IT -- asserted in the
+  test tier itself since round 3: tests/test_gpu_insitu.py captures input and incoming gradient of the CAB, the fused FFM
+  and both OHEM heads inside the real step at BASELINE configs 3 and 5 and replays the fp64 oracle on them;
 * the gradient of a ReLU network is a DISCONTINUOUS function of the forward rounding: a pre-activation within rounding
   distance of zero lands on the other side and the gradient through that unit toggles.  With a forward relative error d the
   fraction of flipped units is ~0.8 d, so on big maps the gradient moves by ~sqrt(0.8 d) per ReLU layer (4.5e-4 for the CPU
   reference's d = 2.5e-7, 9e-4 for MIOpen's convolutions at d = 1e-6), and on the CAB's small maps ONE flipped unit of N
-  positions x 256 channels moves everything upstream by ~1/sqrt(256 N) (2e-3 at N = 1024, found unit by unit with
-  tools/diag_cab_internal.py).  The fp32 CPU reference itself is therefore 1e-3 .. 4e-3 from the fp64 oracle on most
-  gradient tensors of the full-size configurations (profiles/r02_parity_config*.json).
+  positions x 256 channels moves everything behind it by ~1/sqrt(256 N).  The fp32 CPU reference itself is therefore
+  1e-3 .. 4e-3 from the fp64 oracle on most gradient tensors of the full-size configurations (profiles/r03_parity_config*.json,
+  column ref32_vs_f64; `relu_mask_flips_vs_f64` counts the flipped units either side of the CAB for both implementations).
 
-Rule, per gradient tensor (no blanket bound):
+Rule, per gradient tensor -- no per-configuration floor, no blanket bound:
   pass  if within TOL = 1e-3 of the fp32 reference, or of the fp64 oracle;
-  else  the distance from the fp64 oracle must not exceed
-            max( ALLOW_FACTOR x the fp32 reference's own distance from fp64 on this tensor (measured live),
-                 ALLOW_FACTOR x the committed 90th percentile of that distance over the configuration's tensors,
-                 FLIPS / sqrt(256 x CAB positions)   -- three single-unit ReLU flips on the CAB grid )
-  i.e. "as close to the truth as the reference's own fp32 arithmetic is".  The two committed numbers per configuration
-  live in tests/golden/grad_allowlist.json (measured; tests/test_oracle_golden.py limits what may be written there), and
-  every run writes the full per-tensor table (gpurun_out/parity_<tag>.json)."""
+  else  its distance from the fp64 oracle must not exceed ALLOW_FACTOR x the fp32 reference's OWN distance from fp64 ON THIS
+        TENSOR, measured live ("as close to the truth as the reference's own fp32 arithmetic is on this tensor");
+  else  the tensor must be NAMED in tests/golden/grad_allowlist.json[tag]["tensors"] with its measured numbers, and is then
+        bounded by the effect of FLIPS single-unit ReLU flips on the CAB grid, FLIPS / sqrt(256 x CAB positions).  Only
+        parameters inside the CAB may be listed (tests/test_oracle_golden.py enforces names, count and sizes): those are the
+        tensors for which the in-situ tests prove the kernels exact on the model's own inputs, so that what remains is the
+        incoming gradient's flip noise (config 5: d(cab.y) is 2.1e-3 from fp64 on the GPU and 5.9e-4 on the CPU at ~1 flipped
+        unit per million either way -- and the reverse, 4.9e-4 vs 2.1e-3, at config 3).
+Every run writes the full per-tensor table (gpurun_out/parity_<tag>.json; committed copies under profiles/)."""
 import json
 import os
 
@@ -29,7 +32,7 @@ from conftest import GOLDEN, ROOT
 TOL = 1e-3  # north_star: 1e-3 relative (||a-b||/||b|| per tensor), fp32
 ALLOW_FACTOR = 3.0
 FLIPS = 3.0            # single-unit ReLU flips on the CAB grid the bound makes room for
-MAX_REF_P90 = 5e-3     # a configuration whose reference is further than this from fp64 is not a parity test
+MAX_NAMED = 8          # named exceptions per configuration
 MAX_BOUND = 1.5e-2     # no tensor is ever allowed further than this from the fp64 oracle
 
 
@@ -85,11 +88,15 @@ def gradient_table(net, ref32, ref64):
     return rows
 
 
-def tensor_bound(row, cfg):
+def flip_bound(cfg):
+    """FLIPS single-unit ReLU flips on the CAB grid of this configuration."""
+    return FLIPS / (256.0 * cfg["cab_positions"]) ** 0.5
+
+
+def tensor_bound(name, row, cfg):
     """Largest admissible distance of the GPU gradient from the fp64 oracle for one tensor (module docstring)."""
-    floor = cfg.get("ref32_vs_f64_p90", 0.0)
-    flip = FLIPS / (256.0 * cfg["cab_positions"]) ** 0.5 if cfg.get("cab_positions") else 0.0
-    return min(max(TOL, ALLOW_FACTOR * max(row["ref32_vs_f64"], floor), flip), MAX_BOUND)
+    named = flip_bound(cfg) if name in cfg.get("tensors", {}) else 0.0
+    return min(max(TOL, ALLOW_FACTOR * row["ref32_vs_f64"], named), MAX_BOUND)
 
 
 def judge_gradients(rows, cfg):
@@ -98,8 +105,9 @@ def judge_gradients(rows, cfg):
     for k, r in rows.items():
         if r["analytic_zero"] or min(r["gpu_vs_ref32"], r["gpu_vs_f64"]) <= TOL:
             continue
-        if r["gpu_vs_f64"] <= tensor_bound(r, cfg):
+        bound = tensor_bound(k, r, cfg)
+        if r["gpu_vs_f64"] <= bound:
             listed.append(k)
             continue
-        failures.append((k, dict(r, bound=tensor_bound(r, cfg))))
+        failures.append((k, dict(r, bound=bound)))
     return failures, listed

@@ -103,6 +103,7 @@ def test_model_vs_oracle_logits_and_grads(mode, batch, size, ncls):
     rounding noise in front of a ReLU -- the reference's own fp32 and fp64 gradients then differ by 100 %.)"""
     from cabinet_amd.train import build_model, make_criteria, synthetic_batch
     from oracle import model_ref
+    from insitu import instrument, judge_operator_table, operator_table
     from parity_rules import gradient_table, judge_gradients, load_allowlist, write_table
 
     net = build_model(mode, n_classes=ncls, seed=0, gamma=0.5, freeze_unused=False)
@@ -113,6 +114,7 @@ def test_model_vs_oracle_logits_and_grads(mode, batch, size, ncls):
     w64 = model_ref.Weights(sd, dtype=torch.float64)  # the truth both fp32 results approximate
     model_ref.train_step(w64, im.double(), lb, mode)
     net = net.cuda().train()
+    cap = instrument(net)
     crit = make_criteria(batch, size, size, "cuda")
     out, out16 = net(im.cuda())
     loss = crit[0](out, lb.cuda()) + crit[1](out16, lb.cuda())
@@ -122,12 +124,16 @@ def test_model_vs_oracle_logits_and_grads(mode, batch, size, ncls):
     assert_close(out16, out16_ref, TOL, "high_res_logit_up")
     assert abs(float(loss.detach()) - float(loss_ref)) < 1e-4 * float(loss_ref)
     tag = f"{mode}_{batch}x{size}"
+    insitu, _ = operator_table(net, sd, cap, lb, (size, size), max(1, batch * size * size // 16))
+    bad = judge_operator_table(insitu, TOL)
+    assert not bad, {k: {n: (f"{v:.2e}" if isinstance(v, float) else v) for n, v in r.items()} for k, r in bad.items()}
     rows = gradient_table(net, w.grads(), w64.grads())
     if mode == "large":
         rows = {k: r for k, r in rows.items() if k.startswith(("ab.a2block.", "ffm."))}
         assert len(rows) >= 25
     failures, listed = judge_gradients(rows, load_allowlist()[tag])
-    write_table(f"parity_{tag}.json", dict(past_1e3_within_bound=listed, failures=[k for k, _ in failures], tensors=rows))
+    write_table(f"parity_{tag}.json", dict(past_1e3_within_bound=listed, failures=[k for k, _ in failures], tensors=rows,
+                                           insitu_operators_vs_f64_replay=insitu))
     assert not failures, [(k, {n: f"{v:.2e}" for n, v in r.items() if isinstance(v, float)}) for k, r in failures]
     # BatchNorm side effects of the hot path match too
     bufs = w.buffers()
