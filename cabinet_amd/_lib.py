@@ -22,8 +22,9 @@ SIGNATURES = {
     "cabinet_abi_version": (_INT, []),
     "cabinet_last_error": (ctypes.c_char_p, []),
     "cabinet_cab_attn_supported": (_INT, [_INT] * 2),
-    "cabinet_cab_attn_fwd_workspace_bytes": (_SZ, [_INT] * 4),
-    "cabinet_cab_attn_fwd": (_INT, [_PTR, _PTR, _PTR, _FLT, _INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _SZ, _PTR]),
+    "cabinet_cab_attn_precision_supported": (_INT, [_INT] * 3),
+    "cabinet_cab_attn_fwd_workspace_bytes": (_SZ, [_INT] * 5),
+    "cabinet_cab_attn_fwd": (_INT, [_PTR, _PTR, _PTR, _FLT, _INT, _INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _SZ, _PTR]),
     "cabinet_cab_attn_bwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_cab_attn_bwd": (_INT, [_PTR] * 6 + [_FLT] + [_INT] * 4 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_ffm_fwd_workspace_bytes": (_SZ, [_INT] * 7),

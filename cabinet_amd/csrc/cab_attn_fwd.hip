@@ -334,6 +334,13 @@ __global__ void cab_attn_fwd_merge_kernel(const float* __restrict__ part_ctx,
     }
 }
 
+// shared with the split-bf16 variants (cab_attn_bf16.hip)
+void launch_attn_merge(const float* part_ctx, const float* part_lse, float* ctx, float* lse, int B, int VC, int n, int kvsplit,
+                       hipStream_t stream) {
+    const dim3 mgrid((n + 255) / 256, VC < 32 ? VC : 32, B);
+    hipLaunchKernelGGL(cab_attn_fwd_merge_kernel, mgrid, dim3(256), 0, stream, part_ctx, part_lse, ctx, lse, B, VC, n, kvsplit);
+}
+
 template <int KC, int VC>
 static hipError_t launch_fwd(const float* q, const float* k, const float* v, float scale, int B, int n,
                              float* ctx, float* lse, float* part_ctx, float* part_lse, int kvsplit,
@@ -349,9 +356,7 @@ static hipError_t launch_fwd(const float* q, const float* k, const float* v, flo
     } else {
         hipLaunchKernelGGL(kern, grid, block, lds, stream, q, k, v, part_ctx, part_lse, n,
                            scale * LOG2E_F, kvsplit, B);
-        dim3 mgrid((n + 255) / 256, VC < 32 ? VC : 32, B);
-        hipLaunchKernelGGL(cab_attn_fwd_merge_kernel, mgrid, dim3(256), 0, stream, part_ctx, part_lse, ctx,
-                           lse, B, VC, n, kvsplit);
+        launch_attn_merge(part_ctx, part_lse, ctx, lse, B, VC, n, kvsplit, stream);
     }
     return hipGetLastError();
 }

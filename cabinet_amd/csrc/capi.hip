@@ -16,6 +16,12 @@ bool attn_shape_supported(int Kc, int Vc);
 hipError_t attn_fwd_dispatch(const float* q, const float* k, const float* v, float scale, int B, int Kc,
                              int Vc, int n, float* ctx, float* lse, float* part_ctx, float* part_lse,
                              int kvsplit, hipStream_t stream);
+// cab_attn_bf16.hip
+bool attn_bf16_supported(int Kc, int Vc);
+size_t attn_bf16_pack_bytes(int B, int Kc, int Vc, int n, int precision);
+hipError_t attn_fwd_bf16_dispatch(const float* q, const float* k, const float* v, float scale, int B, int Kc, int Vc, int n,
+                                  float* ctx, float* lse, float* part_ctx, float* part_lse, int kvsplit, void* pack, int precision,
+                                  hipStream_t stream);
 // cab_attn_bwd.hip
 size_t attn_bwd_workspace(int B, int Kc, int Vc, int n);
 hipError_t attn_bwd_dispatch(const float* dctx, const float* q, const float* k, const float* v,
@@ -139,20 +145,31 @@ static int check_attn_shape(int B, int Kc, int Vc, int n) {
 
 int cabinet_cab_attn_supported(int Kc, int Vc) { return cabinet::attn_shape_supported(Kc, Vc) ? 1 : 0; }
 
-size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n) {
-    if (B <= 0 || Kc <= 0 || Vc <= 0 || n <= 0) return 0;
-    const int split = cabinet::attn_fwd_kvsplit(B, n);
+int cabinet_cab_attn_precision_supported(int Kc, int Vc, int precision) {
+    if (precision == CABINET_PREC_FP32) return cabinet_cab_attn_supported(Kc, Vc);
+    if (precision == CABINET_PREC_BF16X3 || precision == CABINET_PREC_BF16X6) return cabinet::attn_bf16_supported(Kc, Vc) ? 1 : 0;
+    return 0;
+}
+
+static size_t attn_fwd_split_bytes(int B, int Vc, int n, int split) {
     if (split == 1) return 0;
-    return align_up((size_t)split * B * Vc * n * sizeof(float), 256) +
-           align_up((size_t)split * B * n * sizeof(float), 256);
+    return align_up((size_t)split * B * Vc * n * sizeof(float), 256) + align_up((size_t)split * B * n * sizeof(float), 256);
+}
+
+size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n, int precision) {
+    if (B <= 0 || Kc <= 0 || Vc <= 0 || n <= 0 || !cabinet_cab_attn_precision_supported(Kc, Vc, precision)) return 0;
+    const size_t pack = precision == CABINET_PREC_FP32 ? 0 : cabinet::attn_bf16_pack_bytes(B, Kc, Vc, n, precision);
+    return attn_fwd_split_bytes(B, Vc, n, cabinet::attn_fwd_kvsplit(B, n)) + pack;
 }
 
 int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float scale, int B, int Kc, int Vc,
-                         int n, float* ctx, float* lse, void* workspace, size_t workspace_bytes,
+                         int n, int precision, float* ctx, float* lse, void* workspace, size_t workspace_bytes,
                          cabinet_stream_t stream) {
     if (int rc = check_attn_shape(B, Kc, Vc, n)) return rc;
+    if (!cabinet_cab_attn_precision_supported(Kc, Vc, precision))
+        return fail(CABINET_ERR_UNSUPPORTED, "cab_attn_fwd: precision %d is not built for (Kc=%d, Vc=%d)", precision, Kc, Vc);
     if (!q || !k || !v || !ctx || !lse) return fail(CABINET_ERR_INVALID_ARG, "cab_attn_fwd: null tensor pointer");
-    const size_t need = cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n);
+    const size_t need = cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n, precision);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "cab_attn_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
     const int split = cabinet::attn_fwd_kvsplit(B, n);
@@ -160,6 +177,12 @@ int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float s
     float* part_lse = split > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) +
                                                            align_up((size_t)split * B * Vc * n * sizeof(float), 256))
                                 : nullptr;
+    if (precision != CABINET_PREC_FP32) {
+        void* pack = static_cast<char*>(workspace) + attn_fwd_split_bytes(B, Vc, n, split);
+        return hip_status(cabinet::attn_fwd_bf16_dispatch(q, k, v, scale, B, Kc, Vc, n, ctx, lse, part_ctx, part_lse, split, pack,
+                                                          precision, static_cast<hipStream_t>(stream)),
+                          "cab_attn_fwd (split bf16) launch");
+    }
     return hip_status(cabinet::attn_fwd_dispatch(q, k, v, scale, B, Kc, Vc, n, ctx, lse, part_ctx, part_lse,
                                                  split, static_cast<hipStream_t>(stream)),
                       "cab_attn_fwd launch");

@@ -57,17 +57,21 @@ def _f32c(t):
 # --------------------------------------------------------------------------- attention core
 
 
-def attn_fwd_hip(q, k, v, scale):
+PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2  # include/cabinet_hip.h: CABINET_PREC_*
+_PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
+
+
+def attn_fwd_hip(q, k, v, scale, precision=PREC_FP32):
     """q,k (B,Kc,n), v (B,Vc,n) fp32 device tensors -> ctx (B,Vc,n), lse (B,n)."""
     lib = _lib.load()
     B, Kc, n = q.shape
     Vc = v.shape[1]
     ctx = torch.empty((B, Vc, n), dtype=torch.float32, device=q.device)
     lse = torch.empty((B, n), dtype=torch.float32, device=q.device)
-    ws, nbytes = _workspace(lib.cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n), q.device)
+    ws, nbytes = _workspace(lib.cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n, int(precision)), q.device)
     with torch.cuda.device(q.device):
-        rc = lib.cabinet_cab_attn_fwd(_ptr(q), _ptr(k), _ptr(v), float(scale), B, Kc, Vc, n, _ptr(ctx), _ptr(lse),
-                                      _ptr(ws), nbytes, _stream_handle(q.device))
+        rc = lib.cabinet_cab_attn_fwd(_ptr(q), _ptr(k), _ptr(v), float(scale), B, Kc, Vc, n, int(precision), _ptr(ctx),
+                                      _ptr(lse), _ptr(ws), nbytes, _stream_handle(q.device))
     _lib.check(rc, "cabinet_cab_attn_fwd")
     return ctx, lse
 
@@ -89,9 +93,9 @@ def attn_bwd_hip(g, q, k, v, ctx, lse, scale):
 class _CabAttention(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(fn_ctx, q, k, v, scale):
+    def forward(fn_ctx, q, k, v, scale, precision):
         q, k, v = _f32c(q), _f32c(k), _f32c(v)
-        out, lse = attn_fwd_hip(q, k, v, scale)
+        out, lse = attn_fwd_hip(q, k, v, scale, precision)
         fn_ctx.save_for_backward(q, k, v, out, lse)
         fn_ctx.scale = scale
         return out
@@ -101,7 +105,7 @@ class _CabAttention(torch.autograd.Function):
     def backward(fn_ctx, g):
         q, k, v, out, lse = fn_ctx.saved_tensors
         dq, dk, dv = attn_bwd_hip(_f32c(g), q, k, v, out, lse, fn_ctx.scale)
-        return dq, dk, dv, None
+        return dq, dk, dv, None, None
 
 
 def cab_attention_supported(Kc, Vc):
@@ -109,15 +113,39 @@ def cab_attention_supported(Kc, Vc):
     return bool(_lib.load().cabinet_cab_attn_supported(int(Kc), int(Vc)))
 
 
-def cab_attention(q, k, v, scale):
+# Matrix arithmetic of K1's two contractions (include/cabinet_hip.h, CABINET_PREC_*): "fp32" = exact fp32 MFMA (default),
+# "bf16x6" = fp32 operands as three bf16 pieces each, six bf16 MFMA products per fp32 product (fp32-level accuracy, 2.7x the
+# matrix rate), "bf16x3" = two pieces, three products (~1e-5 per tensor; a measured variant).  Set per call, or process-wide
+# through this module attribute / the environment variable CABINET_ATTN_PRECISION; channel pairs without a split-bf16
+# instantiation always run fp32.
+import os as _os  # noqa: E402
+
+ATTN_PRECISION = _os.environ.get("CABINET_ATTN_PRECISION", "fp32")
+
+
+def _resolve_precision(precision, Kc, Vc):
+    name = ATTN_PRECISION if precision is None else precision
+    if name not in _PRECISIONS:
+        raise RuntimeError(f"cab_attention: unknown precision {name!r} (one of {sorted(_PRECISIONS)})")
+    code = _PRECISIONS[name]
+    if code != PREC_FP32 and not _lib.load().cabinet_cab_attn_precision_supported(int(Kc), int(Vc), code):
+        if precision is not None:
+            raise RuntimeError(f"cab_attention: precision {name!r} is not built for (Kc={Kc}, Vc={Vc})")
+        code = PREC_FP32
+    return code
+
+
+def cab_attention(q, k, v, scale, precision=None):
     """ctx[b,c,i] = sum_j softmax_j(scale * <q[b,:,i], k[b,:,j]>) v[b,c,j].
 
     q,k: (B,Kc,n)  v: (B,Vc,n)  ->  (B,Vc,n).   Reference: cab.py:149-154.
+    ``precision``: None (module default ``ATTN_PRECISION``) | "fp32" | "bf16x6" | "bf16x3" -- forward contractions only; the
+    backward (K2) is fp32 MFMA in every case.
     """
     if q.dim() != 3 or k.shape != q.shape or v.dim() != 3 or v.shape[0] != q.shape[0] or v.shape[2] != q.shape[2]:
         raise RuntimeError(f"cab_attention: bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
     if q.is_cuda and cab_attention_supported(q.shape[1], v.shape[1]):
-        return _CabAttention.apply(q, k, v, float(scale))
+        return _CabAttention.apply(q, k, v, float(scale), _resolve_precision(precision, q.shape[1], v.shape[1]))
     # host tensors, and channel pairs without a gfx950 instantiation: composite ATen ops (module docstring: one rule)
     attn = torch.bmm(q.transpose(1, 2), k) * scale
     attn = F.softmax(attn, dim=-1)

@@ -58,11 +58,23 @@ const char* cabinet_last_error(void);
  * Instantiated for (Kc,Vc) in {(128,128), (256,128), (64,64)}; n >= 1 arbitrary.  cabinet_cab_attn_supported()
  * answers 1 / 0 for a channel pair; callers route other pairs to their composite path (the fwd / bwd entry points
  * return CABINET_ERR_UNSUPPORTED for them).
+ *
+ * `precision` selects the matrix arithmetic of the two contractions (same kernel structure, same operand layout trick):
+ *   CABINET_PREC_FP32   (0)  v_mfma_f32_32x32x2_f32: exact fp32 products and sums (bit-wise an fma chain).  Default.
+ *   CABINET_PREC_BF16X3 (1)  every fp32 operand split into 2 bf16 pieces, 3 bf16 MFMA products per fp32 product
+ *                            (~2^-17 relative per product, ~1e-5 per tensor): 5.3x the fp32 matrix rate.  Measured variant.
+ *   CABINET_PREC_BF16X6 (2)  3 pieces (fp32's 24-bit significand exactly), 6 products: fp32-level accuracy at 2.7x the rate.
+ * The split forms exist for (Kc,Vc) in {(128,128), (64,64)} (cabinet_cab_attn_precision_supported); their workspace
+ * also holds the operands re-laid out as bf16 pieces in MFMA operand order (one pack pass per call).
  * ------------------------------------------------------------------------- */
+#define CABINET_PREC_FP32 0
+#define CABINET_PREC_BF16X3 1
+#define CABINET_PREC_BF16X6 2
 int cabinet_cab_attn_supported(int Kc, int Vc);
-size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n);
+int cabinet_cab_attn_precision_supported(int Kc, int Vc, int precision);
+size_t cabinet_cab_attn_fwd_workspace_bytes(int B, int Kc, int Vc, int n, int precision);
 int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float scale,
-                         int B, int Kc, int Vc, int n,
+                         int B, int Kc, int Vc, int n, int precision,
                          float* ctx /* (B,Vc,n) */, float* lse /* (B,n) */,
                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 

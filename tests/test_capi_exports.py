@@ -54,15 +54,23 @@ def test_workspace_queries_and_argument_errors_need_no_gpu(lib_path):
     from cabinet_amd import _lib
 
     lib = _lib.load()
-    assert lib.cabinet_cab_attn_fwd_workspace_bytes(8, 128, 128, 1024) == 0        # 256 workgroups: no split
-    assert lib.cabinet_cab_attn_fwd_workspace_bytes(2, 128, 128, 2048) > 0         # split over keys
+    assert lib.cabinet_cab_attn_fwd_workspace_bytes(8, 128, 128, 1024, 0) == 0        # 256 workgroups: no split
+    assert lib.cabinet_cab_attn_fwd_workspace_bytes(2, 128, 128, 2048, 0) > 0         # split over keys
+    # split-bf16 forms: the workspace also holds q, k, v as 2 / 3 bf16 pieces each; (256,128) has no such form
+    assert lib.cabinet_cab_attn_fwd_workspace_bytes(8, 128, 128, 1024, 1) == 8 * 2 * 384 * 1024 * 2
+    assert lib.cabinet_cab_attn_fwd_workspace_bytes(8, 128, 128, 1024, 2) == 8 * 3 * 384 * 1024 * 2
+    assert lib.cabinet_cab_attn_fwd_workspace_bytes(1, 256, 128, 64, 2) == 0
+    assert [lib.cabinet_cab_attn_precision_supported(128, 128, p) for p in (0, 1, 2, 3)] == [1, 1, 1, 0]
+    assert [lib.cabinet_cab_attn_precision_supported(256, 128, p) for p in (0, 1, 2)] == [1, 0, 0]
+    rc = lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 256, 128, 16, 2, None, None, None, 0, None)
+    assert rc == -2 and b"precision" in lib.cabinet_last_error()
     assert lib.cabinet_cab_attn_bwd_workspace_bytes(8, 128, 128, 1024) >= 8 * 1024 * 4
     assert lib.cabinet_ffm_bwd_workspace_bytes(8, 128, 256, 256, 64, 128, 128) >= 8 * 256 * 128 * 128 * 4
     assert lib.cabinet_ffm_fwd_workspace_bytes(0, 128, 256, 256, 64, 8, 8) == 0
     # invalid arguments are rejected before any HIP call
-    rc = lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 128, 128, 16, None, None, None, 0, None)
+    rc = lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 128, 128, 16, 0, None, None, None, 0, None)
     assert rc == -1 and b"null" in lib.cabinet_last_error()
-    rc = lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 48, 128, 16, None, None, None, 0, None)
+    rc = lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 48, 128, 16, 0, None, None, None, 0, None)
     assert rc == -2 and b"instantiation" in lib.cabinet_last_error()
     rc = lib.cabinet_ffm_fwd(*([None] * 9), 1, 100, 256, 256, 64, 8, 8, 1, 0.1, 1e-5, *([None] * 6), None, 0, None)
     assert rc == -2

@@ -36,6 +36,83 @@ def test_attn_fwd_golden(path):
     assert rel_err(ctx, ctx64) < 2e-5
 
 
+SPLIT_SHAPES = [(2, 128, 128, 256), (1, 128, 128, 1000), (1, 128, 128, 31), (3, 64, 64, 130), (8, 128, 128, 1024),
+                (2, 128, 128, 2048), (1, 128, 128, 8704)]
+
+
+@pytest.mark.parametrize("B,Kc,Vc,n", SPLIT_SHAPES)
+def test_attn_fwd_split_bf16_vs_fp64(B, Kc, Vc, n):
+    """K1 on the bf16 matrix pipe (include/cabinet_hip.h CABINET_PREC_*): every fp32 operand as two (bf16x3) or three (bf16x6)
+    bf16 pieces.  Against the fp64 oracle of cab.py:149-154, next to the exact-fp32-MFMA kernel on the same inputs:
+    bf16x6 must be as accurate as fp32 (<= 2x its error, or 1e-6), bf16x3 within 5e-5 (measured ~1e-5); lse alike.  Shapes:
+    ragged n, kv-split grids (2 x 2048), the un-tiled validation frame (n = 8704), production grids of configs 3 and 5."""
+    from cabinet_amd.functional import PREC_BF16X3, PREC_BF16X6, PREC_FP32, attn_fwd_hip
+    from oracle.cab_math import attn_core_fwd
+
+    g0 = torch.Generator().manual_seed(n + Kc)
+    q = torch.randn(B, Kc, n, generator=g0).relu()
+    k = torch.randn(B, Kc, n, generator=g0) + 0.5     # a common-mode key component, as PSP outputs have
+    v = torch.randn(B, Vc, n, generator=g0)
+    scale = Kc ** -0.5
+    ctx64, lse64 = attn_core_fwd(q.double(), k.double(), v.double(), scale)
+    err = {}
+    for prec in (PREC_FP32, PREC_BF16X6, PREC_BF16X3):
+        ctx, lse = attn_fwd_hip(q.cuda(), k.cuda(), v.cuda(), scale, prec)
+        torch.cuda.synchronize()
+        err[prec] = (rel_err(ctx, ctx64), rel_err(lse, lse64))
+    assert err[PREC_FP32][0] < 2e-6, err
+    assert err[PREC_BF16X6][0] <= max(2 * err[PREC_FP32][0], 1e-6) and err[PREC_BF16X6][1] <= max(2 * err[PREC_FP32][1], 1e-6), err
+    assert err[PREC_BF16X3][0] < 5e-5 and err[PREC_BF16X3][1] < 5e-5, err
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_attn_*.npz"))), ids=os.path.basename)
+def test_attn_fwd_split_bf16_golden(path):
+    """The split-bf16 forms against the reference-generated vectors (1e-3, the north-star bar) and bit-reproducible."""
+    from cabinet_amd.functional import PREC_BF16X3, PREC_BF16X6, attn_fwd_hip
+
+    g = _load(path)
+    q, k, v = (g[n].flatten(2).cuda() for n in ("q", "k", "v"))
+    for prec in (PREC_BF16X6, PREC_BF16X3):
+        ctx, lse = attn_fwd_hip(q, k, v, float(g["scale"]), prec)
+        ctx2, lse2 = attn_fwd_hip(q, k, v, float(g["scale"]), prec)
+        torch.cuda.synchronize()
+        assert rel_err(ctx, g["ctx"].flatten(2)) < (2e-6 if prec == PREC_BF16X6 else 5e-5)
+        assert torch.equal(ctx, ctx2) and torch.equal(lse, lse2)
+
+
+def test_attn_split_bf16_autograd_and_dispatch():
+    """cab_attention(..., precision=...) runs K1 in the chosen arithmetic and K2 in fp32; gradients stay within 1e-3 of the
+    oracle for both split forms; channel pairs without a split instantiation refuse an explicit request and ignore the
+    process-wide default."""
+    from cabinet_amd import functional as Fn
+    from oracle.cab_math import attn_core_bwd, attn_core_fwd
+
+    g0 = torch.Generator().manual_seed(5)
+    q, k, v, dy = (torch.randn(2, 128, 200, generator=g0) for _ in range(4))
+    q = q.relu()
+    ctx64, lse64 = attn_core_fwd(q.double(), k.double(), v.double(), 128 ** -0.5)
+    want = attn_core_bwd(dy.double(), q.double(), k.double(), v.double(), ctx64, lse64, 128 ** -0.5)
+    for prec in ("bf16x6", "bf16x3"):
+        t = [x.cuda().requires_grad_(True) for x in (q, k, v)]
+        out = Fn.cab_attention(t[0], t[1], t[2], 128 ** -0.5, precision=prec)
+        out.backward(dy.cuda())
+        assert rel_err(out, ctx64) < (2e-6 if prec == "bf16x6" else 5e-5)
+        for got, ref, name in zip(t, want, ("dq", "dk", "dv")):
+            assert rel_err(got.grad, ref) < (1e-5 if prec == "bf16x6" else 2e-4), (prec, name)
+    lib = Fn._lib.load()
+    assert lib.cabinet_cab_attn_precision_supported(128, 128, 2) == 1 and lib.cabinet_cab_attn_precision_supported(256, 128, 2) == 0
+    q2 = torch.randn(1, 256, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="not built"):
+        Fn.cab_attention(q2, q2, torch.randn(1, 128, 64, device="cuda"), 0.1, precision="bf16x6")
+    old = Fn.ATTN_PRECISION
+    try:
+        Fn.ATTN_PRECISION = "bf16x6"   # process-wide default: (256,128) silently stays fp32, (128,128) takes the split form
+        assert Fn.cab_attention(q2, q2, torch.randn(1, 128, 64, device="cuda"), 0.1).shape == (1, 128, 64)
+        assert Fn._resolve_precision(None, 128, 128) == Fn.PREC_BF16X6 and Fn._resolve_precision(None, 256, 128) == Fn.PREC_FP32
+    finally:
+        Fn.ATTN_PRECISION = old
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_attn_*.npz"))), ids=os.path.basename)
 def test_attn_bwd_golden(path):
     from cabinet_amd.functional import attn_bwd_hip, attn_fwd_hip

@@ -322,8 +322,10 @@ def test_graphed_step_follows_a_host_side_lr_schedule_and_clipping():
     (la, lra, na, sa), (lb_, lrb, nb, sb) = res
     assert lra == lrb and len(set(lra)) == 6          # six different learning rates reached the kernels on both paths
     assert len(na) == len(nb) == 6
+    # stock backward kernels with atomics differ run to run and SGD carries the difference along (seen 5e-4 on the sixth
+    # gradient norm); a schedule bug -- a frozen or shifted learning rate -- moves these by tens of percent
     for x, y in zip(la + na, lb_ + nb):
-        assert abs(x - y) <= 2e-4 * max(1.0, abs(x)), (la, lb_, na, nb)
+        assert abs(x - y) <= 3e-3 * max(1.0, abs(x)), (la, lb_, na, nb)
     for k in sa:
         assert_close(sb[k].double(), sa[k].double(), 2e-3, k, atol=1e-5)
     # opt-in capture: plain torch optimizer only, and a changed hyper-parameter raises instead of being ignored

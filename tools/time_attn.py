@@ -35,3 +35,11 @@ tb = timeit(lambda: attn_bwd_hip(d, q, k, v, ctx, lse, sc))
 ff = 2.0 * B * n * n * (Kc + Vc)
 fb = 2.0 * B * n * n * (3 * Kc + 2 * Vc)
 print(f"B={B} Kc={Kc} Vc={Vc} n={n}: fwd {tf:.1f} us ({ff / tf / 1e6:.1f} TF/s)  bwd {tb:.1f} us ({fb / tb / 1e6:.1f} TF/s)")
+from cabinet_amd import _lib  # noqa: E402
+
+for prec, name in ((1, "bf16x3"), (2, "bf16x6")):
+    if _lib.load().cabinet_cab_attn_precision_supported(Kc, Vc, prec):
+        t = timeit(lambda: attn_fwd_hip(q, k, v, sc, prec))
+        c2, _ = attn_fwd_hip(q, k, v, sc, prec)
+        print(f"   fwd {name}: {t:.1f} us incl. pack ({ff / t / 1e6:.1f} effective TF/s)  max|ctx - ctx_fp32| / max|ctx| = "
+              f"{float((c2 - ctx).abs().max() / ctx.abs().max()):.2e}")
