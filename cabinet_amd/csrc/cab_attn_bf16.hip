@@ -63,37 +63,47 @@ struct SplitTerms<3> {
     static constexpr int B[6] = {0, 2, 1, 0, 1, 0};
 };
 
-// ------------------------------------------------------------------------------------------ pack passes
-// q or k (B, C, n) -> [b][piece][s][i][h][8]; grid (ceil(n32 / 128), C / 16, B), 256 threads = 128 positions x 2 halves
+// ------------------------------------------------------------------------------------------ pack pass
+// ONE launch, three roles by block index (three launches of 4-6 us each cost more than the attention kernel saved):
+//   q, k (B, KC, n) -> [b][piece][s][i][h][8]     blocks [0, 2 nbqk): 256 threads = 128 positions x 2 halves of one channel block
+//   v (B, VC, n)    -> [b][piece][kb][c][h][8]    the rest: a workgroup transposes a 32-channel x 64-key block through LDS so
+//                                                 that both the read (along keys) and the write (along channels) are contiguous
 template <int NS>
-__global__ __launch_bounds__(256) void attn_pack_qk_kernel(const float* __restrict__ src, u32x4* __restrict__ dst, int C, int n,
-                                                           int n32) {
-    const int i = blockIdx.x * 128 + (threadIdx.x >> 1), h = threadIdx.x & 1, s = blockIdx.y, b = blockIdx.z, S = C >> 4;
-    if (i >= n32) return;
-    bf16x8 out[NS];
-    const float* p = src + ((size_t)b * C + 16 * s + 8 * h) * n + i;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 pc[NS];
-        split_bf16<NS>(i < n ? p[(size_t)e * n] : 0.f, pc);
-#pragma unroll
-        for (int q = 0; q < NS; ++q) out[q][e] = pc[q];
-    }
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-        dst[((((size_t)b * NS + q) * S + s) * n32 + i) * 2 + h] = __builtin_bit_cast(u32x4, out[q]);
-}
-
-// v (B, VC, n) -> [b][piece][kb][c][h][8]; a workgroup transposes a 32-channel x 64-key block through LDS so that both the
-// read (along keys) and the write (along channels) are contiguous; grid (ceil(n32 / 64), VC / 32, B)
-template <int NS>
-__global__ __launch_bounds__(256) void attn_pack_v_kernel(const float* __restrict__ src, u32x4* __restrict__ dst, int VC, int n,
-                                                          int n32) {
+__global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, u32x4* __restrict__ qp, u32x4* __restrict__ kp,
+                                                        u32x4* __restrict__ vp, int KC, int VC, int n, int n32, int B) {
     __shared__ float tile[32][65];
-    const int j0 = blockIdx.x * 64, c0 = blockIdx.y * 32, b = blockIdx.z, KB = n32 >> 4;
+    const int pb = (n32 + 127) >> 7, S = KC >> 4, nbqk = pb * S * B;
+    int blk = blockIdx.x;
+    if (blk < 2 * nbqk) {
+        const float* src = blk < nbqk ? q : k;
+        u32x4* dst = blk < nbqk ? qp : kp;
+        if (blk >= nbqk) blk -= nbqk;
+        const int b = blk / (pb * S), r = blk - b * pb * S, s = r / pb;
+        const int i = (r - s * pb) * 128 + (threadIdx.x >> 1), h = threadIdx.x & 1;
+        if (i >= n32) return;
+        bf16x8 out[NS];
+        const float* p = src + ((size_t)b * KC + 16 * s + 8 * h) * n + i;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = i < n ? p[(size_t)e * n] : 0.f;  // all eight loads in flight before any arithmetic
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 pc[NS];
+            split_bf16<NS>(x[e], pc);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) out[c][e] = pc[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) dst[((((size_t)b * NS + c) * S + s) * n32 + i) * 2 + h] = __builtin_bit_cast(u32x4, out[c]);
+        return;
+    }
+    blk -= 2 * nbqk;
+    const int jb = (n32 + 63) >> 6, cbk = VC >> 5, KB = n32 >> 4;
+    const int b = blk / (jb * cbk), r = blk - b * jb * cbk, c0 = (r / jb) * 32, j0 = (r - (r / jb) * jb) * 64;
     {
         const int c = threadIdx.x >> 3, col0 = (threadIdx.x & 7) * 8;
-        const float* p = src + ((size_t)b * VC + c0 + c) * n;
+        const float* p = v + ((size_t)b * VC + c0 + c) * n;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[c][col0 + e] = (j0 + col0 + e < n) ? p[j0 + col0 + e] : 0.f;
     }
@@ -106,11 +116,11 @@ __global__ __launch_bounds__(256) void attn_pack_v_kernel(const float* __restric
         __bf16 pc[NS];
         split_bf16<NS>(tile[c][16 * kbl + (e & 3) + 8 * (e >> 2) + 4 * h], pc);
 #pragma unroll
-        for (int q = 0; q < NS; ++q) out[q][e] = pc[q];
+        for (int cc = 0; cc < NS; ++cc) out[cc][e] = pc[cc];
     }
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
-        dst[((((size_t)b * NS + q) * KB + kb) * VC + c0 + c) * 2 + h] = __builtin_bit_cast(u32x4, out[q]);
+    for (int cc = 0; cc < NS; ++cc)
+        vp[((((size_t)b * NS + cc) * KB + kb) * VC + c0 + c) * 2 + h] = __builtin_bit_cast(u32x4, out[cc]);
 }
 
 // ------------------------------------------------------------------------------------------ attention forward
@@ -234,11 +244,82 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_bf16_kernel(const u32x4* __r
         s_chain(sc, k_voff(t + tstep));
         softmax_split(sc, t * 32, t * 32 + 32 > n, alpha, pp);  // O is still zero: nothing to rescale
         for (; t + tstep < NT; t += tstep) {
-            // phase A: S^T of the next tile (K registers move on to the tile after it)
-            s_chain(sn, k_voff(t + 2 * tstep));
-            // phase B: PV of this tile on the matrix pipe, softmax + split of the next tile on the VALU
-            pv_chain(pp, v_voff(t + tstep));
-            softmax_split(sn, (t + tstep) * 32, (t + tstep) * 32 + 32 > n, alpha, pn);
+            // ---- phase A: S^T of the next tile, one fenced slot per MFMA; the K registers of a channel block move on to
+            // the tile after next right behind the MFMAs that consumed them ----
+            {
+                const int nv = k_voff(t + 2 * tstep);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < KS; ++c) {
+#pragma unroll
+                    for (int e = 0; e < T::N; ++e) {
+                        sn = mfma_bf16(kr[T::A[e]][c], qr[T::B[e]][c], sn);
+                        if (e == T::N - 1) load_k_step(c, nv);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            // ---- phase B: PV of this tile, one fenced slot per MFMA, each followed by its share of the next tile's softmax
+            // and P split (the wave issues in order: VALU work placed behind a group of MFMAs would run with the matrix pipe
+            // idle, and left to itself the compiler emits the softmax as one block) and by the V refill loads ----
+            auto phase_b = [&](auto mask_tag) {
+                constexpr bool MASK = decltype(mask_tag)::value;  // only the last key tile can be ragged
+                constexpr int SLOTS = 2 * VB * T::N;
+                // micro-steps of the softmax: 8 x (max of a register pair) | row statistics | 8 pairs x (exp, split...) ;
+                constexpr int PER_PAIR = NS;              // exp + first piece | remaining pieces, one step each
+                constexpr int NSTEP = 8 + 1 + 8 * PER_PAIR;
+                const int nv = v_voff(t + tstep), jn = (t + tstep) * 32;
+                float mt = -INFINITY, mn = 0.f, rs = 0.f;
+                float res[16];
+                auto step = [&](int st) {
+                    if (st < 8) {
+#pragma unroll
+                        for (int r = 2 * st; r < 2 * st + 2; ++r) {
+                            if (MASK) sn[r] = (jn + acc_row(r) + 4 * h >= n) ? -INFINITY : sn[r];
+                            mt = fmaxf(mt, sn[r]);
+                        }
+                    } else if (st == 8) {
+                        mt = fmaxf(mt, swap_half(mt)) * qscale;
+                        mn = (mt > m + kRescaleThresholdBf) ? mt : m;
+                        alpha = fast_exp2(m - mn);
+                        m = mn;
+                    } else {
+                        const int j = (st - 9) / PER_PAIR, piece = (st - 9) - j * PER_PAIR, r0 = 2 * j;
+                        if (piece == 0) {
+#pragma unroll
+                            for (int r = r0; r < r0 + 2; ++r) {
+                                res[r] = fast_exp2(fmaf(sn[r], qscale, -mn));
+                                rs += res[r];
+                            }
+                        }
+#pragma unroll
+                        for (int r = r0; r < r0 + 2; ++r) {
+                            const __bf16 pc = (__bf16)res[r];
+                            pn[piece][r >> 3][r & 7] = pc;
+                            res[r] -= (float)pc;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+                        for (int e = 0; e < T::N; ++e) {
+                            const int slot = (u * VB + cb) * T::N + e;
+                            o[cb] = mfma_bf16(vr[T::A[e]][u][cb], pp[T::B[e]][u], o[cb]);
+                            if (e == T::N - 1) load_v_blk(u, cb, nv);
+#pragma unroll
+                            for (int st = slot * NSTEP / SLOTS; st < (slot + 1) * NSTEP / SLOTS; ++st) step(st);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                l = l * alpha + rs;
+            };
+            if ((t + tstep) * 32 + 32 > n)
+                phase_b(std::true_type{});
+            else
+                phase_b(std::false_type{});
             if (__any(alpha != 1.0f)) {
 #pragma unroll
                 for (int cb = 0; cb < VB; ++cb)
@@ -322,9 +403,8 @@ static hipError_t launch_fwd_bf16(const float* q, const float* k, const float* v
     u32x4* qp = static_cast<u32x4*>(pack);
     u32x4* kp = qp + qk_chunks;
     u32x4* vp = kp + qk_chunks;
-    hipLaunchKernelGGL((attn_pack_qk_kernel<NS>), dim3(ceil_div(n32, 128), KC / 16, B), dim3(256), 0, stream, q, qp, KC, n, n32);
-    hipLaunchKernelGGL((attn_pack_qk_kernel<NS>), dim3(ceil_div(n32, 128), KC / 16, B), dim3(256), 0, stream, k, kp, KC, n, n32);
-    hipLaunchKernelGGL((attn_pack_v_kernel<NS>), dim3(ceil_div(n32, 64), VC / 32, B), dim3(256), 0, stream, v, vp, VC, n, n32);
+    const int nb_pack = 2 * ceil_div(n32, 128) * (KC / 16) * B + ceil_div(n32, 64) * (VC / 32) * B;
+    hipLaunchKernelGGL((attn_pack_kernel<NS>), dim3(nb_pack), dim3(256), 0, stream, q, k, v, qp, kp, vp, KC, VC, n, n32, B);
     const size_t lds = (size_t)(4 * VC * 33 + 3 * 128) * sizeof(float);
     auto kern = cab_attn_fwd_bf16_kernel<KC, VC, NS>;
     static lds_attr_mask attr_mask{0};
