@@ -29,6 +29,23 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # solver search; results are identical either way.  The committed copy is READ-ONLY: every process works on a private
 # copy in a fresh temporary directory (MIOpen appends to its user db), removed at exit.
 _MIOPEN_DB = os.path.join(ROOT, "cabinet_amd", "miopen_db")
+if not os.path.isdir(_MIOPEN_DB) and int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
+    # several ranks of one node: every rank gets its own user database and kernel cache (seeded from the user's, if any), so
+    # that eight processes do not serialise on one SQLite file while MIOpen compiles / looks up ~150 convolution problems
+    import atexit
+    import shutil
+    import tempfile
+    try:
+        _tmp = tempfile.mkdtemp(prefix=f"cabinet_miopen_rank{os.environ.get('LOCAL_RANK', '0')}_")
+        _src = os.path.expanduser("~/.config/miopen")
+        if os.path.isdir(_src):
+            shutil.copytree(_src, os.path.join(_tmp, "db"), dirs_exist_ok=True)
+        os.makedirs(os.path.join(_tmp, "db"), exist_ok=True)
+        atexit.register(shutil.rmtree, _tmp, ignore_errors=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(_tmp, "db")
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(_tmp, "cache"))
+    except OSError:
+        pass
 if os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
     import atexit
     import shutil
@@ -46,6 +63,12 @@ if os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (never the 2:1-sparsity figure)
+# a split-bf16 kernel spends 3 (bf16x3) or 6 (bf16x6) bf16 MFMA products on every fp32 product: its ALGORITHMIC rate is priced
+# against the bf16 peak divided by that count
+MFMA_PEAKS = {"mfma": (PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+              "mfma-bf16x3": (PEAK_BF16_MFMA_TFLOPS / 3, "dense bf16 MFMA 2.5 PFLOP/s / 3 products per fp32 product"),
+              "mfma-bf16x6": (PEAK_BF16_MFMA_TFLOPS / 6, "dense bf16 MFMA 2.5 PFLOP/s / 6 products per fp32 product")}
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -108,7 +131,7 @@ def time_kernel(fn, iters, warm=3, reps=5):
     return start.elapsed_time(stop) / iters
 
 
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def load_traffic(batch, size):
@@ -120,13 +143,13 @@ def load_traffic(batch, size):
     from cabinet_amd import build as _build
 
     if not os.path.exists(TRAFFIC_PROFILE):
-        return {}, "none: profiles/r02_pmc_traffic.json absent"
+        return {}, "none: profiles/r03_pmc_traffic.json absent"
     prof = json.load(open(TRAFFIC_PROFILE))
     if prof.get("source_digest") != _build.source_digest():
-        return {}, "none: profiles/r02_pmc_traffic.json was collected on other kernel sources (digest mismatch)"
+        return {}, "none: profiles/r03_pmc_traffic.json was collected on other kernel sources (digest mismatch)"
     if (prof.get("batch"), prof.get("size")) != (batch, size):
-        return {}, "none: profiles/r02_pmc_traffic.json was collected at another shape"
-    return prof.get("traffic", {}), "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, FETCH x2 calibrated, digest-checked)"
+        return {}, "none: profiles/r03_pmc_traffic.json was collected at another shape"
+    return prof.get("traffic", {}), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc, FETCH x2 calibrated, digest-checked)"
 
 
 def kernel_cases(batch, size):
@@ -155,6 +178,10 @@ def kernel_cases(batch, size):
     ctx, lse = Fh.attn_fwd_hip(q, k, v, scale)
     yield ("cab_attn_fwd (K1: affinity+softmax+aggregate)", lambda: Fh.attn_fwd_hip(q, k, v, scale), 2.0 * B * n * n * (Kc + Vc),
           4.0 * B * n * (2 * Kc + 2 * Vc) + 4.0 * B * n, "mfma")
+    for code, name in ((Fh.PREC_BF16X6, "bf16x6"), (Fh.PREC_BF16X3, "bf16x3")):
+        yield (f"cab_attn_fwd_{name} (K1 on the bf16 matrix pipe: operands split into bf16 pieces, pack pass + attention)",
+               lambda c=code: Fh.attn_fwd_hip(q, k, v, scale, c), 2.0 * B * n * n * (Kc + Vc),
+               4.0 * B * n * (2 * Kc + 2 * Vc) + 4.0 * B * n, "mfma-" + name)
     yield ("cab_attn_bwd (K2: dk/dv + stored dS, dq = dS (K - mean K) as a small GEMM)", lambda: Fh.attn_bwd_hip(dctx, q, k, v, ctx, lse, scale), 2.0 * B * n * n * (3 * Kc + 2 * Vc),
           4.0 * B * n * (3 * Kc + 3 * Vc) * 2 + 8.0 * B * n, "mfma")
 
@@ -259,6 +286,14 @@ def kernel_cases(batch, size):
     yield ("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)", lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (size, size), 0.7, 255, 1e-6), px * ncls * 16,
           px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * size * (size // 8), "hbm")
 
+    lowl2 = torch.randn(B, ncls, size // 8, size // 8, generator=g).to(dev)
+    yield ("ohem_up_pair_fwd (f3: BOTH loss heads per launch, label tile shared)", lambda: Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (size, size), 0.7, 255),
+          2 * px * ncls * 12, px * (8 + 2 * 4) + 8.0 * lowl.numel(), "hbm")
+    loss_px2 = Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (size, size), 0.7, 255)[0]
+    yield ("ohem_up_pair_bwd (f3: both heads, x pass + y pass once)", lambda: Fh.ohem_up_pair_bwd_hip(lowl, lowl2, lab, loss_px2, (size, size), 0.7, 255, 1e-6),
+          2 * px * ncls * 16, px * (8 + 2 * 4) + 8.0 * lowl.numel() + 16.0 * B * ncls * size * (size // 8), "hbm")
+    del lowl2, loss_px2
+
     # ---- K5 / K6: the rest of the Context Aggregation Block at (B, 256, size/32, size/32)
     from cabinet_amd.models.cab import ContextAggregationBlock
 
@@ -285,6 +320,8 @@ _NOTES = {
     "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
                     "and the dq key-range slabs: it replaces recomputing S and dP for dq (4.3 GFLOP)",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
+    "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel), not HBM",
+    "ohem_up_pair_bwd": "what the step runs: both heads per launch; exp and VALU bound (softmax recomputed per pixel)",
     "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
     "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
     "bn_dwconv_bwd": "the depthwise stencil backward is VALU bound; the BatchNorm dx pass is HBM bound",
@@ -302,9 +339,10 @@ def kernel_rooflines(batch, size, iters):
         ms = time_kernel(fn, iters)
         tf = flops / (ms * 1e-3) / 1e12
         gbs = bytes_ / (ms * 1e-3) / 1e9
-        if bound == "mfma":
-            r = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                     frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+        if bound in MFMA_PEAKS:
+            peak, peak_is = MFMA_PEAKS[bound]
+            r = dict(bound="mfma", achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
+                     peak_is=peak_is)
         else:
             r = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                      frac=round(gbs / PEAK_HBM_GBS, 4))

@@ -39,6 +39,9 @@ SIGNATURES = {
     "cabinet_ohem_up_fwd": (_INT, [_PTR, _PTR] + [_INT] * 6 + [_FLT, _INT] + [_PTR] * 3 + [_PTR]),
     "cabinet_ohem_up_bwd_workspace_bytes": (_SZ, [_INT] * 6),
     "cabinet_ohem_up_bwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_FLT, _INT, _FLT] + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_ohem_up_pair_fwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_FLT, _INT] + [_PTR] * 3 + [_PTR]),
+    "cabinet_ohem_up_pair_bwd_workspace_bytes": (_SZ, [_INT] * 6),
+    "cabinet_ohem_up_pair_bwd": (_INT, [_PTR] * 4 + [_INT] * 6 + [_FLT, _INT, _FLT] + [_PTR] + [_PTR, _SZ, _PTR]),
     "cabinet_cab_qkv_supported": (_INT, [_INT] * 7 + [_PTR]),
     "cabinet_cab_qkv_padded_bins": (_INT, [_INT, _PTR]),
     "cabinet_cab_qkv_fwd_workspace_bytes": (_SZ, [_INT] * 7 + [_PTR]),

@@ -100,13 +100,13 @@ hipError_t pwconv_bwd_run(const float* dy, const float* x, const float* w, int B
                           float* dw, void* ws, hipStream_t stream);
 // ohem.hip
 int ohem_blocks(int B, int H, int W);
-hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
-                           float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
+hipError_t ohem_up_fwd_run(int nh, const float* const* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
+                           float thresh, int ignore_lb, float* const* loss_px, float* const* blk_sum, int* const* blk_cnt,
                            hipStream_t stream);
 size_t ohem_up_bwd_workspace(int B, int C, int H, int Wl);
 bool ohem_up_supported(int C, int Wl, int W);
-hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const float* loss_px, int B, int C, int Hl,
-                           int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
+hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* labels, const float* const* loss_px, int B, int C,
+                           int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
                            hipStream_t stream);
 }  // namespace cabinet
 
@@ -351,8 +351,8 @@ int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels, int B,
     if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
     if (!logits_low || !labels || !loss_px || !blk_sum || !blk_cnt)
         return fail(CABINET_ERR_INVALID_ARG, "ohem_up_fwd: null tensor pointer");
-    return hip_status(cabinet::ohem_up_fwd_run(logits_low, labels, B, C, Hl, Wl, H, W, thresh, ignore_lb, loss_px,
-                                               blk_sum, blk_cnt, static_cast<hipStream_t>(stream)),
+    return hip_status(cabinet::ohem_up_fwd_run(1, &logits_low, labels, B, C, Hl, Wl, H, W, thresh, ignore_lb, &loss_px, &blk_sum,
+                                               &blk_cnt, static_cast<hipStream_t>(stream)),
                       "ohem_up_fwd launch");
 }
 
@@ -370,9 +370,46 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
     const size_t need = cabinet_ohem_up_bwd_workspace_bytes(B, C, Hl, Wl, H, W);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "ohem_up_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
-    return hip_status(cabinet::ohem_up_bwd_run(logits_low, labels, loss_px, B, C, Hl, Wl, H, W, thresh, ignore_lb, coef,
+    return hip_status(cabinet::ohem_up_bwd_run(1, &logits_low, labels, &loss_px, B, C, Hl, Wl, H, W, thresh, ignore_lb, coef,
                                                dlogits_low, workspace, static_cast<hipStream_t>(stream)),
                       "ohem_up_bwd launch");
+}
+
+// both loss heads of the step (same labels, same shapes) per launch
+int cabinet_ohem_up_pair_fwd(const float* logits_low_a, const float* logits_low_b, const long long* labels, int B, int C, int Hl,
+                             int Wl, int H, int W, float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
+                             cabinet_stream_t stream) {
+    if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
+    if (!logits_low_a || !logits_low_b || !labels || !loss_px || !blk_sum || !blk_cnt)
+        return fail(CABINET_ERR_INVALID_ARG, "ohem_up_pair_fwd: null tensor pointer");
+    const int nblk = cabinet::ohem_blocks(B, H, W);
+    const float* low[2] = {logits_low_a, logits_low_b};
+    float* lp[2] = {loss_px, loss_px + (size_t)B * H * W};
+    float* bs[2] = {blk_sum, blk_sum + nblk};
+    int* bc[2] = {blk_cnt, blk_cnt + 2 * nblk};
+    return hip_status(cabinet::ohem_up_fwd_run(2, low, labels, B, C, Hl, Wl, H, W, thresh, ignore_lb, lp, bs, bc,
+                                               static_cast<hipStream_t>(stream)),
+                      "ohem_up_pair_fwd launch");
+}
+
+size_t cabinet_ohem_up_pair_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, int W) {
+    return 2 * cabinet_ohem_up_bwd_workspace_bytes(B, C, Hl, Wl, H, W);
+}
+
+int cabinet_ohem_up_pair_bwd(const float* logits_low_a, const float* logits_low_b, const long long* labels, const float* loss_px,
+                             int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef,
+                             float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
+    if (!logits_low_a || !logits_low_b || !labels || !loss_px || !dlogits_low)
+        return fail(CABINET_ERR_INVALID_ARG, "ohem_up_pair_bwd: null tensor pointer");
+    const size_t need = cabinet_ohem_up_pair_bwd_workspace_bytes(B, C, Hl, Wl, H, W);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "ohem_up_pair_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    const float* low[2] = {logits_low_a, logits_low_b};
+    const float* lp[2] = {loss_px, loss_px + (size_t)B * H * W};
+    return hip_status(cabinet::ohem_up_bwd_run(2, low, labels, lp, B, C, Hl, Wl, H, W, thresh, ignore_lb, coef, dlogits_low,
+                                               workspace, static_cast<hipStream_t>(stream)),
+                      "ohem_up_pair_bwd launch");
 }
 
 // ------------------------------------------------------ CAB local branch + block output

@@ -109,31 +109,46 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_kernel(const float* __restric
 // columns g-1, g, g+1 (clamped at the borders, which reproduces the clamped source index of align_corners=False), so the
 // 3 C staged values are fetched once for eight pixels instead of 2 C per pixel, the interpolation weights are the
 // constants (j + 4.5)/8 and (j - 3.5)/8, and labels / losses move as 16-byte vectors.
-template <int CMAX, bool EXACT>
-__global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
-                                                              int C, int Hl, int Wl, int H, int W, float rh, float thresh,
-                                                              int ignore_lb, float* __restrict__ loss_px,
-                                                              float* __restrict__ blk_sum, int* __restrict__ blk_cnt) {
-    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][Wl]
-    __shared__ float s_f[4];
-    __shared__ int s_i[3][4];
-    const int b = blockIdx.y, oy = blockIdx.x, P = H * W, nt = blockDim.x;
+// NH = 2: BOTH loss heads of the step (reference train.py:435: criteria_p(out, lb) + criteria_16(out16, lb)) in one launch.
+// The heads share the label tile (read once) and every thread carries two independent exp / log dependency chains, which is
+// what this VALU-latency-bound kernel lacks with one head (~1000 VALU instructions per wave, v_exp_f32 / v_log_f32 chains).
+template <int NH>
+struct OhemFwdHeads {
+    const float* low[NH];   // (B,C,Hl,Wl) each
+    float* loss_px[NH];     // (B,H,W)
+    float* blk_sum[NH];     // (nblk)
+    int* blk_cnt[NH];       // (nblk,2)
+};
+
+template <int CMAX, bool EXACT, int NH>
+__global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd, const long long* __restrict__ labels, int C,
+                                                              int Hl, int Wl, int H, int W, float rh, float thresh,
+                                                              int ignore_lb) {
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [NH][C][Wl]
+    __shared__ float s_f[NH][4];
+    __shared__ int s_i[NH][3][4];
+    const int b = blockIdx.y, oy = blockIdx.x, P = H * W, nt = blockDim.x, CW = C * Wl;
     const size_t plane = (size_t)Hl * Wl;
-    const float* low_b = low + (size_t)b * C * plane;
     int y0, y1;
     float ly;
     bilinear_taps(oy, rh, Hl, y0, y1, ly);
     {
         const float inv_wl = 1.f / (float)Wl;
-        for (int i = threadIdx.x; i < C * Wl; i += nt) {
-            const int c = (int)(((float)i + 0.5f) * inv_wl), xs = i - c * Wl;
-            const float* p = low_b + (size_t)c * plane;
-            v[i] = (1.f - ly) * p[y0 * Wl + xs] + ly * p[y1 * Wl + xs];
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const float* low_b = hd.low[hh] + (size_t)b * C * plane;
+            for (int i = threadIdx.x; i < CW; i += nt) {
+                const int c = (int)(((float)i + 0.5f) * inv_wl), xs = i - c * Wl;
+                const float* p = low_b + (size_t)c * plane;
+                v[hh * CW + i] = (1.f - ly) * p[y0 * Wl + xs] + ly * p[y1 * Wl + xs];
+            }
         }
     }
     __syncthreads();
-    float my_sum = 0.f;
-    int my_valid = 0, my_above = 0, my_bad = 0;
+    float my_sum[NH];
+    int my_valid = 0, my_bad = 0, my_above[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) my_sum[hh] = 0.f, my_above[hh] = 0;
     for (int g = threadIdx.x; g < Wl; g += nt) {
         const size_t pix = (size_t)b * P + (size_t)oy * W + 8 * g;  // 64-byte aligned labels, 32-byte aligned losses
         long long lb[8];
@@ -145,67 +160,86 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(const float* __rest
                 lb[2 * u] = t.x, lb[2 * u + 1] = t.y;
             }
         }
-        float xm[CMAX], xc[CMAX], xp[CMAX];
+        float xm[NH][CMAX], xc[NH][CMAX], xp[NH][CMAX];
         const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-            if (EXACT || c < C) xm[c] = v[c * Wl + gm], xc[c] = v[c * Wl + g], xp[c] = v[c * Wl + gp];
-        float out[8];
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C) {
+                    const float* vc = v + hh * CW + c * Wl;
+                    xm[hh][c] = vc[gm], xc[hh][c] = vc[g], xp[hh][c] = vc[gp];
+                }
+        float out[NH][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
-            float loss = 0.f;
-            if (lb[j] != (long long)ignore_lb) {
-                float x[CMAX], mx = -INFINITY, xl = 0.f;
+            const bool valid = lb[j] != (long long)ignore_lb;
+            // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): a separate flag,
+            // OR-reduced over the block, poisons the block's valid count so the caller's one host read sees it
+            my_valid += valid ? 1 : 0;
+            my_bad |= (valid && (lb[j] < 0 || lb[j] >= (long long)C)) ? 1 : 0;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (EXACT || c < C) {
-                        x[c] = j < 4 ? (1.f - t) * xm[c] + t * xc[c] : (1.f - t) * xc[c] + t * xp[c];
-                        mx = fmaxf(mx, x[c]);
-                        if (c == (int)lb[j]) xl = x[c];
+            for (int hh = 0; hh < NH; ++hh) {
+                float loss = 0.f;
+                if (valid) {
+                    float x[CMAX], mx = -INFINITY, xl = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (EXACT || c < C) {
+                            x[c] = j < 4 ? (1.f - t) * xm[hh][c] + t * xc[hh][c] : (1.f - t) * xc[hh][c] + t * xp[hh][c];
+                            mx = fmaxf(mx, x[c]);
+                            if (c == (int)lb[j]) xl = x[c];
+                        }
+                    float se = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);
+                    loss = mx + fast_log2(se) * LN2_F - xl;
+                    if (loss > thresh) {
+                        my_above[hh] += 1;
+                        my_sum[hh] += loss;
                     }
-                float se = 0.f;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);
-                loss = mx + fast_log2(se) * LN2_F - xl;
-                my_valid += 1;
-                my_bad |= (lb[j] < 0 || lb[j] >= (long long)C) ? 1 : 0;  // see ohem_up_fwd_kernel
-                if (loss > thresh) {
-                    my_above += 1;
-                    my_sum += loss;
                 }
+                out[hh][j] = loss;
             }
-            out[j] = loss;
         }
-        f32x4* op = reinterpret_cast<f32x4*>(loss_px + pix);
-        op[0] = f32x4{out[0], out[1], out[2], out[3]};
-        op[1] = f32x4{out[4], out[5], out[6], out[7]};
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            f32x4* op = reinterpret_cast<f32x4*>(hd.loss_px[hh] + pix);
+            op[0] = f32x4{out[hh][0], out[hh][1], out[hh][2], out[hh][3]};
+            op[1] = f32x4{out[hh][4], out[hh][5], out[hh][6], out[hh][7]};
+        }
     }
     // ordered block reduction
-    my_sum = wave_sum(my_sum);
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) my_sum[hh] = wave_sum(my_sum[hh]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         my_valid += __shfl_xor(my_valid, o, 64);
-        my_above += __shfl_xor(my_above, o, 64);
         my_bad |= __shfl_xor(my_bad, o, 64);
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) my_above[hh] += __shfl_xor(my_above[hh], o, 64);
     }
     const int nw = (nt + 63) >> 6;
     if ((threadIdx.x & 63) == 0) {
-        s_f[threadIdx.x >> 6] = my_sum;
-        s_i[0][threadIdx.x >> 6] = my_valid;
-        s_i[1][threadIdx.x >> 6] = my_above;
-        s_i[2][threadIdx.x >> 6] = my_bad;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            s_f[hh][threadIdx.x >> 6] = my_sum[hh];
+            s_i[hh][0][threadIdx.x >> 6] = my_valid;
+            s_i[hh][1][threadIdx.x >> 6] = my_above[hh];
+            s_i[hh][2][threadIdx.x >> 6] = my_bad;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x < NH) {
+        const int hh = threadIdx.x, blk = blockIdx.y * gridDim.x + blockIdx.x;
         float fs = 0.f;
         int nv = 0, na = 0, bad = 0;
-        for (int w = 0; w < nw; ++w) fs += s_f[w], nv += s_i[0][w], na += s_i[1][w], bad |= s_i[2][w];
-        blk_sum[blk] = fs;
-        blk_cnt[2 * blk] = bad ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
-        blk_cnt[2 * blk + 1] = na;
+        for (int w = 0; w < nw; ++w) fs += s_f[hh][w], nv += s_i[hh][0][w], na += s_i[hh][1][w], bad |= s_i[hh][2][w];
+        hd.blk_sum[hh][blk] = fs;
+        hd.blk_cnt[hh][2 * blk] = bad ? -(1 << 30) : nv;  // < 0: the block saw an out-of-range label
+        hd.blk_cnt[hh][2 * blk + 1] = na;
     }
 }
 
@@ -224,15 +258,26 @@ constexpr int OBX_T = 256;
 //     the clamped source index folds the window of the first / last column) -- no tap evaluation, no phase bookkeeping;
 //   * every i / FR, i % FR is a shift or a mask.
 // FR == 0 is the general resize ratio (taps evaluated per term).
+// grid.z = NH * B: blockIdx.z / B selects the head (its logits, per-pixel losses and T slab); with NH = 2 the two heads of an
+// output row run as neighbouring workgroups of one launch (shared labels stay in L2) instead of two dependent launches.
+struct OhemBwdHeads {
+    const float* low[2];
+    const float* loss_px[2];
+    float* T[2];
+};
+
 template <int CMAX, bool EXACT, int FR>
-__global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(const float* __restrict__ low, const long long* __restrict__ labels,
-                                                             const float* __restrict__ loss_px, int C, int Hl, int Wl,
-                                                             int H, int W, float rh, float rw, float thresh,
+__global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(OhemBwdHeads hd, const long long* __restrict__ labels, int B,
+                                                             int C, int Hl, int Wl, int H, int W, float rh, float rw, float thresh,
                                                              int ignore_lb, float coef, int SX, int nox_max, int R_,
-                                                             int gplane, float* __restrict__ T) {
+                                                             int gplane) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R = FR ? FR : R_;
-    const int b = blockIdx.z, oy = blockIdx.y, xs0 = blockIdx.x * SX, P = H * W;
+    const int head = blockIdx.z / B;
+    const float* __restrict__ low = hd.low[head];
+    const float* __restrict__ loss_px = hd.loss_px[head];
+    float* __restrict__ T = hd.T[head];
+    const int b = blockIdx.z - head * B, oy = blockIdx.y, xs0 = blockIdx.x * SX, P = H * W;
     const int nxs = min(SX, Wl - xs0);
     // output pixels whose taps can touch [xs0, xs0 + nxs)
     const int ox_lo = FR ? FR * xs0 - 3 * (FR / 2) : max(0, (int)floorf(((float)xs0 - 0.5f) / rw - 0.5f) - 1);
@@ -370,23 +415,36 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_y_kernel(const float* __restr
 
 int ohem_blocks(int B, int H, int W) { (void)W; return B * H; }  // one partial per output row
 
-hipError_t ohem_up_fwd_run(const float* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
-                           float thresh, int ignore_lb, float* loss_px, float* blk_sum, int* blk_cnt,
+// nh = 1 | 2 heads over the same labels; head i: low[i] -> loss_px[i], blk_sum[i], blk_cnt[i]
+hipError_t ohem_up_fwd_run(int nh, const float* const* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
+                           float thresh, int ignore_lb, float* const* loss_px, float* const* blk_sum, int* const* blk_cnt,
                            hipStream_t stream) {
     // the x8 form needs 16-byte aligned label / loss rows (W % 8 == 0 holds) and one thread per source column
-    const bool x8 = Wl > 0 && W == 8 * Wl && (reinterpret_cast<uintptr_t>(labels) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(loss_px) & 15) == 0;
+    bool x8 = Wl > 0 && W == 8 * Wl && (reinterpret_cast<uintptr_t>(labels) & 15) == 0;
+    for (int i = 0; i < nh; ++i) x8 = x8 && (reinterpret_cast<uintptr_t>(loss_px[i]) & 15) == 0;
     const int nt8 = Wl >= 256 ? 256 : ((Wl + 63) / 64) * 64;
+    // both heads in one workgroup (shared label tile, two independent exp / log chains per thread) when their row buffers fit
+    const bool pair = nh == 2 && x8 && (size_t)2 * C * Wl * sizeof(float) <= 60 * 1024;
 #define OHEM_FWD(CM, EX)                                                                                                \
     do {                                                                                                                \
-        if (x8)                                                                                                         \
-            hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX>), dim3(H, B), dim3(nt8), (size_t)C * Wl * sizeof(float),  \
-                               stream, low, labels, C, Hl, Wl, H, W, (float)Hl / (float)H, thresh, ignore_lb, loss_px,  \
-                               blk_sum, blk_cnt);                                                                       \
-        else                                                                                                            \
-            hipLaunchKernelGGL((ohem_up_fwd_kernel<CM, EX>), dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float),     \
-                               stream, low, labels, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, \
-                               ignore_lb, loss_px, blk_sum, blk_cnt);                                                   \
+        if (pair) {                                                                                                     \
+            OhemFwdHeads<2> hd{{low[0], low[1]}, {loss_px[0], loss_px[1]}, {blk_sum[0], blk_sum[1]}, {blk_cnt[0], blk_cnt[1]}}; \
+            hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX, 2>), dim3(H, B), dim3(nt8), (size_t)2 * C * Wl * sizeof(float), \
+                               stream, hd, labels, C, Hl, Wl, H, W, (float)Hl / (float)H, thresh, ignore_lb);           \
+        } else {                                                                                                        \
+            for (int i = 0; i < nh; ++i) {                                                                              \
+                if (x8) {                                                                                               \
+                    OhemFwdHeads<1> hd{{low[i]}, {loss_px[i]}, {blk_sum[i]}, {blk_cnt[i]}};                             \
+                    hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX, 1>), dim3(H, B), dim3(nt8),                       \
+                                       (size_t)C * Wl * sizeof(float), stream, hd, labels, C, Hl, Wl, H, W,              \
+                                       (float)Hl / (float)H, thresh, ignore_lb);                                         \
+                } else {                                                                                                \
+                    hipLaunchKernelGGL((ohem_up_fwd_kernel<CM, EX>), dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float), \
+                                       stream, low[i], labels, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, \
+                                       thresh, ignore_lb, loss_px[i], blk_sum[i], blk_cnt[i]);                          \
+                }                                                                                                       \
+            }                                                                                                           \
+        }                                                                                                               \
     } while (0)
     if (C == 8) OHEM_FWD(8, true);
     else if (C == 19) OHEM_FWD(19, true);
@@ -422,10 +480,14 @@ bool ohem_up_supported(int C, int Wl, int W) {
     return SX > 0 && (size_t)C * Wl * sizeof(float) <= 60 * 1024;
 }
 
-hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const float* loss_px, int B, int C, int Hl,
-                           int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
+// nh heads: dlow is (nh, B, C, Hl, Wl) contiguous, the workspace holds nh T slabs
+hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* labels, const float* const* loss_px, int B, int C,
+                           int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
                            hipStream_t stream) {
     float* T = static_cast<float*>(ws);
+    const size_t slab = ohem_up_bwd_workspace(B, C, H, Wl) / sizeof(float);
+    OhemBwdHeads hd{};
+    for (int i = 0; i < nh; ++i) hd.low[i] = low[i], hd.loss_px[i] = loss_px[i], hd.T[i] = T + i * slab;
     int SX, nox_max, R, gplane;
     size_t lds;
     ohem_segment(C, Wl, W, SX, nox_max, R, gplane, lds);
@@ -434,13 +496,13 @@ hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const floa
 #define OHEM_BWD(CM, EX)                                                                                                 \
     do {                                                                                                                 \
         if (x8)                                                                                                          \
-            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 8>), dim3(ceil_div(Wl, SX), H, B), dim3(OBX_T), lds, stream, \
-                               low, labels, loss_px, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, \
-                               ignore_lb, coef, SX, nox_max, R, gplane, T);                                               \
+            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 8>), dim3(ceil_div(Wl, SX), H, nh * B), dim3(OBX_T), lds, stream, \
+                               hd, labels, B, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh,       \
+                               ignore_lb, coef, SX, nox_max, R, gplane);                                                  \
         else                                                                                                             \
-            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 0>), dim3(ceil_div(Wl, SX), H, B), dim3(OBX_T), lds, stream, \
-                               low, labels, loss_px, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh, \
-                               ignore_lb, coef, SX, nox_max, R, gplane, T);                                               \
+            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 0>), dim3(ceil_div(Wl, SX), H, nh * B), dim3(OBX_T), lds, stream, \
+                               hd, labels, B, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh,       \
+                               ignore_lb, coef, SX, nox_max, R, gplane);                                                  \
     } while (0)
     if (C == 8) OHEM_BWD(8, true);
     else if (C == 19) OHEM_BWD(19, true);
@@ -449,8 +511,16 @@ hipError_t ohem_up_bwd_run(const float* low, const long long* labels, const floa
     else if (C <= 20) OHEM_BWD(20, false);
     else OHEM_BWD(32, false);
 #undef OHEM_BWD
-    hipLaunchKernelGGL(ohem_up_bwd_y_kernel, dim3(ceil_div(B * C * Hl * Wl, 256)), dim3(256), 0, stream, T, B * C, Hl, Wl,
-                       H, (float)Hl / (float)H, fast_y, dlow);
+    // the T slabs are contiguous only when slab == B*C*H*Wl exactly; run the y pass per head otherwise
+    const size_t plane_floats = (size_t)B * C * H * Wl;
+    if (nh == 1 || slab == plane_floats) {
+        hipLaunchKernelGGL(ohem_up_bwd_y_kernel, dim3(ceil_div(nh * B * C * Hl * Wl, 256)), dim3(256), 0, stream, T, nh * B * C, Hl,
+                           Wl, H, (float)Hl / (float)H, fast_y, dlow);
+    } else {
+        for (int i = 0; i < nh; ++i)
+            hipLaunchKernelGGL(ohem_up_bwd_y_kernel, dim3(ceil_div(B * C * Hl * Wl, 256)), dim3(256), 0, stream, T + i * slab, B * C,
+                               Hl, Wl, H, (float)Hl / (float)H, fast_y, dlow + (size_t)i * B * C * Hl * Wl);
+    }
     return hipGetLastError();
 }
 

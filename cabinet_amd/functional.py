@@ -424,6 +424,60 @@ class _OhemUpSelected(torch.autograd.Function):
         return dlow * (g / n_above).to(torch.float32), None, None, None, None, None, None, None
 
 
+def ohem_up_pair_fwd_hip(low_a, low_b, labels, size, thresh, ignore_lb):
+    """Both loss heads over the same labels in ONE launch (reference train.py:435 on the outputs of cabinet.py:240-245).
+    Returns loss_px (2,B,H,W) and stats (2,3) = per head [n_valid, n_above, sum_above] as one device tensor."""
+    lib = _lib.load()
+    B, C, Hl, Wl = low_a.shape
+    H, W = size
+    dev = low_a.device
+    nblk = lib.cabinet_ohem_up_blocks(B, H, W)
+    loss_px = torch.empty((2, B, H, W), dtype=torch.float32, device=dev)
+    blk_sum = torch.empty((2, nblk), dtype=torch.float32, device=dev)
+    blk_cnt = torch.empty((2, nblk, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ohem_up_pair_fwd(_ptr(low_a), _ptr(low_b), _ptr(labels), B, C, Hl, Wl, H, W, float(thresh),
+                                          int(ignore_lb), _ptr(loss_px), _ptr(blk_sum), _ptr(blk_cnt), _stream_handle(dev))
+    _lib.check(rc, "cabinet_ohem_up_pair_fwd")
+    stats = torch.cat([blk_cnt.sum(dim=1).double(), blk_sum.double().sum(dim=1, keepdim=True)], dim=1)
+    return loss_px, stats
+
+
+def ohem_up_pair_bwd_hip(low_a, low_b, labels, loss_px, size, thresh, ignore_lb, coef):
+    lib = _lib.load()
+    B, C, Hl, Wl = low_a.shape
+    H, W = size
+    dev = low_a.device
+    dlow = torch.empty((2, B, C, Hl, Wl), dtype=torch.float32, device=dev)
+    ws, nbytes = _workspace(lib.cabinet_ohem_up_pair_bwd_workspace_bytes(B, C, Hl, Wl, H, W), dev)
+    with torch.cuda.device(dev):
+        rc = lib.cabinet_ohem_up_pair_bwd(_ptr(low_a), _ptr(low_b), _ptr(labels), _ptr(loss_px), B, C, Hl, Wl, H, W,
+                                          float(thresh), int(ignore_lb), float(coef), _ptr(dlow), _ptr(ws), nbytes,
+                                          _stream_handle(dev))
+    _lib.check(rc, "cabinet_ohem_up_pair_bwd")
+    return dlow
+
+
+class _OhemUpSelectedPair(torch.autograd.Function):
+    """loss = sum_above_a / n_above_a + sum_above_b / n_above_b: the two heads' 'at least n_min pixels above thresh' branches
+    (reference loss.py:74-75) with ONE backward launch pair for both (see _OhemUpSelected for the single head)."""
+
+    @staticmethod
+    def forward(fn_ctx, low_a, low_b, labels, loss_px, stats, size, thresh, ignore_lb):
+        fn_ctx.save_for_backward(low_a, low_b, labels, loss_px, stats)
+        fn_ctx.meta = (size, thresh, ignore_lb)
+        return (stats[0, 2] / stats[0, 1] + stats[1, 2] / stats[1, 1]).to(torch.float32)
+
+    @staticmethod
+    def backward(fn_ctx, g):
+        low_a, low_b, labels, loss_px, stats = fn_ctx.saved_tensors
+        size, thresh, ignore_lb = fn_ctx.meta
+        dlow = ohem_up_pair_bwd_hip(low_a, low_b, labels, loss_px, size, thresh, ignore_lb, 1.0)
+        scale = (g / stats[:, 1]).to(torch.float32)  # upstream gradient and 1 / n_above per head: device scalars
+        dlow = dlow * scale.view(2, 1, 1, 1, 1)
+        return dlow[0], dlow[1], None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------- CAB local branch + block output (K5)
 
 

@@ -116,13 +116,86 @@ class SoftmaxFocalLoss(nn.Module):
         return F.nll_loss(focal, labels, weight=w, ignore_index=self.ignore_lb)
 
 
+class _PairPrep:
+    """Forward state of the two loss heads between their launch and the host's branch decision."""
+
+    def __init__(self, crits, lows, labels, size, heads=None, pair=None):
+        self.crits, self.lows, self.labels, self.size = crits, lows, labels, size
+        self.heads = heads    # per-head preps of OhemCELoss._fused_launch (separate launches), or
+        self.pair = pair      # (low_a, low_b, labels, loss_px (2,B,H,W), stats (2,3)) of the one-launch form
+        # (2,3) device tensor [n_valid, n_above, sum_above] per head, or None when a head is not fused
+        if pair is not None:
+            self.stats = pair[4]
+        elif all(h[5] is not None for h in heads):
+            self.stats = torch.stack([h[5][1] for h in heads])
+        else:
+            self.stats = None
+
+
+def fused_pair_launch(crit_a, low_a, crit_b, low_b, labels, size):
+    """Forward kernels of both loss heads (reference train.py:435), ONE launch when the heads agree in shape, threshold and
+    ignore label (they do in the reference's step: two OhemCELoss(0.7, n_min, 255) on two (B,ncls,H/8,W/8) outputs), else one
+    launch per head.  No host synchronisation: ``prep.stats`` is a device tensor."""
+    size = tuple(size) if size is not None else tuple(labels.shape[-2:])
+    same = (low_a.is_cuda and low_b.is_cuda and low_a.shape == low_b.shape and low_a.shape[1] <= 32
+            and not isinstance(crit_a.weight, torch.Tensor) and not isinstance(crit_b.weight, torch.Tensor)
+            and (crit_a.thresh, crit_a.ignore_lb) == (crit_b.thresh, crit_b.ignore_lb))
+    if not same:
+        return _PairPrep((crit_a, crit_b), (low_a, low_b), labels, size,
+                         heads=(crit_a._fused_launch(low_a, labels, size), crit_b._fused_launch(low_b, labels, size)))
+    from .functional import _f32c, ohem_up_pair_fwd_hip
+
+    if labels.dtype != torch.int64:
+        raise RuntimeError(f"OhemCELoss.forward_upsampled: labels must be int64 (torch.long), got {labels.dtype}")
+    if tuple(labels.shape) != (low_a.shape[0],) + size or labels.device != low_a.device:
+        raise RuntimeError(f"OhemCELoss.forward_upsampled: labels {tuple(labels.shape)} on {labels.device} do not "
+                           f"match logits batch {low_a.shape[0]} x size {size} on {low_a.device}")
+    la, lb_, lab = _f32c(low_a), _f32c(low_b), labels.contiguous()
+    loss_px, stats = ohem_up_pair_fwd_hip(la.detach(), lb_.detach(), lab, size, crit_a.thresh, crit_a.ignore_lb)
+    return _PairPrep((crit_a, crit_b), (low_a, low_b), labels, size, pair=(la, lb_, lab, loss_px, stats))
+
+
+def fused_pair_finish(prep, host_stats=None):
+    """Loss of both heads from a launched pair; ``host_stats`` = ``prep.stats.tolist()`` if the caller already read it (the
+    step's one host sync), else it is read here."""
+    crit_a, crit_b = prep.crits
+    if prep.pair is None:
+        host = host_stats if host_stats is not None else [None, None]
+        return crit_a._fused_finish(prep.heads[0], host[0]) + crit_b._fused_finish(prep.heads[1], host[1])
+    la, lb_, lab, loss_px, stats = prep.pair
+    host = host_stats if host_stats is not None else stats.tolist()  # host sync
+    selected = []
+    for crit, (n_valid, n_above, _) in zip(prep.crits, host):
+        n_valid, n_above = int(n_valid), int(n_above)
+        if n_valid < 0:  # the forward kernel poisons the count when it meets a label outside [0, C) that is not ignore_lb
+            raise RuntimeError(f"OhemCELoss.forward_upsampled: label out of range [0, {la.shape[1]}) "
+                               f"(and != ignore_lb {crit.ignore_lb}); F.cross_entropy asserts on the same input")
+        selected.append(n_valid > 0 and n_above >= min(crit.n_min, n_valid))
+    if all(selected):
+        from .functional import _OhemUpSelectedPair
+
+        return _OhemUpSelectedPair.apply(la, lb_, lab, loss_px, stats, prep.size, crit_a.thresh, crit_a.ignore_lb)
+    # a head on the rare top-n_min branch (or without a valid pixel): per-head paths (composite where needed)
+    from .functional import _OhemUpSelected
+
+    total = None
+    for i, (crit, low, ok) in enumerate(zip(prep.crits, prep.lows, selected)):
+        n_valid = int(host[i][0])
+        if n_valid == 0:
+            term = torch.zeros((), device=low.device, requires_grad=True)
+        elif ok:
+            term = _OhemUpSelected.apply((la, lb_)[i], lab, loss_px[i], stats[i, 2], stats[i, 1], prep.size, crit.thresh,
+                                         crit.ignore_lb)
+        else:
+            term = crit.forward(F.interpolate(low, size=prep.size, mode="bilinear", align_corners=False), prep.labels)
+        total = term if total is None else total + term
+    return total
+
+
 def ohem_upsampled_pair(crit_a, low_a, crit_b, low_b, labels, size):
-    """``crit_a.forward_upsampled(low_a, ...) + crit_b.forward_upsampled(low_b, ...)`` with both heads' forward
-    kernels issued before the single host read-back that decides their OHEM branches (the reference's step,
+    """``crit_a.forward_upsampled(low_a, ...) + crit_b.forward_upsampled(low_b, ...)`` with both heads' forward kernels in one
+    launch, one backward launch pair, and a single host read-back that decides their OHEM branches (the reference's step,
     train.py:429-441, syncs once per head inside the sort-based loss)."""
-    pa = crit_a._fused_launch(low_a, labels, size)
-    pb = crit_b._fused_launch(low_b, labels, size)
-    host = [None, None]
-    if pa[5] is not None and pb[5] is not None:
-        host = torch.stack([pa[5][1], pb[5][1]]).tolist()
-    return crit_a._fused_finish(pa, host[0]) + crit_b._fused_finish(pb, host[1])
+    prep = fused_pair_launch(crit_a, low_a, crit_b, low_b, labels, size)
+    stats = prep.stats
+    return fused_pair_finish(prep, stats.tolist() if stats is not None else None)

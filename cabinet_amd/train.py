@@ -19,7 +19,7 @@ import contextlib
 
 import torch
 
-from .loss import OhemCELoss, ohem_upsampled_pair
+from .loss import OhemCELoss, fused_pair_finish, fused_pair_launch, ohem_upsampled_pair
 from .models.cabinet import CABiNet
 from .models.constants import DEFAULT_IGNORE_LABEL, DEFAULT_SCORE_THRESHOLD, MOBILENETV3_CFGS, OHEM_DIVISOR
 
@@ -231,11 +231,10 @@ class GraphedTrainStep:
         self.g_fwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fwd, capture_error_mode=_CAPTURE_MODE):
             low, low16 = self.net.forward_lowres(self.s_im)
-            self.pa = self.crit_p._fused_launch(low, self.s_lb, size)
-            self.pb = self.crit_16._fused_launch(low16, self.s_lb, size)
-            if self.pa[5] is None or self.pb[5] is None:
+            self.prep = fused_pair_launch(self.crit_p, low, self.crit_16, low16, self.s_lb, size)
+            self.s_stats = self.prep.stats
+            if self.s_stats is None:
                 raise RuntimeError("GraphedTrainStep needs the fused OHEM head (device logits, <= 32 classes, no class weights)")
-            self.s_stats = torch.stack([self.pa[5][1], self.pb[5][1]])
         # capture does not execute: replay once to learn the capture batch's branch, then undo its BatchNorm side effects
         self.snap.save()
         self.g_fwd.replay()
@@ -246,7 +245,7 @@ class GraphedTrainStep:
                                "capture on a representative batch")
         self.g_bwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), capture_error_mode=_CAPTURE_MODE):
-            loss = self.crit_p._fused_finish(self.pa, host[0]) + self.crit_16._fused_finish(self.pb, host[1])
+            loss = fused_pair_finish(self.prep, host)
             loss.backward()
             self.s_loss = loss.detach()
         self.opt_seg.record(self.g_fwd.pool())
@@ -395,16 +394,14 @@ class GraphedDDPStep:
             torch._foreach_copy_(dst, src)
 
     def _forward(self, im, lb):
-        """-> (fused preps | None, loss | None, boundary tensors [sb output, mobile output])"""
+        """-> ((pair prep, its device statistics) | None, loss | None, boundary tensors [sb output, mobile output])"""
         boundary = []
         if im.is_cuda:
             low, low16 = self.net.forward_lowres(im, boundary)
-            size = tuple(im.shape[2:])
-            pa = self.crit_p._fused_launch(low, lb, size)
-            pb = self.crit_16._fused_launch(low16, lb, size)
-            if pa[5] is not None and pb[5] is not None:
-                return (pa, pb, torch.stack([pa[5][1], pb[5][1]])), None, boundary
-            return None, self.crit_p._fused_finish(pa, None) + self.crit_16._fused_finish(pb, None), boundary
+            prep = fused_pair_launch(self.crit_p, low, self.crit_16, low16, lb, tuple(im.shape[2:]))
+            if prep.stats is not None:
+                return (prep, prep.stats), None, boundary
+            return None, fused_pair_finish(prep, None), boundary
         final, high_up = self.net.forward_lowres(im, boundary)
         size = im.shape[2:]
         out = torch.nn.functional.interpolate(final, size=size, mode="bilinear", align_corners=False)
@@ -445,8 +442,7 @@ class GraphedDDPStep:
         self._clear()
         fused, loss, boundary = self._forward(im, lb)
         if fused is not None:
-            host = fused[2].tolist()
-            loss = self.crit_p._fused_finish(fused[0], host[0]) + self.crit_16._fused_finish(fused[1], host[1])
+            loss = fused_pair_finish(fused[0], fused[1].tolist())
         ran = self._backward_decoder(loss, boundary)
         self._pack(0)
         works = self._reduce(0)
@@ -479,7 +475,7 @@ class GraphedDDPStep:
             self.fused, _, self.boundary = self._forward(self.s_im, self.s_lb)
             if self.fused is None:
                 raise RuntimeError("GraphedDDPStep with graphs needs the fused OHEM head")
-            self.s_stats = self.fused[2]
+            self.s_stats = self.fused[1]
         self.snap.save()
         gA.replay()
         host = self.s_stats.tolist()
@@ -488,7 +484,7 @@ class GraphedDDPStep:
             raise RuntimeError("GraphedDDPStep: capture batch does not take the OHEM 'n_min above thresh' branch")
         feat_sb, mob = self.boundary
         with torch.cuda.graph(gB1, pool=gA.pool(), capture_error_mode=_CAPTURE_MODE):
-            loss = self.crit_p._fused_finish(self.fused[0], host[0]) + self.crit_16._fused_finish(self.fused[1], host[1])
+            loss = fused_pair_finish(self.fused[0], host)
             self._backward_decoder(loss, self.boundary)
             self._pack(0)
             self.s_loss = loss.detach()

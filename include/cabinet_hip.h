@@ -179,6 +179,18 @@ size_t cabinet_ohem_up_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, 
 int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const float* loss_px,
                         int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef,
                         float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+/* BOTH loss heads of the step in one launch each way -- src/scripts/train.py:435 `criteria_p(out, lb) + criteria_16(out16, lb)`
+ * on the two outputs of cabinet.py:240-245: same labels, same (B,C,Hl,Wl) logits shape, same thresh / ignore_lb.
+ *   fwd : loss_px (2,B,H,W), blk_sum (2,nblk), blk_cnt (2,nblk,2): head 0 = logits_low_a, head 1 = logits_low_b; the label tile
+ *         is read once and every thread runs the two heads' exp / log chains side by side
+ *   bwd : dlogits_low (2,B,C,Hl,Wl); workspace = 2 x the single-head workspace                                              */
+int cabinet_ohem_up_pair_fwd(const float* logits_low_a, const float* logits_low_b, const long long* labels,
+                             int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb,
+                             float* loss_px, float* blk_sum, int* blk_cnt, cabinet_stream_t stream);
+size_t cabinet_ohem_up_pair_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, int W);
+int cabinet_ohem_up_pair_bwd(const float* logits_low_a, const float* logits_low_b, const long long* labels,
+                             const float* loss_px, int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb,
+                             float coef, float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * CAB local branch + block output.

@@ -389,3 +389,72 @@ def test_one_dispatch_rule_for_shapes_outside_kernel_coverage():
     xd = run(256, 128, 1, 68, 128, 5)  # n = 8704: K5 tiled form, K6 + K1/K2 native
     assert cab_local_supported(xd) and "libcabinet_hip.so" in open("/proc/self/maps").read()
     assert _lib.load().cabinet_cab_attn_supported(128, 128) == 1
+
+
+def test_c_abi_is_reentrant_two_threads_one_device():
+    """the C ABI claims no global mutable state (per-device kernel attributes aside, which are
+    idempotent).  Two host threads -- each with its own stream, its own CAB + FFM modules and its own autograd engine
+    activity -- hammer the library concurrently on ONE device (ctypes releases the GIL for the duration of every entry
+    point, and the backward entry points run on autograd's engine thread): every result must be bit-identical to the same
+    work done serially, and cabinet_last_error stays thread-local."""
+    import threading
+
+    from cabinet_amd import _lib
+    from cabinet_amd.models.cab import ContextAggregationBlock
+    from cabinet_amd.models.cabinet import FeatureFusionModule
+
+    def build(seed):
+        torch.manual_seed(seed)
+        cab, ffm = ContextAggregationBlock(256, 128), FeatureFusionModule(384, 256)
+        with torch.no_grad():
+            cab.gamma.fill_(0.5)
+            torch.nn.init.kaiming_normal_(cab.global_attn.project_out.weight, a=1)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(2, 256, 16 + 2 * seed, 12, generator=g)
+        fsp, low = torch.randn(2, 128, 32, 24, generator=g), torch.randn(2, 256, 8, 6, generator=g)
+        return cab.cuda().train(), ffm.cuda().train(), x.cuda(), fsp.cuda(), low.cuda()
+
+    def work(objs, reps, out):
+        cab, ffm, x, fsp, low = objs
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for _ in range(reps):
+                for m in (cab, ffm):
+                    m.zero_grad(set_to_none=True)
+                xr, fr, lr = (t.clone().requires_grad_(True) for t in (x, fsp, low))
+                y = cab(xr)
+                z = ffm.forward_upsampled(fr, lr)
+                (y.square().mean() + z.square().mean()).backward()
+            stream.synchronize()
+        out.extend([y.detach().clone(), z.detach().clone(), xr.grad.clone(), fr.grad.clone(), lr.grad.clone()]
+                   + [p.grad.clone() for m in (cab, ffm) for p in m.parameters()])
+
+    serial = []
+    for seed in (1, 2):
+        res = []
+        work(build(seed), 1, res)
+        serial.append(res)
+    objs = [build(1), build(2)]
+    results, errors = [[], []], []
+
+    def run(i):
+        try:
+            work(objs[i], 12, results[i])
+            # an argument error on this thread must not leak into the other thread's error slot
+            lib = _lib.load()
+            assert lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 128, 128, 16, 0, None, None, None, 0, None) == -1
+            assert b"null" in lib.cabinet_last_error()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        assert len(got) == len(want) > 30
+        for a, b in zip(got, want):
+            # BatchNorm buffers advance with every repetition, outputs and gradients (train-mode statistics) do not
+            assert torch.equal(a, b)

@@ -106,3 +106,64 @@ def test_fused_ohem_rejects_wrong_label_dtype_shape_and_range():
         crit.forward_upsampled(low, bad, (64, 64))
     bad[0, 5, 7] = 255  # ignore_lb is fine
     assert torch.isfinite(crit.forward_upsampled(low, bad, (64, 64)))
+
+
+@pytest.mark.parametrize("B,C,Hl,Wl,H,W,ignore_frac", [
+    (2, 8, 16, 16, 128, 128, 0.0),      # x8: both heads in one workgroup (shared label tile)
+    (8, 8, 128, 128, 1024, 1024, 0.0),  # BASELINE config 3
+    (2, 19, 32, 16, 256, 128, 0.1),     # 19 classes, x8, ignored pixels
+    (1, 8, 9, 7, 61, 50, 0.1),          # general ratio: one launch per head behind the same entry point
+    (1, 19, 16, 136, 128, 1088, 0.1),   # three column segments in the backward
+])
+def test_paired_heads_equal_two_single_heads_bitwise(B, C, Hl, Wl, H, W, ignore_frac):
+    """cabinet_ohem_up_pair_fwd/bwd (both loss heads of reference train.py:435 per launch) against the single-head entry
+    points on the same inputs: per-pixel losses, reduced statistics and gradients are bit-identical (the pairing changes
+    which workgroup computes a head, not its arithmetic), and the autograd pair equals the sum of two single heads."""
+    from cabinet_amd import functional as Fn
+    from cabinet_amd.loss import OhemCELoss, ohem_upsampled_pair
+
+    g = torch.Generator().manual_seed(H + C)
+    la, lb_ = ((torch.randn(B, C, Hl, Wl, generator=g) * 2.0).cuda() for _ in range(2))
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    lab[torch.rand(B, H, W, generator=g) < ignore_frac] = 255
+    lab = lab.cuda()
+    loss_px, stats = Fn.ohem_up_pair_fwd_hip(la, lb_, lab, (H, W), 0.7, 255)
+    singles = [Fn.ohem_up_fwd_hip(x, lab, (H, W), 0.7, 255) for x in (la, lb_)]
+    for i, (lp, st) in enumerate(singles):
+        assert torch.equal(loss_px[i], lp) and torch.equal(stats[i], st)
+    dl = Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37)
+    for i, x in enumerate((la, lb_)):
+        assert torch.equal(dl[i], Fn.ohem_up_bwd_hip(x, lab, loss_px[i], (H, W), 0.7, 255, 0.37))
+    n_min = B * H * W // 16
+    ca, cb = OhemCELoss(0.7, n_min).cuda(), OhemCELoss(0.7, n_min).cuda()
+    xa, xb = la.clone().requires_grad_(True), lb_.clone().requires_grad_(True)
+    pair = ohem_upsampled_pair(ca, xa, cb, xb, lab, (H, W))
+    pair.backward()
+    ya, yb = la.clone().requires_grad_(True), lb_.clone().requires_grad_(True)
+    two = ca.forward_upsampled(ya, lab, (H, W)) + cb.forward_upsampled(yb, lab, (H, W))
+    two.backward()
+    assert abs(float(pair) - float(two)) <= 1e-6 * abs(float(two))
+    assert torch.equal(xa.grad, ya.grad) and torch.equal(xb.grad, yb.grad)
+
+
+def test_paired_heads_with_one_head_on_the_rare_branch():
+    """One head above the threshold everywhere, the other with nothing above it (top-n_min branch, composite path): the pair
+    still equals the two single heads; heads that disagree in threshold are launched separately."""
+    from cabinet_amd.loss import OhemCELoss, ohem_upsampled_pair
+
+    g = torch.Generator().manual_seed(3)
+    la = (torch.randn(1, 8, 8, 8, generator=g) * 2.0).cuda()
+    lab = torch.randint(0, 8, (1, 64, 64), generator=g).cuda()
+    lb_ = torch.nn.functional.one_hot(torch.nn.functional.interpolate(lab[None].float(), size=(8, 8))[0].long(), 8)
+    lb_ = (lb_.permute(0, 3, 1, 2).float() * 30.0).cuda()  # near-perfect logits: every loss far below thresh
+    for thr_b in (0.7, 0.9):
+        ca, cb = OhemCELoss(0.7, 64 * 64 // 16).cuda(), OhemCELoss(thr_b, 64 * 64 // 16).cuda()
+        xa, xb = la.clone().requires_grad_(True), lb_.clone().requires_grad_(True)
+        pair = ohem_upsampled_pair(ca, xa, cb, xb, lab, (64, 64))
+        pair.backward()
+        ya, yb = la.clone().requires_grad_(True), lb_.clone().requires_grad_(True)
+        two = ca.forward_upsampled(ya, lab, (64, 64)) + cb.forward_upsampled(yb, lab, (64, 64))
+        two.backward()
+        assert abs(float(pair) - float(two)) <= 1e-6 * max(1.0, abs(float(two)))
+        assert_close(xa.grad, ya.grad, 1e-6, "head a")
+        assert_close(xb.grad, yb.grad, 1e-5, "head b", atol=1e-12)
