@@ -213,6 +213,9 @@ def kernel_cases(batch, size):
     fl_f = 2.0 * B * Co * (P * Cs + Pl * Cc)
     by_f = 4.0 * B * (P * (Cs + 5 * Co) + Pl * (Cc + 2 * Co))
     yield ("ffm_up_fwd (K3': resize fused, conv commuted to low res)", upf, fl_f, by_f, "hbm")
+    for code, name in ((Fh.PREC_BF16X6, "bf16x6"), (Fh.PREC_BF16X3, "bf16x3")):
+        yield (f"ffm_up_fwd_{name} (K3' with z = W_s fsp + U(W_c low) on the bf16 matrix pipe, operands split while staged)",
+               lambda c=code: Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5, c), fl_f, by_f, "hbm")
     upb = lambda: Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
     fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
     by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))

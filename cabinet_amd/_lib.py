@@ -32,7 +32,7 @@ SIGNATURES = {
     "cabinet_ffm_bwd_workspace_bytes": (_SZ, [_INT] * 7),
     "cabinet_ffm_bwd": (_INT, [_PTR] * 13 + [_INT] * 7 + [_INT] + [_PTR] * 7 + [_PTR, _SZ, _PTR]),
     "cabinet_ffm_up_fwd_workspace_bytes": (_SZ, [_INT] * 9),
-    "cabinet_ffm_up_fwd": (_INT, [_PTR] * 9 + [_INT] * 9 + [_INT, _FLT, _FLT] + [_PTR] * 6 + [_PTR, _SZ, _PTR]),
+    "cabinet_ffm_up_fwd": (_INT, [_PTR] * 9 + [_INT] * 9 + [_INT, _FLT, _FLT, _INT] + [_PTR] * 6 + [_PTR, _SZ, _PTR]),
     "cabinet_ffm_up_bwd_workspace_bytes": (_SZ, [_INT] * 9),
     "cabinet_ffm_up_bwd": (_INT, [_PTR] * 13 + [_INT] * 9 + [_INT] + [_PTR] * 7 + [_PTR, _SZ, _PTR]),
     "cabinet_ohem_up_blocks": (_INT, [_INT] * 3),

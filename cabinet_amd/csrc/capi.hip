@@ -44,7 +44,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
                           const float* w_blk, const float* bn_w, const float* bn_b, float* run_mean,
                           float* run_var, const float* w1, const float* w2, int training, float momentum,
                           float eps, float* out, float* z, float* save_mean, float* save_invstd, float* pooled,
-                          float* gate, void* ws, hipStream_t stream);
+                          float* gate, void* ws, int precision, hipStream_t stream);
 hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, const float* fsp,
                           const float* low, const float* w_blk, const float* bn_w, const float* bn_b,
                           const float* w1, const float* w2, const float* z, const float* save_mean,
@@ -284,11 +284,13 @@ size_t cabinet_ffm_up_fwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm,
 int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk, const float* bn_weight,
                        const float* bn_bias, float* running_mean, float* running_var, const float* w1,
                        const float* w2, int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl,
-                       int training, float momentum, float eps, float* out, float* z, float* save_mean,
+                       int training, float momentum, float eps, int precision, float* out, float* z, float* save_mean,
                        float* save_invstd, float* pooled, float* gate, void* workspace, size_t workspace_bytes,
                        cabinet_stream_t stream) {
     if (int rc = check_ffm_shape(B, Cs, Cc, Co, Cm, H, W)) return rc;
     if (int rc = check_low(Hl, Wl)) return rc;
+    if (precision < CABINET_PREC_FP32 || precision > CABINET_PREC_BF16X6)
+        return fail(CABINET_ERR_INVALID_ARG, "ffm_up_fwd: unknown precision %d", precision);
     if (!fsp || !low || !w_blk || !bn_weight || !bn_bias || !running_mean || !running_var || !w1 || !w2 || !out ||
         !z || !save_mean || !save_invstd || !pooled || !gate)
         return fail(CABINET_ERR_INVALID_ARG, "ffm_up_fwd: null tensor pointer");
@@ -297,7 +299,7 @@ int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk, c
         return fail(CABINET_ERR_WORKSPACE, "ffm_up_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
     return hip_status(cabinet::ffm_up_fwd_run({B, Cs, Cc, Co, Cm, H, W}, Hl, Wl, fsp, low, w_blk, bn_weight, bn_bias,
                                               running_mean, running_var, w1, w2, training, momentum, eps, out, z,
-                                              save_mean, save_invstd, pooled, gate, workspace,
+                                              save_mean, save_invstd, pooled, gate, workspace, precision,
                                               static_cast<hipStream_t>(stream)),
                       "ffm_up_fwd launch");
 }

@@ -982,8 +982,14 @@ static size_t low_bytes(const FfmShape& s, int Hl, int Wl) {
 }
 
 size_t ffm_fwd_workspace(const FfmShape& s) { return wt_bytes(s) + stat_bytes(s); }
+// gemm_bf16.hip
+bool gemm_bf16_supported(int M, int K, int P, int W, int Wl, bool up);
+size_t gemm_bf16_pack_bytes(int M, int K, int precision);
+hipError_t gemm_bf16_run(int precision, const float* w, int ldw, const float* src, float* dst, int B, int M, int K, int P,
+                         const float* up_src, int Hl, int W, float rh, float rw, void* pack, hipStream_t stream);
+
 size_t ffm_up_fwd_workspace(const FfmShape& s, int Hl, int Wl) {
-    return wt_bytes(s) + stat_bytes(s) + low_bytes(s, Hl, Wl);
+    return wt_bytes(s) + stat_bytes(s) + low_bytes(s, Hl, Wl) + gemm_bf16_pack_bytes(s.Co, s.Cs, 2);
 }
 
 // everything after z exists: BN statistics, pooling, SE gate, gated output
@@ -1029,12 +1035,13 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
                           const float* w_blk, const float* bn_w, const float* bn_b, float* run_mean,
                           float* run_var, const float* w1, const float* w2, int training, float momentum,
                           float eps, float* out, float* z, float* save_mean, float* save_invstd, float* pooled,
-                          float* gate, void* ws, hipStream_t stream) {
+                          float* gate, void* ws, int precision, hipStream_t stream) {
     const int P = s.H * s.W, Pl = Hl * Wl, Cin = s.Cs + s.Cc;
     char* base = static_cast<char*>(ws);
     float* wt = reinterpret_cast<float*>(base);
     double* stat_part = reinterpret_cast<double*>(base + wt_bytes(s));
     float* ylow = reinterpret_cast<float*>(base + wt_bytes(s) + stat_bytes(s));
+    void* wpack = base + wt_bytes(s) + stat_bytes(s) + low_bytes(s, Hl, Wl);
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
                        s.Co, Cin);
     if (small_grid(s.B, s.Co, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0) {
@@ -1051,7 +1058,13 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
         a.P = Pl;
         gemm_kmajor(a, s.B, stream);
     }
-    {   // z = W_s . fsp + U(y_low), BN partial sums in the epilogue
+    if (precision != 0 && gemm_bf16_supported(s.Co, s.Cs, P, s.W, Wl, true)) {
+        // z = W_s . fsp + U(y_low) on the bf16 matrix pipe (operands split into bf16 pieces, gemm_bf16.hip)
+        if (hipError_t e = gemm_bf16_run(precision, w_blk, Cin, fsp, z, s.B, s.Co, s.Cs, P, ylow, Hl, s.W, (float)Hl / (float)s.H,
+                                         (float)Wl / (float)s.W, wpack, stream);
+            e != hipSuccess)
+            return e;
+    } else {   // z = W_s . fsp + U(y_low), exact fp32 MFMA
         GemmKArgs a{};
         a.at = wt, a.lda = s.Co, a.M = s.Co, a.K = s.Cs;
         a.src0 = fsp, a.src1 = fsp, a.K0 = s.Cs;

@@ -121,6 +121,9 @@ def cab_attention_supported(Kc, Vc):
 import os as _os  # noqa: E402
 
 ATTN_PRECISION = _os.environ.get("CABINET_ATTN_PRECISION", "fp32")
+# the same switch for the FFM's big forward product z = W_s . fsp + U(W_c . low) (cabinet_ffm_up_fwd); shapes without a
+# split-bf16 instantiation run fp32 whatever is set
+FFM_PRECISION = _os.environ.get("CABINET_FFM_PRECISION", "fp32")
 
 
 def _resolve_precision(precision, Kc, Vc):
@@ -230,7 +233,7 @@ class _FfmFused(torch.autograd.Function):
                 None, None, None, None, None)
 
 
-def ffm_up_fwd_hip(fsp, low, w_blk, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps):
+def ffm_up_fwd_hip(fsp, low, w_blk, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, precision=0):
     lib = _lib.load()
     B, Cs, H, W = fsp.shape
     Cc, Hl, Wl = low.shape[1:]
@@ -247,7 +250,7 @@ def ffm_up_fwd_hip(fsp, low, w_blk, bn_w, bn_b, run_mean, run_var, w1, w2, train
     with torch.cuda.device(dev):
         rc = lib.cabinet_ffm_up_fwd(_ptr(fsp), _ptr(low), _ptr(w_blk), _ptr(bn_w), _ptr(bn_b), _ptr(run_mean),
                                     _ptr(run_var), _ptr(w1), _ptr(w2), *dims, int(training), float(momentum),
-                                    float(eps), _ptr(out), _ptr(z), _ptr(save_mean), _ptr(save_invstd),
+                                    float(eps), int(precision), _ptr(out), _ptr(z), _ptr(save_mean), _ptr(save_invstd),
                                     _ptr(pooled), _ptr(gate), _ptr(ws), nbytes, _stream_handle(dev))
     _lib.check(rc, "cabinet_ffm_up_fwd")
     return out, z, save_mean, save_invstd, pooled, gate
@@ -284,7 +287,8 @@ class _FfmUpFused(torch.autograd.Function):
         w2_2 = _f32c(w2).view(w2.shape[0], -1)
         bn_w, bn_b = _f32c(bn_w), _f32c(bn_b)
         out, z, mean, invstd, pooled, gate = ffm_up_fwd_hip(fsp, low, w_blk2, bn_w, bn_b, run_mean, run_var,
-                                                            w1_2, w2_2, training, momentum, eps)
+                                                            w1_2, w2_2, training, momentum, eps,
+                                                            _PRECISIONS.get(FFM_PRECISION, PREC_FP32))
         fn_ctx.save_for_backward(fsp, low, w_blk2, bn_w, bn_b, w1_2, w2_2, z, mean, invstd, pooled, gate)
         fn_ctx.training = training
         fn_ctx.w_shapes = (w_blk.shape, w1.shape, w2.shape)

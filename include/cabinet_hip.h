@@ -133,6 +133,9 @@ int cabinet_ffm_bwd(const float* dout, const float* fsp, const float* fcp, const
  * materialised.  The 1x1 conv and the resize commute (both linear, different indices), so the Cc part of
  * the conv runs at (Hl,Wl) and is added bilinearly in the GEMM epilogue; backward likewise returns dlow at
  * (Hl,Wl).  Everything else (BN, gate, saved tensors, argument meaning) is as cabinet_ffm_fwd/bwd.
+ * `precision` (CABINET_PREC_*, see the attention section) selects the matrix arithmetic of the big product z = W_s . fsp +
+ * U(W_c . low): the split-bf16 forms exist for Co % 256 == 0, Cs == 128, (H*W) % 128 == 0, W == 128, Wl == 32 (the model's
+ * grid at 1024 x 1024); any other shape runs the exact fp32 MFMA product whatever is asked.
  * ------------------------------------------------------------------------- */
 size_t cabinet_ffm_up_fwd_workspace_bytes(int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl);
 int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk,
@@ -140,7 +143,7 @@ int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk,
                        float* running_mean, float* running_var,
                        const float* w1, const float* w2,
                        int B, int Cs, int Cc, int Co, int Cm, int H, int W, int Hl, int Wl,
-                       int training, float momentum, float eps,
+                       int training, float momentum, float eps, int precision,
                        float* out, float* z, float* save_mean, float* save_invstd,
                        float* pooled, float* gate,
                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);

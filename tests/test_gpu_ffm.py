@@ -207,3 +207,35 @@ def test_ffm_bn_statistics_with_large_channel_means():
     y = bn_act(z64.float().cuda(), bn2, "relu")
     assert_close(bn2.running_var, bn.running_var, 1e-4, "K7 vs FFM running_var")
     assert float(y.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("B", [2, 8])
+def test_ffm_up_fwd_split_bf16_vs_fp64(B):
+    """The FFM's big forward product z = W_s . fsp + U(W_c . low) (reference cabinet.py:143-144 + :228-230) on the bf16 matrix
+    pipe (include/cabinet_hip.h, `precision` of cabinet_ffm_up_fwd) at the model's grid (128 | 256@32^2 -> 256 @128^2; B = 8 is
+    BASELINE config 3): against an fp64 evaluation, next to the exact-fp32-MFMA product on the same inputs, bf16x6 must be as
+    accurate as fp32 (<= 2x its error or 1e-6) and bf16x3 within 5e-5; `out` (after BatchNorm, pooling and the gate) alike."""
+    import torch.nn.functional as F
+
+    from cabinet_amd.functional import PREC_BF16X3, PREC_BF16X6, PREC_FP32, ffm_up_fwd_hip
+
+    g0 = torch.Generator().manual_seed(11 + B)
+    fsp = torch.randn(B, 128, 128, 128, generator=g0) + 0.3
+    low = torch.randn(B, 256, 32, 32, generator=g0)
+    wb = torch.randn(256, 384, generator=g0) * 0.07
+    w1, w2 = torch.randn(64, 256, generator=g0) * 0.1, torch.randn(256, 64, generator=g0) * 0.1
+    z64 = F.conv2d(fsp.double(), wb[:, :128].double()[:, :, None, None]) + F.interpolate(
+        F.conv2d(low.double(), wb[:, 128:].double()[:, :, None, None]), size=(128, 128), mode="bilinear", align_corners=False)
+    dev = "cuda"
+    args = [t.to(dev) for t in (fsp, low, wb, torch.ones(256), torch.zeros(256))]
+    err, outs = {}, {}
+    for prec in (PREC_FP32, PREC_BF16X6, PREC_BF16X3):
+        rm, rv = torch.zeros(256, device=dev), torch.ones(256, device=dev)
+        out, z, *_ = ffm_up_fwd_hip(*args, rm, rv, w1.to(dev), w2.to(dev), True, 0.1, 1e-5, prec)
+        torch.cuda.synchronize()
+        err[prec] = rel_err(z, z64)
+        outs[prec] = out
+    assert err[PREC_FP32] < 2e-6, err
+    assert err[PREC_BF16X6] <= max(2 * err[PREC_FP32], 1e-6), err
+    assert err[PREC_BF16X3] < 5e-5, err
+    assert rel_err(outs[PREC_BF16X6], outs[PREC_FP32]) < 5e-6 and rel_err(outs[PREC_BF16X3], outs[PREC_FP32]) < 2e-4

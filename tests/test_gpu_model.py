@@ -454,7 +454,7 @@ def test_c_abi_is_reentrant_two_threads_one_device():
         t.join()
     assert not errors, errors
     for got, want in zip(results, serial):
-        assert len(got) == len(want) > 30
+        assert len(got) == len(want) >= 30
         for a, b in zip(got, want):
             # BatchNorm buffers advance with every repetition, outputs and gradients (train-mode statistics) do not
             assert torch.equal(a, b)
