@@ -89,11 +89,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_rowtile_kernel(GemmBf16Args a) 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int M = a.M, P = a.P, mblk = blockIdx.y * 256, m0 = mblk + wave * 32;
 
-    bf16x8 A[NS][KS];
+    // the two leading pieces of A stay in registers for the whole kernel; the third (NS = 3: used by ONE of the six products,
+    // A2 . B0) is re-read per k-step from the 64 KB L2-resident image -- holding it cost 32 more registers and spilled
+    constexpr int NSR = NS < 2 ? NS : 2;
+    bf16x8 A[NSR][KS];
 #pragma unroll
-    for (int p = 0; p < NS; ++p)
+    for (int p = 0; p < NSR; ++p)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) A[p][ks] = __builtin_bit_cast(bf16x8, a.wp[(((size_t)p * KS + ks) * M + m0 + li) * 2 + h]);
+    const u32x4* a2p = a.wp + (((size_t)2 * KS) * M + m0 + li) * 2 + h;  // piece 2, k-step 0 (stride 2 M chunks per k-step)
 
     f32x16 acc[4];
 #pragma unroll
@@ -166,6 +170,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_rowtile_kernel(GemmBf16Args a) 
         if (q + 1 < Q) stage_load(q + 1);
         if (a.up_src && kh == 0) vrow_load(q);
         // ---- MFMAs of this half-tile ----
+        bf16x8 a2[KH];
+        if (NS == 3) {
+#pragma unroll
+            for (int ksl = 0; ksl < KH; ++ksl) a2[ksl] = __builtin_bit_cast(bf16x8, a2p[(size_t)(kh * KH + ksl) * M * 2]);
+        }
 #pragma unroll
         for (int ksl = 0; ksl < KH; ++ksl)
 #pragma unroll
@@ -176,10 +185,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_rowtile_kernel(GemmBf16Args a) 
                     bf[pc] = __builtin_bit_cast(bf16x8, lds[buf * BUF + ((pc * KH + ksl) * 2 + h) * NT + cb * 32 + li]);
 #pragma unroll
                 for (int e = 0; e < T::N; ++e) {
-                    if (kh == 0)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[T::A[e]][ksl], bf[T::B[e]], acc[cb], 0, 0, 0);
+                    const int ap = T::A[e];
+                    bf16x8 av;
+                    if (ap == 2)
+                        av = a2[ksl];
+                    else if (kh == 0)
+                        av = A[ap < NSR ? ap : 0][ksl];
                     else
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[T::A[e]][KH + ksl], bf[T::B[e]], acc[cb], 0, 0, 0);
+                        av = A[ap < NSR ? ap : 0][KH + ksl];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf[T::B[e]], acc[cb], 0, 0, 0);
                 }
             }
         if (q + 1 < Q) stage_store(buf ^ 1);

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, assert_close
+from conftest import GOLDEN, assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3  # north_star: 1e-3 relative (||a-b||/||b|| per tensor), fp32
