@@ -132,7 +132,33 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
     int y0, y1;
     float ly;
     bilinear_taps(oy, rh, Hl, y0, y1, ly);
-    {
+    if ((Wl & 3) == 0) {
+        // the rows of v are contiguous in the source (class-major planes, Wl floats per row): all 16-byte loads of a thread are
+        // independent and issued before the first lerp (a scalar loop made this 16 dependent L2 round trips per thread)
+        const int q4 = CW >> 2;  // float4 slots per head
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const float* low_b = hd.low[hh] + (size_t)b * C * plane;
+            for (int i0 = threadIdx.x; i0 < q4; i0 += 4 * nt) {
+                f32x4 a0[4], a1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u * nt, q4 - 1), c = (4 * i) / Wl, xs = 4 * i - c * Wl;
+                    const float* p = low_b + (size_t)c * plane + xs;
+                    a0[u] = *reinterpret_cast<const f32x4*>(p + y0 * Wl);
+                    a1[u] = *reinterpret_cast<const f32x4*>(p + y1 * Wl);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * nt < q4) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = ((1.f - ly) * a0[u][e] + ly * a1[u][e]) * LOG2E_F;
+                        *reinterpret_cast<f32x4*>(v + hh * CW + 4 * (i0 + u * nt)) = o;
+                    }
+            }
+        }
+    } else {
         const float inv_wl = 1.f / (float)Wl;
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
@@ -140,7 +166,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
             for (int i = threadIdx.x; i < CW; i += nt) {
                 const int c = (int)(((float)i + 0.5f) * inv_wl), xs = i - c * Wl;
                 const float* p = low_b + (size_t)c * plane;
-                v[hh * CW + i] = (1.f - ly) * p[y0 * Wl + xs] + ly * p[y1 * Wl + xs];
+                v[hh * CW + i] = ((1.f - ly) * p[y0 * Wl + xs] + ly * p[y1 * Wl + xs]) * LOG2E_F;
             }
         }
     }
@@ -160,7 +186,12 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
                 lb[2 * u] = t.x, lb[2 * u + 1] = t.y;
             }
         }
-        float xm[NH][CMAX], xc[NH][CMAX], xp[NH][CMAX];
+        // v holds the vertically interpolated logits times log2(e).  This kernel is VALU-issue bound (1823 VALU instructions
+        // per wave measured for two heads: 81 % of the SIMD cycles), so the per-pixel chain is kept short: the horizontal
+        // lerp is one fma on a difference formed once per source interval, exp2 needs no scaling multiply, and the label's
+        // logit is gathered from LDS (rows are Wl floats apart and lanes walk consecutive columns: conflict-free whatever the
+        // labels) instead of a compare + select per class.
+        float xc[NH][CMAX], dm[NH][CMAX], dp[NH][CMAX];
         const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh)
@@ -168,34 +199,39 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
             for (int c = 0; c < CMAX; ++c)
                 if (EXACT || c < C) {
                     const float* vc = v + hh * CW + c * Wl;
-                    xm[hh][c] = vc[gm], xc[hh][c] = vc[g], xp[hh][c] = vc[gp];
+                    xc[hh][c] = vc[g], dm[hh][c] = vc[g] - vc[gm], dp[hh][c] = vc[gp] - vc[g];
                 }
         float out[NH][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float t = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+            // pixel j of the interval: x = xm + t (xc - xm) = xc - (1 - t)(xc - xm), t = (j + 4.5)/8, for j < 4;
+            //                          x = xc + t (xp - xc),                          t = (j - 3.5)/8, for j >= 4
+            const float t = j < 4 ? -(1.f - ((float)j + 4.5f) * 0.125f) : ((float)j - 3.5f) * 0.125f;
             const bool valid = lb[j] != (long long)ignore_lb;
+            const bool inrange = lb[j] >= 0 && lb[j] < (long long)C;
             // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): a separate flag,
             // OR-reduced over the block, poisons the block's valid count so the caller's one host read sees it
             my_valid += valid ? 1 : 0;
-            my_bad |= (valid && (lb[j] < 0 || lb[j] >= (long long)C)) ? 1 : 0;
+            my_bad |= (valid && !inrange) ? 1 : 0;
+            const int lrow = inrange ? (int)lb[j] * Wl : 0;
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
                 float loss = 0.f;
                 if (valid) {
-                    float x[CMAX], mx = -INFINITY, xl = 0.f;
+                    const float* vl = v + hh * CW + lrow;
+                    const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);
+                    float x[CMAX], mx = -INFINITY;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c)
                         if (EXACT || c < C) {
-                            x[c] = j < 4 ? (1.f - t) * xm[hh][c] + t * xc[hh][c] : (1.f - t) * xc[hh][c] + t * xp[hh][c];
+                            x[c] = fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]);
                             mx = fmaxf(mx, x[c]);
-                            if (c == (int)lb[j]) xl = x[c];
                         }
                     float se = 0.f;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c)
-                        if (EXACT || c < C) se += fast_exp2((x[c] - mx) * LOG2E_F);
-                    loss = mx + fast_log2(se) * LN2_F - xl;
+                        if (EXACT || c < C) se += fast_exp2(x[c] - mx);
+                    loss = ((mx - xl) + fast_log2(se)) * LN2_F;
                     if (loss > thresh) {
                         my_above[hh] += 1;
                         my_sum[hh] += loss;
@@ -301,7 +337,7 @@ __global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(OhemBwdHeads hd, c
             int c = (int)(((float)i + 0.5f) * inv_nvx);
             const int q = i - c * nvx;
             const float* p = low_b + (size_t)c * plane;
-            v[c * (SX + 4) + q] = (1.f - ly) * p[y0 * Wl + vx0 + q] + ly * p[y1 * Wl + vx0 + q];
+            v[c * (SX + 4) + q] = ((1.f - ly) * p[y0 * Wl + vx0 + q] + ly * p[y1 * Wl + vx0 + q]) * LOG2E_F;  // exp2 domain
         }
     }
     __syncthreads();
@@ -310,36 +346,31 @@ __global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(OhemBwdHeads hd, c
         const int gi = FR ? (i & (FR - 1)) * gplane + i / (FR ? FR : 1) : (i % R) * gplane + i / R;
         const bool inimg = !FR || (ox >= 0 && ox < W);
         int x0 = 0, x1 = 0;
-        float lx = 0.f;
+        float lx = 0.f, loss = 0.f;
         bool sel = false;
         long long lb = 0;
         if (inimg) {
             bilinear_taps(ox, rw, Wl, x0, x1, lx);
             const size_t pix = (size_t)b * P + (size_t)oy * W + ox;
             lb = labels[pix];
-            sel = lb != (long long)ignore_lb && loss_px[pix] > thresh;
+            loss = loss_px[pix];
+            sel = lb != (long long)ignore_lb && loss > thresh;
         }
         // taps outside the staged window belong to a pixel no column of this segment receives from
         const bool inwin = x0 >= vx0 && x1 < vx0 + nvx;
         if (sel && inwin) {
-            float x[CMAX], mx = -INFINITY;
+            // softmax_c = exp(x_c - lse) with lse = loss + x_label: the forward's per-pixel loss IS lse - x_label, so neither
+            // the running max nor the sum of exponentials (nor its reciprocal) is recomputed -- this pass is VALU-issue bound
+            // (612 VALU instructions per wave measured, 100 % of the SIMD cycles).  v is in the exp2 domain (x log2 e).
+            const int lrow = (lb >= 0 && lb < (long long)C) ? (int)lb * (SX + 4) : 0;
+            const float xl = (1.f - lx) * v[lrow + x0 - vx0] + lx * v[lrow + x1 - vx0];
+            const float lse2 = fmaf(loss, LOG2E_F, xl);
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
                 if (EXACT || c < C) {
-                    x[c] = (1.f - lx) * v[c * (SX + 4) + x0 - vx0] + lx * v[c * (SX + 4) + x1 - vx0];
-                    mx = fmaxf(mx, x[c]);
+                    const float xcv = (1.f - lx) * v[c * (SX + 4) + x0 - vx0] + lx * v[c * (SX + 4) + x1 - vx0];
+                    G[c * gsize + gi] = coef * fast_exp2(xcv - lse2) - (c == (int)lb ? coef : 0.f);
                 }
-            float se = 0.f;
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (EXACT || c < C) {
-                    x[c] = fast_exp2((x[c] - mx) * LOG2E_F);
-                    se += x[c];
-                }
-            const float inv = coef * __builtin_amdgcn_rcpf(se);  // se in [1, C]
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (EXACT || c < C) G[c * gsize + gi] = x[c] * inv - (c == (int)lb ? coef : 0.f);
         } else {
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
