@@ -311,7 +311,7 @@ def kernel_cases(batch, size):
     gq = [torch.randn_like(t) for t in q3]
     fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
     yield ("cab_qkv_fwd (K6: projections + BN + PSP, 5 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
-    yield ("cab_qkv_bwd (K6: adjoint chain, 7 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
+    yield ("cab_qkv_bwd (K6: adjoint chain, 6 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
 
 
 
@@ -319,7 +319,7 @@ _NOTES = {
     "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
     "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
     "cab_qkv_fwd": "5 dependent launches of <= 21 us each on 8192 positions: latency / small-tile MFMA bound",
-    "cab_qkv_bwd": "7 dependent launches on 8192 positions: latency / small-tile MFMA bound",
+    "cab_qkv_bwd": "6 dependent launches on 8192 positions: latency / small-tile MFMA bound",
     "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
                     "and the dq key-range slabs: it replaces recomputing S and dP for dq (4.3 GFLOP)",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",

@@ -44,6 +44,7 @@ static PyrGeom make_geom(const QkvShape& q) {
     return g;
 }
 
+constexpr int QC_T = 512;  // threads of the channel-resident kernels
 __device__ __forceinline__ int bin_start(int r, int n, int s) { return (r * n) / s; }            // floor(r*n/s)
 __device__ __forceinline__ int bin_end(int r, int n, int s) { return ((r + 1) * n + s - 1) / s; }  // ceil((r+1)*n/s)
 
@@ -411,6 +412,129 @@ __global__ __launch_bounds__(256) void qkv_bn_bwd_kernel(const float* __restrict
     for (int p = threadIdx.x; p < P; p += 256) d[p] = gi * (d[p] - m1 - (z[p] - mu) * inv * m2);
 }
 
+// Backward plane pass + BatchNorm backward of ONE stacked channel over all B images in one workgroup -- the idea of K5
+// (cab_local.hip): a per-channel BatchNorm never mixes channels, so the B planes of a channel are an independent problem with an
+// IN-WORKGROUP reduction.  Replaces qkv_plane_bwd_kernel + qkv_bn_bwd_kernel and their bnpart round trip (7 -> 6 launches):
+//   q : dy = dq 1[bn(zq) > 0]                        -> sums -> dz_q                  (dzqk rows [0, Kc))
+//   k : dy = (lin_k + A^T dpooled_k) 1[bn(zk) > 0]   -> sums -> dz_k                  (dzqk rows [Kc, 2Kc))
+//   v : dvv += A^T dpooled_v                                                          (in place)
+// dy of the B planes waits in LDS for the channel's two sums (double), then dz = gamma invstd (dy - mean(dy) - xhat mean(dy xhat)).
+static size_t lds_channel_bwd(const PyrGeom& g, int B) {
+    return ((size_t)B * g.NBp + (size_t)B * g.H * g.NCB + (size_t)g.ns * (g.W + g.H) + (size_t)B * g.H * g.W) * sizeof(float);
+}
+
+__global__ __launch_bounds__(QC_T) void qkv_channel_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ lin_k,
+                                                               const float* __restrict__ zqk, const float* __restrict__ dpe_k,
+                                                               const float* __restrict__ dpe_v, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ bnq_w,
+                                                               const float* __restrict__ bnq_b, const float* __restrict__ bnk_w,
+                                                               const float* __restrict__ bnk_b, int B, int Kc, int Vc, PyrGeom g,
+                                                               int training, float* __restrict__ dzqk, float* __restrict__ dvv,
+                                                               float* __restrict__ dbnq_w, float* __restrict__ dbnq_b,
+                                                               float* __restrict__ dbnk_w, float* __restrict__ dbnk_b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ double s_red[2][QC_T / 64];
+    __shared__ float s_m[2];
+    const int P = g.H * g.W, m = blockIdx.x, tid = threadIdx.x, C2 = 2 * Kc, nrp = g.H * g.NCB;
+    const bool is_q = m < Kc, is_v = m >= C2;
+    float* dp = smem;                                   // [B][NBp]   dpooled / bin size
+    float* E = dp + (size_t)B * g.NBp;                  // [B][H][NCB] row-expanded
+    int* xr = reinterpret_cast<int*>(E + (size_t)B * nrp);  // [ns][W]  lo | hi << 8 : column bins of size i that contain x
+    int* yr = xr + g.ns * g.W;                              // [ns][H]
+    float* dyb = reinterpret_cast<float*>(yr + g.ns * g.H);  // [B][P]   dy of this channel
+    const float inv_w = 1.f / (float)g.W;
+    if (!is_q) {
+        for (int it = tid; it < g.ns * (g.W + g.H); it += QC_T) {
+            const bool isx = it < g.ns * g.W;
+            const int j = isx ? it : it - g.ns * g.W, n = isx ? g.W : g.H;
+            const int i = j / n, c = j - i * n, s = g.s[i];
+            int lo = s, hi = -1;
+            for (int r = 0; r < s; ++r)
+                if (bin_start(r, n, s) <= c && c < bin_end(r, n, s)) lo = min(lo, r), hi = max(hi, r);
+            (isx ? xr : yr)[j] = lo | (hi << 8);
+        }
+        const int ch = is_v ? m - C2 : m - Kc, nch = is_v ? Vc : Kc;
+        const float* dpe = is_v ? dpe_v : dpe_k;
+        for (int it = tid; it < B * g.NBp; it += QC_T) {
+            const int b = it / g.NBp, t = it - b * g.NBp;
+            float val = 0.f;
+            if (t < g.NB) {
+                int i = 0;
+                while (i + 1 < g.ns && t >= g.off[i + 1]) ++i;
+                const int s = g.s[i], r = (t - g.off[i]) / s, c = (t - g.off[i]) - r * s;
+                const int cnt = (bin_end(r, g.H, s) - bin_start(r, g.H, s)) * (bin_end(c, g.W, s) - bin_start(c, g.W, s));
+                val = dpe[(((size_t)b * g.ns + i) * nch + ch) * g.NBp + t] / (float)cnt;
+            }
+            dp[it] = val;
+        }
+        __syncthreads();
+        for (int it = tid; it < B * nrp; it += QC_T) {
+            const int b = it / nrp, r0 = it - b * nrp, y = r0 / g.NCB, cb = r0 - y * g.NCB;
+            int i = 0;
+            while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
+            const int s = g.s[i], c = cb - g.coff[i], rr = yr[i * g.H + y];
+            float acc = 0.f;
+            for (int r = rr & 255; r <= (rr >> 8); ++r) acc += dp[b * g.NBp + g.off[i] + r * s + c];
+            E[it] = acc;
+        }
+        __syncthreads();
+    }
+    auto pool_adjoint = [&](int b, int p) {
+        const int y = idiv_small(p, inv_w), x = p - y * g.W;
+        const float* Ey = E + (size_t)b * nrp + y * g.NCB;
+        float acc = 0.f;
+        for (int i = 0; i < g.ns; ++i) {
+            const int cr = xr[i * g.W + x];
+            for (int c = cr & 255; c <= (cr >> 8); ++c) acc += Ey[g.coff[i] + c];
+        }
+        return acc;
+    };
+    if (is_v) {
+        for (int b = 0; b < B; ++b) {
+            float* d = dvv + ((size_t)b * Vc + (m - C2)) * P;
+            for (int p = tid; p < P; p += QC_T) d[p] += pool_adjoint(b, p);
+        }
+        return;
+    }
+    const int ch = is_q ? m : m - Kc;
+    const float mu = mean[m], inv = invstd[m];
+    const float gam = is_q ? bnq_w[ch] : bnk_w[ch], bet = is_q ? bnq_b[ch] : bnk_b[ch];
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* z = zqk + ((size_t)b * C2 + m) * P;
+        const float* din = is_q ? dq + ((size_t)b * Kc + ch) * P : lin_k + ((size_t)b * Kc + ch) * P;
+        for (int p = tid; p < P; p += QC_T) {
+            const float xh = (z[p] - mu) * inv;
+            float d = din[p];
+            if (!is_q) d += pool_adjoint(b, p);
+            const float dy = fmaf(xh, gam, bet) > 0.f ? d : 0.f;
+            dyb[(size_t)b * P + p] = dy;
+            s1 += (double)dy, s2 = fma((double)dy, (double)xh, s2);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s1 += __shfl_xor(s1, o, 64), s2 += __shfl_xor(s2, o, 64);
+    if ((tid & 63) == 0) s_red[0][tid >> 6] = s1, s_red[1][tid >> 6] = s2;
+    __syncthreads();
+    if (tid == 0) {
+        s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < QC_T / 64; ++w) s1 += s_red[0][w], s2 += s_red[1][w];
+        (is_q ? dbnq_w : dbnk_w)[ch] = (float)s2;
+        (is_q ? dbnq_b : dbnk_b)[ch] = (float)s1;
+        const double inv_n = 1.0 / ((double)B * (double)P);
+        s_m[0] = training ? (float)(s1 * inv_n) : 0.f;
+        s_m[1] = training ? (float)(s2 * inv_n) : 0.f;
+    }
+    __syncthreads();
+    const float m1 = s_m[0], m2 = s_m[1], gi = gam * inv;
+    for (int b = 0; b < B; ++b) {
+        const float* z = zqk + ((size_t)b * C2 + m) * P;
+        float* d = dzqk + ((size_t)b * C2 + m) * P;
+        for (int p = tid; p < P; p += QC_T) d[p] = gi * (dyb[(size_t)b * P + p] - m1 - (z[p] - mu) * inv * m2);
+    }
+}
+
 // ------------------------------------------------------------------------------- host side
 static size_t fbytes(size_t n) { return align_up(n * sizeof(float), 256); }
 
@@ -550,6 +674,8 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
         jobs.j[2] = sg_job(w.wv, s.C, 1, x, s.C, s.C, s.Vc, P, sv.vv, s.Vc);
         sg_gemm(jobs, s.B, stream);
     }
+    // (a channel-resident form of these two launches -- statistics + plane pass of one stacked channel over all B images in one
+    // workgroup, as the backward uses -- measured 36 us against 5 + 19: 384 workgroups leave the pooling phases latency-bound)
     hipLaunchKernelGGL(qk_bn_stats_kernel, dim3(2 * s.Kc), dim3(QS_T), 0, stream, sv.zqk, s.B, s.Kc, P, training, momentum, eps,
                        w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean, sv.invstd);
     hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
@@ -648,12 +774,23 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
         jobs.j[3] = sg_job(w.wpv, ldv, 0, dv, s.Vc, s.Vc, s.Vc, P, at(L.dvv), s.Vc);
         sg_gemm(jobs, s.B, stream);
     }
-    hipLaunchKernelGGL(qkv_plane_bwd_kernel, dim3(s.B * Mtot), dim3(256), lds_bwd_plane(g), stream, dq, at(L.link), sv.zqk,
-                       at(L.dpek), at(L.dpev), sv.mean, sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.B, s.Kc, s.Vc, g,
-                       at(L.dzqk), at(L.dvv), at(L.bnpart));
-    hipLaunchKernelGGL(qkv_bn_bwd_kernel, dim3(s.B * 2 * s.Kc), dim3(256), 0, stream, sv.zqk, sv.mean, sv.invstd, w.bnq_w,
-                       w.bnk_w, at(L.bnpart), s.B, s.Kc, P, training, at(L.dzqk), gr.dbnq_w, gr.dbnq_b, gr.dbnk_w,
-                       gr.dbnk_b);
+    const size_t lds_ch = lds_channel_bwd(g, s.B);
+    if (lds_ch <= 150 * 1024 && P < (1 << 21)) {  // plane pass + BatchNorm backward of a channel in ONE workgroup
+        static lds_attr_mask attr_mask{0};
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(qkv_channel_bwd_kernel), 150 * 1024, attr_mask);
+            e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(qkv_channel_bwd_kernel, dim3(Mtot), dim3(QC_T), lds_ch, stream, dq, at(L.link), sv.zqk, at(L.dpek),
+                           at(L.dpev), sv.mean, sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.B, s.Kc, s.Vc, g, training,
+                           at(L.dzqk), at(L.dvv), gr.dbnq_w, gr.dbnq_b, gr.dbnk_w, gr.dbnk_b);
+    } else {
+        hipLaunchKernelGGL(qkv_plane_bwd_kernel, dim3(s.B * Mtot), dim3(256), lds_bwd_plane(g), stream, dq, at(L.link), sv.zqk,
+                           at(L.dpek), at(L.dpev), sv.mean, sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.B, s.Kc, s.Vc, g,
+                           at(L.dzqk), at(L.dvv), at(L.bnpart));
+        hipLaunchKernelGGL(qkv_bn_bwd_kernel, dim3(s.B * 2 * s.Kc), dim3(256), 0, stream, sv.zqk, sv.mean, sv.invstd, w.bnq_w,
+                           w.bnk_w, at(L.bnpart), s.B, s.Kc, P, training, at(L.dzqk), gr.dbnq_w, gr.dbnq_b, gr.dbnk_w,
+                           gr.dbnk_b);
+    }
     {   // dx = W_q^T dzq + W_k^T dzk + W_v^T dvv : the row-major weights ARE the K-major A operands
         SgJobs jobs{};
         jobs.n = 1;
