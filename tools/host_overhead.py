@@ -75,5 +75,6 @@ if os.environ.get("CABINET_FORCE_DDP") == "1":
     del net, opt, red
     torch.cuda.empty_cache()
     net, opt, crit = fresh()
-    measure(GraphedDDPStep(net, crit, optimizer=opt, always_reduce=True), "world 1 with RCCL forced: GraphedDDPStep (4 graphs + 8 all-reduces)")
+    gd = GraphedDDPStep(net, crit, optimizer=opt, always_reduce=True)
+    measure(gd, f"world 1 with RCCL forced: GraphedDDPStep (4 graphs + {len(gd.bucket_megabytes)} all-reduces)")
     torch.distributed.destroy_process_group()
