@@ -14,18 +14,26 @@ import sys
 
 
 def main(run_dir, out):
-    path = glob.glob(os.path.join(run_dir, "**", "*_kernel_trace.csv"), recursive=True)[0]
-    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    if run_dir.endswith(".csv"):  # a step list written by an earlier run of this tool: rebuild the summary from it
+        path = run_dir
+        rows = [dict(Kernel_Name=r["kernel"], Start_Timestamp=str(int(round(float(r["start_us"]) * 1e3))),
+                     End_Timestamp=str(int(round(float(r["end_us"]) * 1e3))), Queue_Id=r["queue"]) for r in csv.DictReader(open(path))]
+        rows.append(dict(Kernel_Name="ohem_up_fwd sentinel", Start_Timestamp=rows[-1]["End_Timestamp"], End_Timestamp=rows[-1]["End_Timestamp"], Queue_Id="-"))
+    else:
+        path = glob.glob(os.path.join(run_dir, "**", "*_kernel_trace.csv"), recursive=True)[0]
+        rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     name = lambda r: r["Kernel_Name"]
-    is_rccl = lambda r: any(k in name(r) for k in ("nccl", "Nccl", "rccl"))
+    # (at world size 1 RCCL runs its all-reduce as `oneRankReduce<FuncPreMulSum<float>>`: the AVG pre-multiplication, one kernel per bucket)
+    is_rccl = lambda r: any(k in name(r) for k in ("nccl", "Nccl", "rccl", "oneRankReduce"))
     steps = [i for i, r in enumerate(rows) if "ohem_up_fwd" in name(r)]          # one forward OHEM launch per step
     first_fwd = [i for i, r in enumerate(rows) if "stem_conv_fwd" in name(r)]    # sb.conv1 forward: first kernel of a step
     lo = max(i for i in first_fwd if i < steps[-1])
     hi = len(rows)
-    step = rows[lo:hi]
+    step = [r for r in rows[lo:hi] if "sentinel" not in name(r)]
     t0 = int(step[0]["Start_Timestamp"])
     us = lambda t: (int(t) - t0) / 1e3
-    with open(out + ".csv", "w", newline="") as f:
+    if not run_dir.endswith(".csv"):
+      with open(out + ".csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["start_us", "end_us", "dur_us", "queue", "rccl", "kernel"])
         for r in step:
@@ -47,20 +55,29 @@ def main(run_dir, out):
              f"* B3 spatial branch (`sb`): ends with `stem_conv_wrw_kernel` at {span(wrw)[1]:.0f} us" if wrw else "",
              f"* last compute kernel of the step (optimizer) ends at {us(max(int(r['End_Timestamp']) for r in comp)):.0f} us\n",
              "## RCCL kernels\n",
-             "| # | start | end | duration | compute kernels running meanwhile (time inside the interval) | segment it overlaps |",
-             "|---|---|---|---|---|---|"]
+             "| # | start | end | duration | compute kernels running meanwhile (time inside the interval) | previous compute kernel ended | next compute kernel starts | position in the schedule |",
+             "|---|---|---|---|---|---|---|---|"]
     for i, r in enumerate([r for r in step if is_rccl(r)]):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         busy = sum(max(0, min(e, int(c["End_Timestamp"])) - max(s, int(c["Start_Timestamp"]))) for c in comp)
         n_over = sum(1 for c in comp if int(c["End_Timestamp"]) > s and int(c["Start_Timestamp"]) < e)
         seg = "-"
+        if dw and us(e) <= span(dw)[0]:
+            seg = "B1 | B2 boundary: decoder bucket, issued behind graph B1, graph B2 (backbone backward) enqueued beside it"
         if dw and us(s) < span(dw)[1] and us(e) > span(dw)[0]:
-            seg = "B2 (backbone backward)"
+            seg = "inside B2 (backbone backward)"
         if wrw and dw and us(s) >= span(dw)[1] and us(s) < span(wrw)[1]:
-            seg = "B3 (spatial-branch backward)"
+            seg = "B2 | B3 boundary / inside B3: backbone bucket beside the spatial branch's backward"
         if wrw and us(s) >= span(wrw)[1]:
-            seg = "exposed (after the last backward kernel)"
-        lines.append(f"| {i} | {us(s):.0f} | {us(e):.0f} | {(e - s) / 1e3:.0f} | {n_over} kernels, {busy / 1e3:.0f} us | {seg} |")
+            seg = "after the last backward kernel: the spatial branch's own bucket (the only exposed collective)"
+        prev_end = max((int(c["End_Timestamp"]) for c in comp if int(c["End_Timestamp"]) <= s), default=s)
+        next_start = min((int(c["Start_Timestamp"]) for c in comp if int(c["Start_Timestamp"]) >= e), default=e)
+        lines.append(f"| {i} | {us(s):.0f} | {us(e):.0f} | {(e - s) / 1e3:.0f} | {n_over} kernels, {busy / 1e3:.0f} us | "
+                     f"{(s - prev_end) / 1e3:.0f} us earlier | {(next_start - e) / 1e3:.0f} us later | {seg} |")
+    lines.append("\nAt world size 1 RCCL's all-reduce is a `oneRankReduce` kernel of a few microseconds per bucket (the AVG pre-multiplication): "
+                 "this trace shows WHERE in the schedule each bucket's collective is issued -- on RCCL's own stream, behind the graph "
+                 "segment that produced the bucket and beside the next segment -- not how long a real 8-rank all-reduce lasts "
+                 "(no 8-GPU node was available to the builder; the driver's SCALE run measures that).")
     open(out + ".md", "w").write("\n".join(l for l in lines if l != "") + "\n")
     print("\n".join(lines[-12:]))
     print("wrote", out + ".csv", out + ".md")
