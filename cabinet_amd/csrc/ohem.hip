@@ -494,6 +494,8 @@ static void ohem_segment(int C, int Wl, int W, int& SX, int& nox_max, int& R, in
     const float rw = (float)Wl / (float)W;
     R = (W + Wl / 2) / Wl;
     if (R < 1) R = 1;
+    // (a segment as wide as the whole row -- no halo pixels, exactly filled passes -- measured 164 vs 157 us for both heads:
+    // residency, 7 workgroups per CU by LDS, hides more of the dependent phases than the halo costs)
     for (SX = 64; SX >= 1; SX >>= 1) {
         nox_max = (int)((float)(SX + 2) / rw) + 8;
         gplane = ceil_div(nox_max, R);
