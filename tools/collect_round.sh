@@ -23,3 +23,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- pytho
 cd $GRAFT_REPO_ROOT && python tools/summarize_rocprof.py /tmp/prof_bench gpurun_out/${TAG}_bench_n1 "rocprofv3 --kernel-trace --stats of: python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-roofline --no-graph (eager enqueue, so that every kernel is a separate dispatch)"
 bash tools/pmc_traffic.sh
 bash tools/pmc_counters.sh $TAG
+# the bench line again, now that the traffic profile of THIS build exists (bench.py checks the source digest)
+cp $O/${TAG}_pmc_traffic.json $GRAFT_REPO_ROOT/profiles/${TAG}_pmc_traffic.json
+cd $GRAFT_REPO_ROOT && python bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.log
+tail -c 300 $O/${TAG}_bench_n1.json
+python tools/run_config5.py > $O/${TAG}_config5.log 2>&1; tail -n 3 $O/${TAG}_config5.log

@@ -31,6 +31,8 @@ def main(root, out_path):
         for k, cs in acc.items():
             row = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
             row["launches_seen"] = max(len(v) for v in cs.values())
+            if row["launches_seen"] < 4:  # operand set-up of an earlier group (run once or twice), not this group's 4 iterations
+                continue
             waves = row.get("SQ_WAVES", 0.0)
             if row.get("GRBM_GUI_ACTIVE"):
                 row["mfma_busy_share"] = round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * 256 * row["GRBM_GUI_ACTIVE"] / 8.0), 4)
@@ -43,7 +45,8 @@ def main(root, out_path):
     out = {"source_digest": build.source_digest(), "batch": int(os.environ.get("CAB_B", "8")),
            "size": int(os.environ.get("CAB_SIZE", "1024")),
            "method": "rocprofv3 --pmc, three separate counter-only passes per kernel group over tools/run_kernels.py 4 <group> "
-                     "(tools/pmc_counters.sh); per-launch averages per kernel",
+                     "(tools/pmc_counters.sh); per-launch averages per kernel; kernels launched fewer than 4 times in a group's "
+                     "run (operand set-up of earlier groups) are dropped",
            "groups": groups}
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     for g, ks in groups.items():
