@@ -4,7 +4,7 @@
 # usage (on the GPU box):  bash tools/pmc_traffic.sh [group ...]   ->  gpurun_out/r03_pmc_traffic.json
 set -u
 cd /tmp && export TMPDIR=/tmp
-GROUPS_ALL="cab_attn_fwd cab_attn_fwd_bf16x6 cab_attn_fwd_bf16x3 cab_attn_bwd ffm_fwd ffm_bwd ffm_up_fwd ffm_up_bwd bn_act_fwd bn_act_bwd bn_dwconv_fwd bn_dwconv_bwd stem_conv_fwd stem_conv_wrw pwconv_fwd pwconv_bwd ohem_up_fwd ohem_up_bwd ohem_up_pair_fwd ohem_up_pair_bwd cab_local_fwd cab_local_bwd cab_qkv_fwd cab_qkv_bwd"
+GROUPS_ALL="cab_attn_fwd cab_attn_fwd_bf16x6 cab_attn_fwd_bf16x3 cab_attn_bwd ffm_fwd ffm_bwd ffm_up_fwd ffm_up_fwd_bf16x6 ffm_up_fwd_bf16x3 ffm_up_bwd bn_act_fwd bn_act_bwd bn_dwconv_fwd bn_dwconv_bwd stem_conv_fwd stem_conv_wrw pwconv_fwd pwconv_bwd ohem_up_fwd ohem_up_bwd ohem_up_pair_fwd ohem_up_pair_bwd cab_local_fwd cab_local_bwd cab_qkv_fwd cab_qkv_bwd"
 GROUPS_RUN=${*:-$GROUPS_ALL}
 OUT=/tmp/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
