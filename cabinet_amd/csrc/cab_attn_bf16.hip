@@ -21,6 +21,8 @@
 // The kernel keeps cab_attn_fwd.hip's structure: query on the lane, 4 waves split the key tiles (no barrier in the loop), one
 // wave per SIMD with Q / K / V / O register-resident, next tile's S chain and softmax software-pipelined against the current
 // tile's PV chain, deferred rescaling, 4-wave merge through LDS, kvsplit for small grids.
+#include <stdint.h>
+
 #include <type_traits>
 
 #include "common.hpp"
@@ -68,34 +70,51 @@ struct SplitTerms<3> {
 //   q, k (B, KC, n) -> [b][piece][s][i][h][8]     blocks [0, 2 nbqk): 256 threads = 128 positions x 2 halves of one channel block
 //   v (B, VC, n)    -> [b][piece][kb][c][h][8]    the rest: a workgroup transposes a 32-channel x 64-key block through LDS so
 //                                                 that both the read (along keys) and the write (along channels) are contiguous
-template <int NS>
+template <int NS, bool VEC>  // VEC: n % 4 == 0 -- 16-byte loads, a thread packs FOUR consecutive positions (q, k) / eight keys (v)
 __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, u32x4* __restrict__ qp, u32x4* __restrict__ kp,
                                                         u32x4* __restrict__ vp, int KC, int VC, int n, int n32, int B) {
     __shared__ float tile[32][65];
-    const int pb = (n32 + 127) >> 7, S = KC >> 4, nbqk = pb * S * B;
+    constexpr int PPT = VEC ? 4 : 1, PB = 128 * PPT;  // positions per thread / per block of the q, k roles
+    const int pb = (n32 + PB - 1) / PB, S = KC >> 4, nbqk = pb * S * B;
     int blk = blockIdx.x;
     if (blk < 2 * nbqk) {
         const float* src = blk < nbqk ? q : k;
         u32x4* dst = blk < nbqk ? qp : kp;
         if (blk >= nbqk) blk -= nbqk;
         const int b = blk / (pb * S), r = blk - b * pb * S, s = r / pb;
-        const int i = (r - s * pb) * 128 + (threadIdx.x >> 1), h = threadIdx.x & 1;
+        const int i = (r - s * pb) * PB + (threadIdx.x >> 1) * PPT, h = threadIdx.x & 1;
         if (i >= n32) return;
-        bf16x8 out[NS];
         const float* p = src + ((size_t)b * KC + 16 * s + 8 * h) * n + i;
-        float x[8];
+        float x[PPT][8];
+        if (VEC) {  // all eight 16-byte loads in flight before any arithmetic (n % 4 == 0 and i % 4 == 0: whole vectors in or out)
+            f32x4 t[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = i < n ? p[(size_t)e * n] : 0.f;  // all eight loads in flight before any arithmetic
+            for (int e = 0; e < 8; ++e) t[e] = i < n ? *reinterpret_cast<const f32x4*>(p + (size_t)e * n) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            __bf16 pc[NS];
-            split_bf16<NS>(x[e], pc);
+            for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int c = 0; c < NS; ++c) out[c][e] = pc[c];
+                for (int j = 0; j < PPT; ++j) x[j][e] = t[e][j];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[0][e] = i < n ? p[(size_t)e * n] : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < NS; ++c) dst[((((size_t)b * NS + c) * S + s) * n32 + i) * 2 + h] = __builtin_bit_cast(u32x4, out[c]);
+        for (int j = 0; j < PPT; ++j) {
+            bf16x8 out[NS];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 pc[NS];
+                split_bf16<NS>(x[j][e], pc);
+#pragma unroll
+                for (int c = 0; c < NS; ++c) out[c][e] = pc[c];
+            }
+            if (i + j < n32) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c)
+                    dst[((((size_t)b * NS + c) * S + s) * n32 + i + j) * 2 + h] = __builtin_bit_cast(u32x4, out[c]);
+            }
+        }
         return;
     }
     blk -= 2 * nbqk;
@@ -104,8 +123,18 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
     {
         const int c = threadIdx.x >> 3, col0 = (threadIdx.x & 7) * 8;
         const float* p = v + ((size_t)b * VC + c0 + c) * n;
+        if (VEC) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tile[c][col0 + e] = (j0 + col0 + e < n) ? p[j0 + col0 + e] : 0.f;
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + col0 + 4 * u;
+                const f32x4 t = j < n ? *reinterpret_cast<const f32x4*>(p + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[c][col0 + 4 * u + e] = t[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[c][col0 + e] = (j0 + col0 + e < n) ? p[j0 + col0 + e] : 0.f;
+        }
     }
     __syncthreads();
     const int kbl = threadIdx.x >> 6, c = (threadIdx.x >> 1) & 31, h = threadIdx.x & 1, kb = (j0 >> 4) + kbl;
@@ -403,8 +432,12 @@ static hipError_t launch_fwd_bf16(const float* q, const float* k, const float* v
     u32x4* qp = static_cast<u32x4*>(pack);
     u32x4* kp = qp + qk_chunks;
     u32x4* vp = kp + qk_chunks;
-    const int nb_pack = 2 * ceil_div(n32, 128) * (KC / 16) * B + ceil_div(n32, 64) * (VC / 32) * B;
-    hipLaunchKernelGGL((attn_pack_kernel<NS>), dim3(nb_pack), dim3(256), 0, stream, q, k, v, qp, kp, vp, KC, VC, n, n32, B);
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int nb_pack = 2 * ceil_div(n32, vec ? 512 : 128) * (KC / 16) * B + ceil_div(n32, 64) * (VC / 32) * B;
+    if (vec)
+        hipLaunchKernelGGL((attn_pack_kernel<NS, true>), dim3(nb_pack), dim3(256), 0, stream, q, k, v, qp, kp, vp, KC, VC, n, n32, B);
+    else
+        hipLaunchKernelGGL((attn_pack_kernel<NS, false>), dim3(nb_pack), dim3(256), 0, stream, q, k, v, qp, kp, vp, KC, VC, n, n32, B);
     const size_t lds = (size_t)(4 * VC * 33 + 3 * 128) * sizeof(float);
     auto kern = cab_attn_fwd_bf16_kernel<KC, VC, NS>;
     static lds_attr_mask attr_mask{0};
