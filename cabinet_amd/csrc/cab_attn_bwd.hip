@@ -16,17 +16,20 @@
 //
 // Default form (n % 4 == 0 and B*n*n*4 <= DS_MAX_BYTES), no atomics, bitwise deterministic -- S and dP are computed ONCE:
 //   prep      D_i = sum_c g ctx, and the mean key                                            (attn_bwd_prep_kernel)
-//   dk, dv    workgroup = 32 keys, 4 waves split the queries; S = Q^T K, dP = G^T V, dV += G P, dK += Q dS;
-//             it also STORES dS (B*n*n floats, rows of 128 contiguous bytes)                  (cab_attn_bwd_dkdv_fast_kernel)
-//   dq        = scale * dS (K - mean K)^T as a small-GEMM product over the stored dS         (sg_gemm + sum_parts)
+//   dk, dv    workgroup = 32 keys, 8 waves (two per SIMD) split the queries; S = Q^T K, dP = G^T V, dV += G P, dK += Q dS;
+//             it also STORES dS (B*n*n floats, rows of 128 contiguous bytes)                  (cab_attn_bwd_dkdv_w8_kernel)
+//   dq        = scale * dS (K - mean K)^T, one kernel over the stored dS, no partial slabs   (cab_attn_bwd_dq_ds_kernel)
 // executed = algorithmic FLOPs, 2 n^2 (3Kc + 2Vc) per image.  Fallback forms that recompute S and dP for dq instead of
-// storing dS (2 n^2 (4Kc + 3Vc) executed): ragged n and dS above DS_MAX_BYTES (cab_attn_bwd_dq_fast_kernel), and the
-// generic chunk-staged pair cab_attn_bwd_dq_kernel / cab_attn_bwd_dkdv_kernel for (Kc, Vc) = (256, 128) in those cases.
+// storing dS (2 n^2 (4Kc + 3Vc) executed): ragged n and dS above DS_MAX_BYTES (cab_attn_bwd_dq_fast_kernel with the
+// one-wave-per-SIMD cab_attn_bwd_dkdv_fast_kernel), and the generic chunk-staged pair cab_attn_bwd_dq_kernel /
+// cab_attn_bwd_dkdv_kernel for (Kc, Vc) = (256, 128) in those cases.
 //
 // Layout trick shared with the forward kernel: the tile index that is NOT contracted
 // sits on the lane, so every accumulator is directly the B operand of the next product
 // and only the operand that must be read "channel on lane" crosses LDS, in 32-channel
 // chunks through a small wave-private double buffer (no workgroup barrier in the loop).
+#include <type_traits>
+
 #include "blocks.hpp"
 #include "common.hpp"
 
@@ -44,13 +47,13 @@ __device__ __forceinline__ void stage_chunk(float* tb, const float* __restrict__
 }
 
 // Pre-pass of the stored-dS form, ONE launch with two roles:
-//   blocks [0, nb_delta)  D_i = sum_c g[b][c][i] ctx[b][c][i] for 64 queries per workgroup (4 waves split the channels)
+//   blocks [0, nb_delta)  D_i = sum_c g[b][c][i] ctx[b][c][i] for 64 queries per workgroup (8 waves split the channels)
 //   the rest              kmean[b][c] = mean_j k[b][c][j], one wave per row (any vector near the mean serves the identity
 //                         of the header; fp32 is ample)
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ ctx,
+__global__ __launch_bounds__(512) void attn_bwd_prep_kernel(const float* __restrict__ g, const float* __restrict__ ctx,
                                                              const float* __restrict__ k, float* __restrict__ delta,
                                                              float* __restrict__ kmean, int VC, int rows, int n, int nb_delta) {
-    __shared__ float part[4][64];
+    __shared__ float part[8][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if ((int)blockIdx.x < nb_delta) {
         const int tiles = (n + 63) >> 6, b = blockIdx.x / tiles, i = (blockIdx.x - b * tiles) * 64 + lane;
@@ -58,18 +61,21 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
         if (i < n) {
             const float* gp = g + (size_t)b * VC * n + i;
             const float* cp = ctx + (size_t)b * VC * n + i;
-#pragma unroll 8
-            for (int c = wave; c < VC; c += 4) acc += gp[(size_t)c * n] * cp[(size_t)c * n];
+#pragma unroll 16
+            for (int c = wave; c < VC; c += 8) acc += gp[(size_t)c * n] * cp[(size_t)c * n];
         }
         part[wave][lane] = acc;
         __syncthreads();
-        if (wave == 0 && i < n) delta[(size_t)b * n + i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (wave == 0 && i < n)
+            delta[(size_t)b * n + i] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                                       ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
         return;
     }
-    const int row = (blockIdx.x - nb_delta) * 4 + wave;
+    const int row = (blockIdx.x - nb_delta) * 8 + wave;
     if (row >= rows) return;
     const float* p = k + (size_t)row * n;
     float a = 0.f;
+#pragma unroll 4
     for (int j = lane; j < n; j += 64) a += p[j];
     a = wave_sum(a);
     if (lane == 0) kmean[row] = a / (float)n;
@@ -630,6 +636,236 @@ __global__ __launch_bounds__(256) void cab_attn_bwd_dkdv_fast_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two waves per SIMD.  The kernel above holds a whole query tile of q and g in 128 staging registers (416 in all, one wave
+// per SIMD): its softmax, row-constant loads and dS stores run with the matrix pipe idle (59 % busy).  This form needs no
+// transposed LDS images and 256 registers:
+//   * the "channel on lane" operand of the dv / dk products is read STRAIGHT from global memory.  At product step r the
+//     B operand p[r] of lane (key, h) is row acc_row(r) + 4h of the tile, so lane (channel, h) needs
+//     g[channel][i0 + 8 (r / 4) + 4h + r % 4]: four consecutive floats per r / 4 -- one 16-byte buffer load serves four
+//     product steps, and the four loads of a 32-channel block use every byte of the 32 cache lines they touch;
+//   * every operand travels in BATCHES of 16 registers, one batch per 16 MFMAs (q and g chain batches, then the transposed
+//     g and q blocks), double-buffered: batch K + 1 is loaded in the MFMA slots of batch K, the last batch of a tile loads
+//     the first one of the wave's next tile.  q and g of an image (1 MB at config 3) stay in the XCD's L2;
+//   * 8 waves split the queries of the workgroup's 32 keys; the second wave of each SIMD covers the other one's softmax.
+// LDS holds only the raw k | v tiles; after the loop it is reused for a three-round tree sum of the eight partial results.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+
+// An MFMA has no side effect, so instruction selection is free to sink a whole chain below the loads that share its slots
+// (it did: every S / dP MFMA landed behind the last prefetch and 72 registers spilled).  An empty volatile asm that "modifies"
+// the accumulator is ordered against the slot fences and emits nothing.
+__device__ __forceinline__ void pin(f32x16& acc) { asm volatile("" : "+v"(acc)); }
+
+template <int KC, int VC, bool DK>
+__global__ __launch_bounds__(512) void cab_attn_bwd_dkdv_w8_kernel(
+    const float* __restrict__ g, const float* __restrict__ q, const float* __restrict__ k,
+    const float* __restrict__ v, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ ds, int n, float scale, int B, int nsplit) {
+    constexpr int KB = KC / 32, VB = VC / 32, NW = 8;
+    constexpr int QT0 = KB + 2 * VB;                 // first transposed q batch
+    constexpr int NBATCH = QT0 + (DK ? KB : 0);      // q chain | g chain | g transposed | q transposed
+    static_assert(NBATCH % 2 == 0, "the buffer parity of batch 0 must repeat from tile to tile");
+    constexpr int IMG = (DK ? KC + VC : VC) * 32, VOFF = DK ? KC : 0;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* kt = smem;            // [KC][32] raw k tile   (B operand of S)
+    float* vt = kt + KC * 32;    // [VC][32] raw v tile   (B operand of dP)
+    float* s_lse = vt + VC * 32; // [n4] log2(e) * lse of the image's queries, then [n4] D_i (n4 = n rounded up to 4)
+    float* red = smem;           // [4][IMG] reduction scratch, aliases all of the above after the main loop
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int nkt = (n + 31) >> 5, per_img = nkt * nsplit;
+    const int tile = xcd_chunked_tile(blockIdx.x, per_img * B);
+    const int b = tile / per_img, rem = tile - b * per_img, split = rem / nkt, j0 = (rem - split * nkt) * 32;
+    const int tstep = NW * nsplit, t0 = split * NW + wave;
+    const size_t qk_base = (size_t)b * KC * n, v_base = (size_t)b * VC * n;
+    const float qscale = scale * LOG2E_F;
+    const int row_bytes = n * 4;
+    const buf_rsrc q_rs = make_rsrc(q + qk_base, (unsigned)KC * row_bytes);
+    const buf_rsrc g_rs = make_rsrc(g + v_base, (unsigned)VC * row_bytes);
+    const int NT = (n + 31) >> 5, n4 = (n + 3) & ~3;
+    float* s_delta = s_lse + n4;
+
+    f32x4 buf[2][4];   // the two operand batches in flight
+    int voff_c, voff_cn, cq[4];  // chain offsets of this / the next tile; first query of each transposed quad of this tile
+    const int lin4 = li * n * 4;
+    auto chain_off = [&](int t) { return (h * n + min(min(t, NT - 1) * 32 + li, n - 1)) * 4; };
+
+    // element U of batch KN (KN == NBATCH: batch 0 of the wave's next tile)
+    auto prefetch = [&](auto kn_tag, auto u_tag) {
+        constexpr int KN = decltype(kn_tag)::value, U = decltype(u_tag)::value, P = KN & 1;
+        if constexpr (KN < KB) {
+            buf[P][U >> 2][U & 3] = bload(q_rs, voff_c, (32 * KN + 2 * U) * row_bytes);
+        } else if constexpr (KN < KB + VB) {
+            buf[P][U >> 2][U & 3] = bload(g_rs, voff_c, (32 * (KN - KB) + 2 * U) * row_bytes);
+        } else if constexpr (KN < QT0) {
+            if constexpr (U < 4) buf[P][U] = bload4(g_rs, lin4 + cq[U] * 4, (KN - KB - VB) * 32 * row_bytes);
+        } else if constexpr (KN < NBATCH) {
+            if constexpr (U < 4) buf[P][U] = bload4(q_rs, lin4 + cq[U] * 4, (KN - QT0) * 32 * row_bytes);
+        } else {
+            buf[P][U >> 2][U & 3] = bload(q_rs, voff_cn, 2 * U * row_bytes);
+        }
+    };
+
+    voff_c = chain_off(t0);
+    static_for<0, 16>([&](auto u) { prefetch(std::integral_constant<int, 0>{}, u); });
+    {
+        const int j = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int jg = min(j0 + j, n - 1);
+        for (int c = part; c < KC; c += 16) kt[c * 32 + j] = k[qk_base + (size_t)c * n + jg];
+        for (int c = part; c < VC; c += 16) vt[c * 32 + j] = v[v_base + (size_t)c * n + jg];
+        for (int i = threadIdx.x; i < n; i += 512) {  // row constants of every query of the image (8 n bytes)
+            s_lse[i] = lse[(size_t)b * n + i] * LOG2E_F;
+            s_delta[i] = delta[(size_t)b * n + i];
+        }
+    }
+    __syncthreads();
+
+    f32x16 dka[DK ? KB : 1], dva[VB];
+#pragma unroll
+    for (int cb = 0; cb < (DK ? KB : 1); ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dka[cb][r] = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dva[cb][r] = 0.f;
+
+    for (int t = t0; t < NT; t += tstep) {
+        const int i0 = t * 32;
+        voff_c = chain_off(t), voff_cn = chain_off(t + tstep);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cq[a] = min(i0 + 8 * a + 4 * h, n - 4);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f, dp[r] = 0.f;
+        // S = q^T k and dP = g^T v: A from the batch registers, B from the LDS tiles (read four slots ahead)
+        {
+            float bq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bq[u] = kt[(2 * u + h) * 32 + li];
+            static_for<0, KC / 2>([&](auto c2_tag) {
+                constexpr int c2 = decltype(c2_tag)::value, K = c2 / 16, U = c2 % 16;
+                const float bcur = bq[c2 & 3];
+                if constexpr (c2 + 4 < KC / 2) bq[c2 & 3] = kt[(2 * (c2 + 4) + h) * 32 + li];
+                s = mfma32(buf[K & 1][U >> 2][U & 3], bcur, s);
+                pin(s);
+                prefetch(std::integral_constant<int, K + 1>{}, std::integral_constant<int, U>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bq[u] = vt[(2 * u + h) * 32 + li];
+            static_for<0, VC / 2>([&](auto c2_tag) {
+                constexpr int c2 = decltype(c2_tag)::value, K = KB + c2 / 16, U = c2 % 16;
+                const float bcur = bq[c2 & 3];
+                if constexpr (c2 + 4 < VC / 2) bq[c2 & 3] = vt[(2 * (c2 + 4) + h) * 32 + li];
+                dp = mfma32(buf[K & 1][U >> 2][U & 3], bcur, dp);
+                pin(dp);
+                prefetch(std::integral_constant<int, K + 1>{}, std::integral_constant<int, U>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        f32x16 p;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {  // the four rows of quad a: one broadcast 16-byte LDS read per constant
+            const f32x4 l2 = *reinterpret_cast<const f32x4*>(s_lse + cq[a]);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(s_delta + cq[a]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * a + e;
+                const bool valid = i0 + acc_row(r) + 4 * h < n;
+                p[r] = valid ? fast_exp2(fmaf(s[r], qscale, -l2[e])) : 0.f;  // P[query][key]
+                s[r] = p[r] * (dp[r] - dl[e]);                               // dS[query][key]
+            }
+        }
+        if (ds && j0 + li < n) {
+            float* dsp = ds + ((size_t)b * n + i0 + 4 * h) * n + j0 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (i0 + acc_row(r) + 4 * h < n) dsp[(size_t)acc_row(r) * n] = s[r];
+        }
+        // dv += g P, dk += q dS: A = the transposed batch (channel on lane), B = p / dS registers
+        static_for<0, VB>([&](auto cb_tag) {
+            constexpr int cb = decltype(cb_tag)::value, K = KB + VB + cb;
+            static_for<0, 16>([&](auto r_tag) {
+                constexpr int r = decltype(r_tag)::value;
+                dva[cb] = mfma32(buf[K & 1][r >> 2][r & 3], p[r], dva[cb]);
+                pin(dva[cb]);
+                prefetch(std::integral_constant<int, K + 1>{}, r_tag);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        if constexpr (DK) {
+            static_for<0, KB>([&](auto cb_tag) {
+                constexpr int cb = decltype(cb_tag)::value, K = QT0 + cb;
+                static_for<0, 16>([&](auto r_tag) {
+                    constexpr int r = decltype(r_tag)::value;
+                    dka[cb] = mfma32(buf[K & 1][r >> 2][r & 3], s[r], dka[cb]);
+                    pin(dka[cb]);
+                    prefetch(std::integral_constant<int, K + 1>{}, r_tag);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        }
+    }
+
+    // ---- tree sum of the eight waves' partial results: 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0 (fixed order: deterministic) ----
+    auto put = [&](float* dst) {
+        if constexpr (DK) {
+#pragma unroll
+            for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(cb * 32 + acc_row(r) + 4 * h) * 32 + li] = dka[cb][r];
+        }
+#pragma unroll
+        for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(VOFF + cb * 32 + acc_row(r) + 4 * h) * 32 + li] = dva[cb][r];
+    };
+    auto add = [&](const float* src) {
+        if constexpr (DK) {
+#pragma unroll
+            for (int cb = 0; cb < KB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dka[cb][r] += src[(cb * 32 + acc_row(r) + 4 * h) * 32 + li];
+        }
+#pragma unroll
+        for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dva[cb][r] += src[(VOFF + cb * 32 + acc_row(r) + 4 * h) * 32 + li];
+    };
+    __syncthreads();  // every wave is done with the k | v tiles
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) put(red + (wave - half) * IMG);
+        __syncthreads();
+        if (wave < half) add(red + wave * IMG);
+        __syncthreads();
+    }
+    if (wave == 0) put(red);
+    __syncthreads();
+    float* dk_out = dk + (size_t)split * B * KC * n;
+    float* dv_out = dv + (size_t)split * B * VC * n;
+    if constexpr (DK) {
+        for (int idx = threadIdx.x; idx < KC * 32; idx += 512) {
+            const int c = idx >> 5, j = idx & 31;
+            if (j0 + j < n) dk_out[qk_base + (size_t)c * n + j0 + j] = red[idx] * scale;
+        }
+    }
+    for (int idx = threadIdx.x; idx < VC * 32; idx += 512) {
+        const int c = idx >> 5, j = idx & 31;
+        if (j0 + j < n) dv_out[v_base + (size_t)c * n + j0 + j] = red[VOFF * 32 + idx];
+    }
+}
+
 // workgroups per tile so that a small batch still covers the chip (each wave keeps >= 2 tiles)
 static int bwd_nsplit(int B, int n) {
     const int nt = (n + 31) / 32;
@@ -638,40 +874,171 @@ static int bwd_nsplit(int B, int n) {
     return split;
 }
 
-// dq from the stored dS: dq[b][c][i] = scale * sum_j dS[b][i][j] (k[b][c][j] - mean_j k[b][c][.])  -- one job of the small
-// GEMM (A = K as stored, row-biased; B = dS position-major), 2 n^2 Kc FLOP per image instead of the 6 n^2 Kc of a dq
-// kernel that recomputes S and dP.
-// The key range is cut into `ksplit` segments, one job each (the launch then has 4x .. 8x more workgroups than CUs and
-// every workgroup only 8 dependent chunks: a single job had one workgroup per CU walking 32 chunks, latency-bound at 64 us);
-// the partial dq slabs are summed in order.
+// ---------------------------------------------------------------------------------------------------------------------
+// dq from the stored dS, dq[b][c][i] = scale * sum_j (k[b][c][j] - mean_j k[b][c][.]) dS[b][i][j], as ONE kernel without LDS
+// operands and without partial slabs.  Both operands have the contracted index j contiguous in memory (k rows, dS rows), so
+// each lane loads four consecutive j with one 16-byte buffer load: lane (c, h) of A and lane (i, h) of B both take
+// j8 + 4h .. + 3 of an eight-key octet, and MFMA step e of the octet contracts the key pair (j8 + e, j8 + 4 + e) -- any
+// pairing serves as long as A and B agree.  Workgroup = 32 queries x NCB blocks of 32 channels; its 8 waves (two per SIMD)
+// split the key range in groups of 32 keys (one cache line per row) prefetched a group ahead in registers, and their partial
+// tiles meet in a three-round tree sum through LDS.  Replaces a key-split small-GEMM launch (31 us at
+// config 3: 64 x 64 tiles, operands staged through LDS) plus the ordered sum of its four partial slabs (5 us).
+template <int NCB>
+__global__ __launch_bounds__(512) void cab_attn_bwd_dq_ds_kernel(const float* __restrict__ k, const float* __restrict__ kmean,
+                                                                  const float* __restrict__ ds, float* __restrict__ dq, int KC,
+                                                                  int n, float scale, int B) {
+    constexpr int IMG = NCB * 32 * 32, NQ = NCB * 4, RS = 36, KIMG = NCB * 32 * RS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;  // [4][IMG] after the main loop; before it: [8 waves][KIMG] wave-private k images
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    float* kimg = smem + wave * KIMG;  // [NCB * 32 channels][32 keys], row stride 36 words (16-byte reads of 16 rows: no conflict)
+    const int nqt = (n + 31) >> 5;
+    const int tile = xcd_chunked_tile(blockIdx.x, nqt * B);
+    const int b = tile / nqt, i0 = (tile - b * nqt) * 32, cb0 = blockIdx.y * NCB;
+    const int row_bytes = n * 4;
+    const int span = ((n + 255) >> 8) << 5;  // keys per wave: a multiple of the 32-key group
+    const int jb = wave * span, je = min(n, jb + span);
+    const int ng = je > jb ? (je - jb + 31) >> 5 : 0;
+    const buf_rsrc k_rs = make_rsrc(k + ((size_t)b * KC + cb0 * 32) * n, (unsigned)(NCB * 32) * row_bytes);
+    const int rows = min(32, n - i0);
+    const buf_rsrc ds_rs = make_rsrc(ds + ((size_t)b * n + i0) * n, (unsigned)rows * row_bytes);
+    const int b_off = min(li, rows - 1) * row_bytes;
+    float kbar[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) kbar[cb] = kmean[b * KC + (cb0 + cb) * 32 + li];
+
+    // A group = 32 keys = one 128-byte line of every row.
+    //   k : COALESCED 16-byte loads (an instruction = 8 rows x 128 bytes) -> wave-private LDS image -> one 16-byte LDS read per
+    //       (channel row, octet half).  Read per lane straight from global the same quads are a 32-line gather per instruction:
+    //       that form measured 31 us, 25 us with three of four k gathers removed -- the L1's line rate, not latency, bound it.
+    //   dS: four gathers per group (its rows are private to the workgroup and read once), a group ahead.
+    f32x4 S[NQ], a[2][4], Bq[2][4];  // staged k quads of the NEXT group; k operand quads of this / the next step; dS quads
+    const int srow = lane >> 3, squad = lane & 7;
+    auto stage_load = [&](int g) {
+        const int voff = (srow * n + min(jb + g * 32 + 4 * squad, n - 4)) * 4;  // clamped: masked at use where out of range
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) S[t] = bload4(k_rs, voff, 8 * t * row_bytes);
+    };
+    auto stage_write = [&](auto t_tag) {
+        constexpr int t = decltype(t_tag)::value;
+        *reinterpret_cast<f32x4*>(kimg + (8 * t + srow) * RS + 4 * squad) = S[t];
+    };
+    auto read_a = [&](auto par_tag, auto cb_tag, auto o_tag) {
+        constexpr int par = decltype(par_tag)::value, cb = decltype(cb_tag)::value, o = decltype(o_tag)::value;
+        a[par][o] = *reinterpret_cast<const f32x4*>(kimg + (cb * 32 + li) * RS + (2 * o + h) * 4);
+    };
+    auto load_b = [&](auto p_tag, auto o_tag, int g) {
+        constexpr int P = decltype(p_tag)::value, o = decltype(o_tag)::value;
+        Bq[P][o] = bload4(ds_rs, b_off + min(jb + g * 32 + 8 * o + 4 * h, n - 4) * 4, 0);
+    };
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+    // group g (dS buffer P): NCB steps of 16 MFMAs, one accumulator each.  Slots of a step: the next step's four k quads are
+    // read from LDS; the LAST step of a group lays down the staged group g + 1 (slots 0-7), reads the first step's quads of
+    // it (8-11) and requests group g + 2 from global memory (12-15) -- a whole group of lead.
+    auto group = [&](auto p_tag, int g) {
+        constexpr int P = decltype(p_tag)::value;
+        static_for<0, NCB>([&](auto cb_tag) {
+            constexpr int cb = decltype(cb_tag)::value, par = (P * NCB + cb) & 1;
+            constexpr bool LAST = cb == NCB - 1;
+            static_for<0, 4>([&](auto o_tag) {
+                constexpr int o = decltype(o_tag)::value;
+                const bool valid = jb + g * 32 + 8 * o + 4 * h < je;
+                f32x4 av;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = valid ? a[par][o][e] - kbar[cb] : 0.f;
+                static_for<0, 4>([&](auto e_tag) {
+                    constexpr int e = decltype(e_tag)::value, slot = 4 * o + e;
+                    acc[cb] = mfma32(av[e], Bq[P][o][e], acc[cb]);
+                    pin(acc[cb]);
+                    if constexpr (cb == 0 && e == 0) load_b(std::integral_constant<int, 1 - P>{}, o_tag, g + 1);
+                    if constexpr (!LAST && slot >= 4 && slot < 8)
+                        read_a(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, LAST ? 0 : cb + 1>{},
+                               std::integral_constant<int, slot - 4>{});
+                    if constexpr (LAST) {
+                        if constexpr (slot < 8)
+                            static_for<slot * NQ / 8, (slot + 1) * NQ / 8>([&](auto t) { stage_write(t); });
+                        else if constexpr (slot < 12)
+                            read_a(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, 0>{},
+                                   std::integral_constant<int, slot - 8>{});
+                        else if constexpr (slot == 12)
+                            stage_load(g + 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        });
+    };
+    stage_load(0);
+    static_for<0, 4>([&](auto o) { load_b(std::integral_constant<int, 0>{}, o, 0); });
+    static_for<0, NQ>([&](auto t) { stage_write(t); });
+    stage_load(1);
+    static_for<0, 4>([&](auto o) { read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, o); });
+    for (int g = 0; g < ng; g += 2) {
+        group(std::integral_constant<int, 0>{}, g);
+        group(std::integral_constant<int, 1>{}, g + 1);  // all-masked when ng is odd
+    }
+
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(cb * 32 + acc_row(r) + 4 * h) * 32 + li] = acc[cb][r];
+    };
+    __syncthreads();  // the partial-result images alias the k images
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) put(red + (wave - half) * IMG);
+        __syncthreads();
+        if (wave < half) {
+            const float* src = red + wave * IMG;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] += src[(cb * 32 + acc_row(r) + 4 * h) * 32 + li];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) put(red);
+    __syncthreads();
+    float* out = dq + ((size_t)b * KC + cb0 * 32) * n + i0;
+    for (int idx = threadIdx.x; idx < IMG; idx += 512) {
+        const int c = idx >> 5, i = idx & 31;
+        if (i0 + i < n) out[(size_t)c * n + i] = red[idx] * scale;
+    }
+}
+
+template <int NCB>
+static hipError_t launch_dq_ds_kernel(const float* k, const float* kmean, const float* ds, float scale, int B, int KC, int n,
+                                      float* dq, hipStream_t stream) {
+    auto fn = cab_attn_bwd_dq_ds_kernel<NCB>;
+    const size_t lds = (size_t)8 * NCB * 32 * 36 * sizeof(float);  // eight wave-private k images (>= the four result images)
+    static lds_attr_mask mask{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), lds, mask); e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(((n + 31) / 32) * B, KC / 32 / NCB), dim3(512), lds, stream, k, kmean, ds, dq, KC, n, scale, B);
+    return hipSuccess;
+}
+// channel blocks per workgroup: as many as still leave the chip covered (every workgroup re-reads its dS rows from L2)
+static hipError_t launch_dq_direct(const float* k, const float* kmean, const float* ds, float scale, int B, int KC, int n,
+                                   float* dq, hipStream_t stream) {
+    const int tiles = ((n + 31) / 32) * B, blocks = KC / 32;
+    if (blocks % 4 == 0 && tiles * (blocks / 4) >= 200) return launch_dq_ds_kernel<4>(k, kmean, ds, scale, B, KC, n, dq, stream);
+    if (blocks % 2 == 0 && tiles * (blocks / 2) >= 200) return launch_dq_ds_kernel<2>(k, kmean, ds, scale, B, KC, n, dq, stream);
+    return launch_dq_ds_kernel<1>(k, kmean, ds, scale, B, KC, n, dq, stream);
+}
+
+// segments of the contracted range of a product over the stored dS (one small-GEMM job each; partial slabs summed in order):
+// a single job had one workgroup per CU walking 32 dependent chunks, latency-bound
 static int dq_ksplit(int n) {
     int s = n / 256;
     s = s < 1 ? 1 : (s > 8 ? 8 : s);
     while (s > 1 && (n / s) % 4) --s;  // every segment keeps 16-byte aligned rows
     return s;
 }
-static void launch_dq_from_ds(const float* k, const float* kmean, const float* ds, float scale, int B, int KC, int n,
-                              float* dq, float* slabs, hipStream_t stream) {
-    const int ks = dq_ksplit(n), seg = (n / ks + 3) & ~3;
-    SgJobs jobs{};
-    jobs.n = ks;
-    for (int i = 0; i < ks; ++i) {
-        const int k0 = i * seg, kl = (i == ks - 1) ? n - k0 : seg;
-        SgJob& j = jobs.j[i];
-        j.seg[0] = {k + k0, ds + k0, kl, n};
-        j.nseg = 1, j.lda = n, j.a_mmajor = 1, j.M = KC, j.P = n, j.dst = ks == 1 ? dq : slabs + (size_t)i * B * KC * n,
-        j.dst_rows = KC;
-        j.b_pmajor = 1, j.ldb = n, j.a_bias = kmean, j.alpha = scale;
-        j.a_img_stride = (size_t)KC * n;  // A = the keys of image b
-    }
-    sg_gemm(jobs, B, stream);  // (128-row tiles, sg_gemm's mb = 2, read every dS tile once but measured 41 vs 36 us: the
-                               // product is bound by the per-chunk latency of its 8-chunk workgroups, not by traffic)
-    if (ks > 1) {
-        const size_t cq = (size_t)B * KC * n;
-        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, slabs, dq, cq, ks);
-    }
-}
-
 // dk from the stored dS: dk[b][c][j] = scale * sum_i q[b][c][i] dS[b][i][j]  (A = Q as stored, B = dS row-major), the query
 // range cut into segments like the key range above.  Used where the dk accumulators do not fit the dk/dv kernel (Kc = 256).
 static void launch_dk_from_ds(const float* q, const float* ds, float scale, int B, int KC, int n, float* dk, float* slabs,
@@ -710,7 +1077,7 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
     if (!DK && !dsp) return hipErrorInvalidValue;
     if (dsp) {
         const int nb_delta = B * ((n + 63) / 64);
-        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 3) / 4), dim3(256), 0, stream, g, ctx, k, delta,
+        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 7) / 8), dim3(512), 0, stream, g, ctx, k, delta,
                            kmean, VC, B * KC, n, nb_delta);
     } else {
         hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
@@ -741,36 +1108,46 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
                                    cq, nsplit);
         }
     }
+    // stored-dS form: the two-waves-per-SIMD kernel (16-byte transposed loads need n % 4 == 0, which that form implies)
+    auto k_w8 = cab_attn_bwd_dkdv_w8_kernel<KC, VC, DK>;
+    // k | v tiles + the image's row constants, reused as four partial-result images by the final tree sum
+    const size_t w8_loop = ((size_t)(KC + VC) * 32 + 2 * (size_t)((n + 3) & ~3)) * sizeof(float);
+    const size_t w8_tree = (size_t)4 * (DK ? KC + VC : VC) * 32 * sizeof(float);
+    const size_t lds_w8 = w8_loop > w8_tree ? w8_loop : w8_tree;
+    static lds_attr_mask mask_w8{0};
+    if (dsp) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_w8), lds_w8, mask_w8); e != hipSuccess) return e;
+    }
+    auto launch_kv = [&](float* dk_dst, float* dv_dst, int ns) {
+        if (dsp)
+            hipLaunchKernelGGL(k_w8, grid, dim3(512), lds_w8, stream, g, q, k, v, lse, delta, dk_dst, dv_dst, ds, n, scale, B, ns);
+        else
+            hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk_dst, dv_dst, ds, n, scale, B, ns);
+    };
     if (nsplit == 1) {
-        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, ds, n, scale, B, 1);
+        launch_kv(dk, dv, 1);
     } else {
         // partial slabs live behind D_i and the mean key in the workspace: [nsplit][B][KC][n] then [nsplit][B][VC][n]
-        hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, part_k, part_v, ds, n, scale, B, nsplit);
+        launch_kv(part_k, part_v, nsplit);
         if (DK)
             hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cq + 255) / 256)), dim3(256), 0, stream, part_k, dk, cq, nsplit);
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((cv + 255) / 256)), dim3(256), 0, stream, part_v, dv, cv, nsplit);
     }
     if (dsp) {
-        float* slabs = ds + (size_t)B * n * n;
-        launch_dq_from_ds(k, kmean, ds, scale, B, KC, n, dq, slabs, stream);
-        if (!DK) launch_dk_from_ds(q, ds, scale, B, KC, n, dk, slabs + (size_t)(dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * cq, stream);
+        if (hipError_t e = launch_dq_direct(k, kmean, ds, scale, B, KC, n, dq, stream); e != hipSuccess) return e;
+        if (!DK) launch_dk_from_ds(q, ds, scale, B, KC, n, dk, ds + (size_t)B * n * n, stream);
     }
     return hipGetLastError();
 }
 
+// generic chunk-staged pair, recompute form only: it serves (Kc, Vc) = (256, 128) where the stored-dS form does not apply
+// (ragged n, or dS above DS_MAX_BYTES); the dispatcher sends every other case to launch_bwd_fast
 template <int KC, int VC>
 static hipError_t launch_bwd(const float* g, const float* q, const float* k, const float* v, const float* ctx,
                              const float* lse, float scale, int B, int n, float* dq, float* dk, float* dv,
                              float* delta, hipStream_t stream) {
     float* kmean = delta + align_up((size_t)B * n, 64);
-    const bool dsp = use_ds_path(B, n);
-    if (dsp) {
-        const int nb_delta = B * ((n + 63) / 64);
-        hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(nb_delta + (B * KC + 3) / 4), dim3(256), 0, stream, g, ctx, k, delta,
-                           kmean, VC, B * KC, n, nb_delta);
-    } else {
-        hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
-    }
+    hipLaunchKernelGGL(attn_key_mean_kernel, dim3((B * KC + 3) / 4), dim3(256), 0, stream, k, kmean, B * KC, n);
     const size_t lds_dq = (size_t)((KC + VC) * 32 + 8 * TCHUNK + KC * 32 + 256 + 64 + KC) * sizeof(float);
     const size_t lds_kv = (size_t)((KC + VC) * 32 + 8 * TCHUNK + (KC + VC) * 32) * sizeof(float);
     auto k_dq = cab_attn_bwd_dq_kernel<KC, VC>;
@@ -779,11 +1156,8 @@ static hipError_t launch_bwd(const float* g, const float* q, const float* k, con
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_dq), lds_dq, mask_dq); e != hipSuccess) return e;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_kv), lds_kv, mask_kv); e != hipSuccess) return e;
     dim3 grid((n + 31) / 32, 1, B);
-    float* ds = dsp ? kmean + align_up((size_t)B * KC, 64) : nullptr;
-    if (!dsp)
-        hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale);
-    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, ds, n, scale);
-    if (dsp) launch_dq_from_ds(k, kmean, ds, scale, B, KC, n, dq, ds + (size_t)B * n * n, stream);
+    hipLaunchKernelGGL(k_dq, grid, dim3(256), lds_dq, stream, g, q, k, v, ctx, lse, kmean, dq, delta, n, scale);
+    hipLaunchKernelGGL(k_kv, grid, dim3(256), lds_kv, stream, g, q, k, v, lse, delta, dk, dv, (float*)nullptr, n, scale);
     return hipGetLastError();
 }
 
@@ -792,8 +1166,8 @@ size_t attn_bwd_workspace(int B, int Kc, int Vc, int n) {
     const bool fast = (Kc <= 128 && Kc + Vc <= 256) || (Kc == 256 && Vc == 128 && use_ds_path(B, n));
     const int nsplit = fast ? bwd_nsplit(B, n) : 1;
     if (nsplit > 1) bytes += (size_t)nsplit * B * (Kc + Vc) * n * sizeof(float);  // partial dq|dk and dv slabs
-    if (use_ds_path(B, n))  // dS, then the key-range slabs of dq (and the query-range slabs of dk for Kc = 256)
-        bytes += ((size_t)B * n * n + (size_t)(Kc == 256 ? 2 : 1) * (dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * B * Kc * n) *
+    if (use_ds_path(B, n))  // dS, then the query-range slabs of dk for Kc = 256 (dq needs none: cab_attn_bwd_dq_ds_kernel)
+        bytes += ((size_t)B * n * n + (size_t)(Kc == 256 ? 1 : 0) * (dq_ksplit(n) > 1 ? dq_ksplit(n) : 0) * B * Kc * n) *
                  sizeof(float);
     return align_up(bytes, 256);
 }
