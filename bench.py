@@ -310,7 +310,7 @@ def kernel_cases(batch, size):
     q3 = Fh.cab_qkv(xc, cab.global_attn)
     gq = [torch.randn_like(t) for t in q3]
     fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
-    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 5 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
+    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 4 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
     yield ("cab_qkv_bwd (K6: adjoint chain, 6 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
 
 

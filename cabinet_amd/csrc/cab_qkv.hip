@@ -15,8 +15,9 @@
 // the pooled bins (110 positions for sizes 1,3,6,8), done as ONE GEMM per branch over a block-expanded
 // operand, and come back as a 4-tap gather from LDS.  The three projections share one GEMM (stacked weights).
 //   fwd : G(x -> zq|zk|vv) as one 3-job launch, BN statistics + finalize (one launch), plane pass (BN+ReLU, q, kk, pooled bins),
-//         G(pooled -> T_k, T_v) + G(kk -> k, vv -> v) as one 4-job launch, pyramid add              = 5 launches
-//   bwd : the adjoint chain in 7 launches, all deterministic (no atomics)
+//         output stage (cab_qkv_fused.hip: T = W_i . pooled_i per workgroup, W_0 product, bilinear gathers)   = 4 launches
+//         (shapes outside that kernel's range: G(pooled -> T_k, T_v) + G(kk -> k, vv -> v) as one launch, pyramid add = 5)
+//   bwd : the adjoint chain in 6 launches, all deterministic (no atomics)
 // GEMMs are the job-batched exact-fp32 MFMA kernels of small_gemm.hip (64x64 tiles: the batch has only 8192 positions).
 #include "cab_qkv.hpp"
 
@@ -657,7 +658,7 @@ static SgJob sg_job(const float* a, int lda, int a_mmajor, const float* b, int k
     return sg_make(a, lda, a_mmajor, b, k, b_rows, M, P, dst, dst_rows);
 }
 
-// forward: 5 launches (was 11): [zq|zk|vv] GEMMs (one launch, weights read as stored), BN statistics + finalize,
+// forward: 4 launches where cab_qkv_fused.hip applies (the model's shapes), else 5: [zq|zk|vv] GEMMs (one launch, weights read as stored), BN statistics + finalize,
 // plane pass (BN + ReLU, q, kk, pooled bins), [T_k, T_v, W0 kk, W0 vv] GEMMs (one launch), pyramid add
 hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, int training, float momentum, float eps,
                        const QkvSaved& sv, float* q, float* k, float* v, void* ws, hipStream_t stream) {
@@ -666,6 +667,7 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
     const FwdWs L = fwd_layout(s);
     char* base = static_cast<char*>(ws);
     auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
+    const bool fused = qkv_fused_fwd_supported(s);
     {
         SgJobs jobs{};
         jobs.n = 3;
@@ -680,6 +682,10 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
                        w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean, sv.invstd);
     hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
                        sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);
+    if (fused) {  // the output products with the pyramid terms formed per workgroup (one launch instead of two)
+        if (hipError_t e = qkv_fused_out(s, w, sv, k, v, stream); e != hipSuccess) return e;
+        return hipGetLastError();
+    }
     {   // k, v = W_p[:, :Kc] . kk | vv (pyramid terms added below);  T_i = W_p[:, block i] . pooled_i on the bins of size i:
         // the block-expanded operand is zero outside its own bins, so each size is its own K = Kc product on a column
         // window of T (one K = ns*Kc product per branch had 32 workgroups walking 16 dependent chunks: 29 us)

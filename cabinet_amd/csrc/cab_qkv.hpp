@@ -44,6 +44,10 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
                        const float* x, int training, const QkvSaved& sv, const QkvGrads& gr, void* ws,
                        hipStream_t stream);
 
+// output stage of the forward as one kernel (cab_qkv_fused.hip): pyramid terms per workgroup, W_0 product, bilinear gathers
+bool qkv_fused_fwd_supported(const QkvShape& s);
+hipError_t qkv_fused_out(const QkvShape& s, const QkvParams& w, const QkvSaved& sv, float* k, float* v, hipStream_t stream);
+
 size_t conv1x1_fwd_workspace(int Ci, int Co);
 size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P);
 hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int Co, int P, float* y, void* ws,
