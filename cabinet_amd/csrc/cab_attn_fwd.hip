@@ -5,23 +5,24 @@
 //   q, k : (B, KC, n)   v : (B, VC, n)   ->   ctx : (B, VC, n),  lse : (B, n)
 //
 // Design (MI355X, exact fp32 via v_mfma_f32_32x32x2_f32):
-//  * "query on the lane" throughout.  One workgroup = 32 queries x 4 waves; the 4
-//    waves split the KEYS (wave w takes key tiles t == w mod 4), so there is no
-//    barrier in the main loop and a 8x32x32 image still fills 256 CUs with one
-//    wave per SIMD (512-VGPR budget: Q, O and the streamed K tile live in VGPRs).
+//  * "query on the lane" throughout.  One workgroup = 32 queries; its waves split the KEYS (wave w takes key tiles
+//    t == w mod #waves), so there is no barrier in the main loop and a 8x32x32 image still fills 256 CUs.
 //  * S^T tile (32 keys x 32 queries) = K^T Q:  A = K[c][j] (key on lane),
 //    B = Q[c][i] (query on lane): both are contiguous 128-B reads of NCHW rows.
 //    The accumulator then has the query on the lane and 16 keys in registers,
 //    which is exactly the B operand of O^T += V P^T, so P never leaves registers
 //    and the softmax row statistics are per-lane scalars (one cross-half swap).
-//  * V needs the channel on the lane (contraction over keys), i.e. a transpose of
-//    the NCHW row: each wave stages its V tile through a private, padded LDS
-//    image (stride 33 floats: conflict-free both ways); no workgroup barrier.
 //  * Rescaling of O is deferred (only when the running max grows by > 2^12), so
 //    the common tile is MFMA + 16 exp2 per lane.
-//  * The four per-wave partial results are merged through LDS at the end; with
+//  * The per-wave partial results are merged through LDS at the end; with
 //    kvsplit > 1 (small batches) partials go to a workspace and a tiny second
 //    kernel merges them, so the grid always covers the chip.
+// Two kernels share this design:
+//    cab_attn_fwd_w8_kernel  (default: n % 4 == 0, Kc <= 128)  8 waves = two per SIMD, operands in 16-register batches, the V
+//                            operand (channel on the lane) as 16-byte loads straight from global memory, no LDS in the loop;
+//    cab_attn_fwd_kernel     (ragged n, Kc = 256)  4 waves = one per SIMD with the 512-VGPR budget (Q, O and the streamed
+//                            K tile in registers), V transposed through a wave-private padded LDS image, tile t + 1's
+//                            softmax interleaved into tile t's PV slots.
 #include <type_traits>
 
 #include "common.hpp"
@@ -312,6 +313,177 @@ __global__ __launch_bounds__(256) void cab_attn_fwd_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two waves per SIMD (n % 4 == 0).  The kernel above keeps Q, O, a whole K tile and a whole V tile of one wave in registers
+// (one wave per SIMD) and hides the softmax by interleaving tile t + 1's statistics into tile t's PV slots; the matrix
+// pipes are busy 58 % of its time.  This form gives the second wave of every SIMD that job:
+//   * 8 waves split the keys of the workgroup's 32 queries; Q (64 registers) and O (64) stay resident;
+//   * K and V travel in BATCHES of 16 registers, one per 16 MFMAs, double-buffered (batch b + 1 is requested in the MFMA
+//     slots of batch b; the last batch of a tile requests the first one of the wave's next tile);
+//   * the V operand of O^T += V P^T needs the channel on the lane.  At PV step r the B operand p[r] of lane (query, h) is key
+//     acc_row(r) + 4h of the tile, so lane (channel, h) needs v[channel][j0 + 8 (r / 4) + 4h + r % 4]: four consecutive keys
+//     per r / 4, i.e. ONE 16-byte load serves four steps -- no LDS transpose image, no LDS at all in the loop;
+//   * per tile: S chain, softmax (plain, in the gap the other wave fills), O rescale if the maximum moved, PV.
+// LDS is used once, for the merge of the eight partial (m, l, O) results.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// an MFMA has no side effect: without this the instruction selector may sink a chain below the loads that share its slots
+// ("+v": a 512-thread kernel keeps its accumulators in the VGPR half)
+__device__ __forceinline__ void pin(f32x16& acc) { asm volatile("" : "+v"(acc)); }
+__device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+
+template <int KC, int VC>
+__global__ __launch_bounds__(512) void cab_attn_fwd_w8_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit, int B) {
+    constexpr int KB = KC / 32, VB = VC / 32, NW = 8, NBATCH = KB + VB;
+    static_assert(NBATCH % 2 == 0, "the buffer parity of batch 0 must repeat from tile to tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    float* s_m = smem + NW * VC * 32;  // [8][32] running max per wave / query
+    float* s_l = s_m + NW * 32;        // [8][32] running sum
+    float* s_f = s_l + NW * 32;        // [8][32] merge factors
+
+    const int nqt = (n + 31) >> 5, per_img = nqt * kvsplit;
+    const int tile = xcd_chunked_tile(blockIdx.x, per_img * B);
+    const int b = tile / per_img, rem = tile - b * per_img, split = rem / nqt, i0 = (rem - split * nqt) * 32;
+    const int row_bytes = n * 4;
+    const buf_rsrc q_rs = make_rsrc(q + (size_t)b * KC * n, (unsigned)KC * row_bytes);
+    const buf_rsrc k_rs = make_rsrc(k + (size_t)b * KC * n, (unsigned)KC * row_bytes);
+    const buf_rsrc v_rs = make_rsrc(v + (size_t)b * VC * n, (unsigned)VC * row_bytes);
+    const int NT = (n + 31) >> 5, tstep = NW * kvsplit, t0 = split * NW + wave;
+    const int lin4 = li * n * 4;
+
+    f32x4 buf[2][4];
+    int voff_k, voff_kn, cq[4];
+    auto chain_off = [&](int t) { return (h * n + min(min(t, NT - 1) * 32 + li, n - 1)) * 4; };
+    auto prefetch = [&](auto kn_tag, auto u_tag) {
+        constexpr int KN = decltype(kn_tag)::value, U = decltype(u_tag)::value, P = KN & 1;
+        if constexpr (KN < KB) {
+            buf[P][U >> 2][U & 3] = bload(k_rs, voff_k, (32 * KN + 2 * U) * row_bytes);
+        } else if constexpr (KN < NBATCH) {
+            if constexpr (U < 4) buf[P][U] = bload4(v_rs, lin4 + cq[U] * 4, (KN - KB) * 32 * row_bytes);
+        } else {
+            buf[P][U >> 2][U & 3] = bload(k_rs, voff_kn, 2 * U * row_bytes);
+        }
+    };
+    voff_k = chain_off(t0);
+    static_for<0, 16>([&](auto u) { prefetch(std::integral_constant<int, 0>{}, u); });
+    float qreg[KC / 2];  // raw q[2s + h][i0 + li]; scale * log2(e) is applied inside the softmax
+    {
+        const int voff = (h * n + min(i0 + li, n - 1)) * 4;
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) qreg[s] = bload(q_rs, voff, s * 2 * row_bytes);
+    }
+    f32x16 o[VB];
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int t = t0; t < NT; t += tstep) {
+        const int j0 = t * 32;
+        voff_k = chain_off(t), voff_kn = chain_off(t + tstep);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cq[a] = min(j0 + 8 * a + 4 * h, n - 4);
+        f32x16 sn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+        static_for<0, KC / 2>([&](auto c2_tag) {  // S^T = K^T Q: keys in accumulator rows, query on the lane
+            constexpr int c2 = decltype(c2_tag)::value, K = c2 / 16, U = c2 % 16;
+            sn = mfma32(buf[K & 1][U >> 2][U & 3], qreg[c2], sn);
+            pin(sn);
+            prefetch(std::integral_constant<int, K + 1>{}, std::integral_constant<int, U>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // online softmax, statistics per lane (= per query); rescaling deferred until the maximum grows by > 2^12
+        if (j0 + 32 > n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[r] = (j0 + acc_row(r) + 4 * h >= n) ? -INFINITY : sn[r];
+        }
+        float mt = sn[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sn[r]);
+        mt = fmaxf(mt, swap_half(mt)) * qscale;
+        const float mn = (mt > m + kRescaleThreshold) ? mt : m;
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sn[r] = fast_exp2(fmaf(sn[r], qscale, -mn));
+            rs += sn[r];
+        }
+        l = l * alpha + rs;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+        }
+        static_for<0, VB>([&](auto cb_tag) {  // O^T += V P^T: A = the transposed batch (channel on lane), B = P^T registers
+            constexpr int cb = decltype(cb_tag)::value, K = KB + cb;
+            static_for<0, 16>([&](auto r_tag) {
+                constexpr int r = decltype(r_tag)::value;
+                o[cb] = mfma32(buf[K & 1][r >> 2][r & 3], sn[r], o[cb]);
+                pin(o[cb]);
+                prefetch(std::integral_constant<int, K + 1>{}, r_tag);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    }
+
+    // ---- merge the 8 waves (disjoint key subsets) ----
+    l += swap_half(l);
+    if (h == 0) {
+        s_m[wave * 32 + li] = m;
+        s_l[wave * 32 + li] = l;
+    }
+    float* vs = smem + wave * (VC * 32);
+#pragma unroll
+    for (int cb = 0; cb < VB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vs[(cb * 32 + acc_row(r) + 4 * h) * 32 + li] = o[cb][r];
+    __syncthreads();
+    float ms = -INFINITY, lt = 0.f;
+    if (threadIdx.x < NW * 32) {
+        const int i = threadIdx.x & 31, w = threadIdx.x >> 5;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) ms = fmaxf(ms, s_m[ww * 32 + i]);
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const float mw = s_m[ww * 32 + i];
+            lt += (mw == -INFINITY) ? 0.f : s_l[ww * 32 + i] * fast_exp2(mw - ms);  // a wave without a key tile: m = -inf, l = 0
+        }
+        const float mw = s_m[w * 32 + i];
+        s_f[w * 32 + i] = (lt > 0.f && mw != -INFINITY) ? fast_exp2(mw - ms) / lt : 0.f;
+    }
+    __syncthreads();
+    const size_t out_base = ((size_t)split * B + b) * VC * n;
+    for (int idx = threadIdx.x; idx < VC * 8; idx += 512) {  // four consecutive queries per thread (n % 4 == 0)
+        const int c = idx >> 3, i = (idx & 7) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(smem + w * (VC * 32) + c * 32 + i);
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(s_f + w * 32 + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += ov[e] * fv[e];
+        }
+        if (i0 + i < n) *reinterpret_cast<f32x4*>(ctx + out_base + (size_t)c * n + i0 + i) = acc;
+    }
+    if (threadIdx.x < 32 && i0 + threadIdx.x < n)
+        lse[((size_t)split * B + b) * n + i0 + threadIdx.x] = (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
+}
+
 // merge kvsplit partial results: lse = logsumexp_s(lse_s), ctx = sum_s exp(lse_s - lse) ctx_s
 __global__ void cab_attn_fwd_merge_kernel(const float* __restrict__ part_ctx,
                                           const float* __restrict__ part_lse,
@@ -351,13 +523,21 @@ static hipError_t launch_fwd(const float* q, const float* k, const float* v, flo
     static lds_attr_mask attr_mask{0};
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_mask); e != hipSuccess) return e;
     dim3 grid(((n + 31) / 32) * kvsplit * B);
-    if (kvsplit == 1) {
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, q, k, v, ctx, lse, n, scale * LOG2E_F, 1, B);
-    } else {
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, q, k, v, part_ctx, part_lse, n,
-                           scale * LOG2E_F, kvsplit, B);
-        launch_attn_merge(part_ctx, part_lse, ctx, lse, B, VC, n, kvsplit, stream);
+    float* out_ctx = kvsplit == 1 ? ctx : part_ctx;
+    float* out_lse = kvsplit == 1 ? lse : part_lse;
+    if constexpr (KC <= 128) {  // (KC = 256: the resident Q alone is 128 registers of the 256 a wave has at two per SIMD)
+      if ((n & 3) == 0) {  // two waves per SIMD: needs 16-byte aligned key quads
+        auto kern8 = cab_attn_fwd_w8_kernel<KC, VC>;
+        const size_t lds8 = (size_t)(8 * VC * 32 + 3 * 8 * 32) * sizeof(float);
+        static lds_attr_mask mask8{0};
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern8), lds8, mask8); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern8, grid, dim3(512), lds8, stream, q, k, v, out_ctx, out_lse, n, scale * LOG2E_F, kvsplit, B);
+        if (kvsplit > 1) launch_attn_merge(part_ctx, part_lse, ctx, lse, B, VC, n, kvsplit, stream);
+        return hipGetLastError();
+      }
     }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, q, k, v, out_ctx, out_lse, n, scale * LOG2E_F, kvsplit, B);
+    if (kvsplit > 1) launch_attn_merge(part_ctx, part_lse, ctx, lse, B, VC, n, kvsplit, stream);
     return hipGetLastError();
 }
 
