@@ -133,7 +133,11 @@ def test_attn_bwd_golden(path):
 
 @pytest.mark.parametrize("B,Kc,Vc,n", [(1, 128, 128, 1), (1, 128, 128, 31), (2, 128, 128, 33), (3, 64, 64, 130),
                                        (4, 128, 128, 256), (1, 256, 128, 2048), (8, 128, 128, 1024),
-                                       (2, 128, 128, 2048), (1, 256, 128, 66), (2, 256, 128, 1000)])
+                                       (2, 128, 128, 2048), (1, 256, 128, 66), (2, 256, 128, 1000),
+                                       # n % 4 == 0 (the two-waves-per-SIMD kernels): one partial tile, two tiles for eight
+                                       # waves (six waves merge an empty result), a ragged last tile, a key-split batch
+                                       (1, 128, 128, 4), (1, 128, 128, 36), (2, 128, 128, 1000), (5, 64, 64, 520),
+                                       (1, 128, 128, 3076)])
 def test_attn_autograd_vs_oracle(B, Kc, Vc, n):
     """cab_attention (autograd Function over the C ABI) vs the explicit-formula oracle, fp64 truth."""
     from cabinet_amd.functional import cab_attention

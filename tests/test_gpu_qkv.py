@@ -53,6 +53,9 @@ def _oracle_qkv(m, x, grads, training, sizes):
     (1, 64, 32, 48, 5, 7, (1, 3, 6, 8)),        # more bins than pixels, ragged, Kc != Vc
     (2, 32, 16, 16, 8, 20, (2, 5)),             # overlapping bins, non-square, two sizes
     (1, 512, 256, 128, 32, 64, (1, 3, 6, 8)),   # the reference's own test block (test_models.py:49): n = 2048
+    (2, 256, 128, 128, 64, 32, (1, 3, 6, 8)),   # config 5's map (H != W): one-kernel output stage, Kc = 128
+    (3, 96, 64, 64, 16, 32, (2, 5)),            # one-kernel output stage at Kc = 64, two sizes, odd batch
+    (1, 320, 256, 256, 16, 16, (1, 3, 6, 8)),   # ... and at Kc = 256 (pyramid operand fetched in chunks)
 ])
 def test_qkv_vs_oracle(B, C, Kc, Vc, H, W, sizes, training):
     from cabinet_amd.functional import cab_qkv
