@@ -17,7 +17,7 @@
 //   fwd : G(x -> zq|zk|vv) as one 3-job launch, BN statistics + finalize (one launch), plane pass (BN+ReLU, q, kk, pooled bins),
 //         output stage (cab_qkv_fused.hip: T = W_i . pooled_i per workgroup, W_0 product, bilinear gathers)   = 4 launches
 //         (shapes outside that kernel's range: G(pooled -> T_k, T_v) + G(kk -> k, vv -> v) as one launch, pyramid add = 5)
-//   bwd : the adjoint chain in 6 launches, all deterministic (no atomics)
+//   bwd : the adjoint chain in 6 launches (dx of the projections: qkv_dx_kernel, cab_qkv_fused.hip), all deterministic (no atomics)
 // GEMMs are the job-batched exact-fp32 MFMA kernels of small_gemm.hip (64x64 tiles: the batch has only 8192 positions).
 #include "cab_qkv.hpp"
 
@@ -797,7 +797,9 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
                            w.bnk_w, at(L.bnpart), s.B, s.Kc, P, training, at(L.dzqk), gr.dbnq_w, gr.dbnq_b, gr.dbnk_w,
                            gr.dbnk_b);
     }
-    {   // dx = W_q^T dzq + W_k^T dzk + W_v^T dvv : the row-major weights ARE the K-major A operands
+    if (qkv_dx_supported(s)) {  // both operands K-major as stored: an LDS-free kernel (cab_qkv_fused.hip)
+        if (hipError_t e = qkv_dx_run(s, w, at(L.dzqk), at(L.dvv), gr.dx, stream); e != hipSuccess) return e;
+    } else {  // dx = W_q^T dzq + W_k^T dzk + W_v^T dvv : the row-major weights ARE the K-major A operands
         SgJobs jobs{};
         jobs.n = 1;
         SgJob& j = jobs.j[0];

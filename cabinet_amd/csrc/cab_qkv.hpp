@@ -47,6 +47,9 @@ hipError_t qkv_bwd_run(const QkvShape& s, const QkvParams& w, const float* dq, c
 // output stage of the forward as one kernel (cab_qkv_fused.hip): pyramid terms per workgroup, W_0 product, bilinear gathers
 bool qkv_fused_fwd_supported(const QkvShape& s);
 hipError_t qkv_fused_out(const QkvShape& s, const QkvParams& w, const QkvSaved& sv, float* k, float* v, hipStream_t stream);
+// dx of the three projections as one LDS-free kernel (cab_qkv_fused.hip)
+bool qkv_dx_supported(const QkvShape& s);
+hipError_t qkv_dx_run(const QkvShape& s, const QkvParams& w, const float* dzqk, const float* dvv, float* dx, hipStream_t stream);
 
 size_t conv1x1_fwd_workspace(int Ci, int Co);
 size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P);
