@@ -1116,7 +1116,9 @@ static hipError_t launch_bwd_fast(const float* g, const float* q, const float* k
     const size_t lds_w8 = w8_loop > w8_tree ? w8_loop : w8_tree;
     static lds_attr_mask mask_w8{0};
     if (dsp) {
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_w8), lds_w8, mask_w8); e != hipSuccess) return e;
+        // the size depends on n: the attribute is set once per device, to the most the kernel can ever ask for
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_w8), 160 * 1024, mask_w8); e != hipSuccess) return e;
+        if (lds_w8 > 160 * 1024) return hipErrorInvalidValue;
     }
     auto launch_kv = [&](float* dk_dst, float* dv_dst, int ns) {
         if (dsp)

@@ -270,7 +270,8 @@ static hipError_t launch_psp(const PspArgs& a, const QkvShape& s, hipStream_t st
     auto fn = qkv_psp_out_kernel<KCH>;
     const size_t lds = psp_lds(s, KCH, a.NBp);
     static lds_attr_mask mask{0};
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), lds, mask); e != hipSuccess) return e;
+    // the size depends on the pyramid: the attribute is set once per device, to the most the kernel can ever ask for
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(fn), 160 * 1024, mask); e != hipSuccess) return e;
     const int blocks = ((a.kch[0] + a.kch[1]) / 32) * (a.P / 256) * a.B;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, stream, a);
     return hipSuccess;

@@ -240,3 +240,29 @@ def test_attn_bwd_dq_is_conditioned_for_common_mode_keys(B, Kc, Vc, n):
     assert naive > 4 * err  # the test inputs do exercise the cancellation
     assert_close(dk, dk64, 1e-5, "dk")
     assert_close(dv, dv64, 1e-5, "dv")
+
+
+def test_attn_bwd_lds_attribute_covers_a_later_larger_n():
+    """The stored-dS dk/dv kernel's dynamic LDS grows with n (8 n bytes of row constants beside the k | v tiles) while
+    hipFuncAttributeMaxDynamicSharedMemorySize is set once per device: a small n first must not pin the attribute to its
+    size.  (Kc, Vc) = (256, 128): 48 KB of tiles, so n = 4096 needs 80 KB -- above both the 64 KB default and what n = 128
+    asked for."""
+    from cabinet_amd.functional import cab_attention
+    from oracle.cab_math import attn_core_bwd, attn_core_fwd
+
+    for n in (128, 4096):
+        gen = torch.Generator().manual_seed(n)
+        q = torch.randn(1, 256, n, generator=gen).relu()
+        k = torch.randn(1, 256, n, generator=gen)
+        v = torch.randn(1, 128, n, generator=gen)
+        g = torch.randn(1, 128, n, generator=gen)
+        qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+        ctx = cab_attention(qd, kd, vd, 256 ** -0.5)
+        ctx.backward(g.cuda())
+        torch.cuda.synchronize()
+        ctx_ref, lse_ref = attn_core_fwd(q, k, v, 256 ** -0.5)
+        dq_ref, dk_ref, dv_ref = attn_core_bwd(g, q, k, v, ctx_ref, lse_ref, 256 ** -0.5)
+        assert_close(ctx, ctx_ref, TOL, f"ctx n={n}")
+        assert_close(qd.grad, dq_ref, TOL, f"dq n={n}")
+        assert_close(kd.grad, dk_ref, TOL, f"dk n={n}")
+        assert_close(vd.grad, dv_ref, TOL, f"dv n={n}")

@@ -46,6 +46,15 @@ def _oracle_qkv(m, x, grads, training, sizes):
     return (q.detach(), k.detach(), v.detach()), xo.grad, w.grads(), w.buffers()
 
 
+def test_qkv_output_stage_lds_attribute_covers_a_later_larger_pyramid():
+    """The one-kernel output stage keeps (ns + 1) weight blocks and the pyramid terms in dynamic LDS; the per-device
+    MaxDynamicSharedMemorySize attribute is set once, so a small pyramid first must not pin it (Kc = 128: 34 KB for
+    sizes (1,), 101 KB for (1, 3, 6, 8), which crosses the 64 KB default).  First test of the file, so that run on its own
+    the small pyramid is the first call of the process."""
+    _run_qkv_case(1, 64, 128, 128, 16, 16, (1,), True)
+    _run_qkv_case(1, 64, 128, 128, 16, 16, (1, 3, 6, 8), True)
+
+
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("B,C,Kc,Vc,H,W,sizes", [
     (2, 256, 128, 128, 16, 16, (1, 3, 6, 8)),   # golden-fixture shape
@@ -58,6 +67,10 @@ def _oracle_qkv(m, x, grads, training, sizes):
     (1, 320, 256, 256, 16, 16, (1, 3, 6, 8)),   # ... and at Kc = 256 (pyramid operand fetched in chunks)
 ])
 def test_qkv_vs_oracle(B, C, Kc, Vc, H, W, sizes, training):
+    _run_qkv_case(B, C, Kc, Vc, H, W, sizes, training)
+
+
+def _run_qkv_case(B, C, Kc, Vc, H, W, sizes, training):
     from cabinet_amd.functional import cab_qkv
 
     m = _make(C, Kc, Vc, sizes, 5).cuda()
