@@ -18,8 +18,6 @@
 
 namespace cabinet {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 
 
 // One workgroup per output row (b, oy).  The two source rows are lerped vertically into LDS once (coalesced
@@ -122,29 +120,11 @@ struct OhemFwdHeads {
     int* blk_cnt[NH];       // (nblk,2)
 };
 
-// One upsampled pixel with its own running maximum (the form every pixel took before the bound of ohem_up_fwd_x8_kernel):
-// logits x_c = v[c][g] + t (v[c][gn] - v[c][g]), t in (0, 1/2), gn the neighbouring source column.  Called only when the
-// interval's bound sits ~100 binades above every logit of the pixel.
-__device__ __attribute__((noinline)) float ohem_pixel_exact(const float* vh, int C, int Wl, int g, int gn, float t, int lrow) {
-    float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) {
-        const float* vc = vh + c * Wl;
-        mx = fmaxf(mx, fmaf(t, vc[gn] - vc[g], vc[g]));
-    }
-    float s2 = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float* vc = vh + c * Wl;
-        s2 += fast_exp2(fmaf(t, vc[gn] - vc[g], vc[g]) - mx);
-    }
-    const float* vl = vh + lrow;
-    return ((mx - fmaf(t, vl[gn] - vl[g], vl[g])) + fast_log2(s2)) * LN2_F;
-}
-
 template <int CMAX, bool EXACT, int NH>
 __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd, const long long* __restrict__ labels, int C,
                                                               int Hl, int Wl, int H, int W, float rh, float thresh,
                                                               int ignore_lb) {
-    extern __shared__ __attribute__((aligned(16))) float v[];  // [NH][C][Wl], then [NH][Wl] class maxima
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [NH][C][Wl]
     __shared__ float s_f[NH][4];
     __shared__ int s_i[NH][3][4];
     const int b = blockIdx.y, oy = blockIdx.x, P = H * W, nt = blockDim.x, CW = C * Wl;
@@ -191,18 +171,6 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
         }
     }
     __syncthreads();
-    // per source column, the maximum over the classes: every upsampled logit is a convex combination of two staged values of
-    // its class, so max(Mx[g], Mx[neighbour]) bounds all C of them from above -- the per-pixel running maximum (one v_max per
-    // class and pixel) is replaced by two per source interval
-    float* Mx = v + NH * CW;  // [NH][Wl]
-    for (int i = threadIdx.x; i < NH * Wl; i += nt) {
-        const int hh = i >= Wl ? 1 : 0, g = i - hh * Wl;
-        const float* col = v + hh * CW + g;
-        float m = col[0];
-        for (int c = 1; c < C; ++c) m = fmaxf(m, col[c * Wl]);
-        Mx[i] = m;
-    }
-    __syncthreads();
     float my_sum[NH];
     int my_valid = 0, my_bad = 0, my_above[NH];
 #pragma unroll
@@ -218,75 +186,65 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
                 lb[2 * u] = t.x, lb[2 * u + 1] = t.y;
             }
         }
-        // v holds the vertically interpolated logits times log2(e).  This kernel is VALU-issue bound (1823, then 1368 VALU
-        // instructions per wave measured for two heads), so the per-pixel chain is kept short: the horizontal lerp is ONE fma
-        // on a difference formed once per source interval, with the interval's upper bound already subtracted from its
-        // constant term (no running maximum, no subtraction in front of the exponential); exp2 needs no scaling multiply;
-        // pixels are processed in PAIRS as two-component vectors, which the compiler issues as v_pk_fma_f32 / v_pk_add_f32
-        // (two fp32 lanes per instruction -- only the exponentials stay scalar); the label's logit is gathered from LDS (rows
-        // are Wl floats apart and lanes walk consecutive columns: conflict-free whatever the labels).
+        // v holds the vertically interpolated logits times log2(e).  This kernel is VALU-issue bound (1823 VALU instructions
+        // per wave measured for two heads: 81 % of the SIMD cycles), so the per-pixel chain is kept short: the horizontal
+        // lerp is one fma on a difference formed once per source interval, exp2 needs no scaling multiply, and the label's
+        // logit is gathered from LDS (rows are Wl floats apart and lanes walk consecutive columns: conflict-free whatever the
+        // labels) instead of a compare + select per class.
+        float xc[NH][CMAX], dm[NH][CMAX], dp[NH][CMAX];
         const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
-        bool valid[8];
-        int lrow[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            valid[j] = lb[j] != (long long)ignore_lb;
-            const bool inrange = lb[j] >= 0 && lb[j] < (long long)C;
-            // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): a separate flag,
-            // OR-reduced over the block, poisons the block's valid count so the caller's one host read sees it
-            my_valid += valid[j] ? 1 : 0;
-            my_bad |= (valid[j] && !inrange) ? 1 : 0;
-            lrow[j] = inrange ? (int)lb[j] * Wl : 0;
-        }
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const float* vh = v + hh * CW;
-            const float bm = fmaxf(Mx[hh * Wl + g], Mx[hh * Wl + gm]), bp = fmaxf(Mx[hh * Wl + g], Mx[hh * Wl + gp]);
-            float xm[CMAX], xp[CMAX], dm[CMAX], dp[CMAX];  // constant term minus the bound, and slope, of the left / right half
+        for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
                 if (EXACT || c < C) {
-                    const float* vc = vh + c * Wl;
-                    const float vg = vc[g];
-                    xm[c] = vg - bm, xp[c] = vg - bp, dm[c] = vg - vc[gm], dp[c] = vc[gp] - vg;
+                    const float* vc = v + hh * CW + c * Wl;
+                    xc[hh][c] = vc[g], dm[hh][c] = vc[g] - vc[gm], dp[hh][c] = vc[gp] - vc[g];
                 }
-            float out[8];
+        float out[NH][8];
 #pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                // pixel j of the interval: x = xc - (1 - t)(xc - xm) with t = (j + 4.5)/8 for j < 4 (left half),
-                //                          x = xc + t (xp - xc)      with t = (j - 3.5)/8 for j >= 4 (right half)
-                constexpr float T[8] = {-0.4375f, -0.3125f, -0.1875f, -0.0625f, 0.0625f, 0.1875f, 0.3125f, 0.4375f};
-                const int j0 = 2 * jp;
-                const bool left = jp < 2;
-                const f32x2 t2 = {T[j0], T[j0 + 1]};
-                f32x2 se = {0.f, 0.f};
+        for (int j = 0; j < 8; ++j) {
+            // pixel j of the interval: x = xm + t (xc - xm) = xc - (1 - t)(xc - xm), t = (j + 4.5)/8, for j < 4;
+            //                          x = xc + t (xp - xc),                          t = (j - 3.5)/8, for j >= 4
+            const float t = j < 4 ? -(1.f - ((float)j + 4.5f) * 0.125f) : ((float)j - 3.5f) * 0.125f;
+            const bool valid = lb[j] != (long long)ignore_lb;
+            const bool inrange = lb[j] >= 0 && lb[j] < (long long)C;
+            // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): a separate flag,
+            // OR-reduced over the block, poisons the block's valid count so the caller's one host read sees it
+            my_valid += valid ? 1 : 0;
+            my_bad |= (valid && !inrange) ? 1 : 0;
+            const int lrow = inrange ? (int)lb[j] * Wl : 0;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (EXACT || c < C) {
-                        const float d = left ? dm[c] : dp[c], x0 = left ? xm[c] : xp[c];
-                        const f32x2 x = __builtin_elementwise_fma(t2, f32x2{d, d}, f32x2{x0, x0});
-                        se += f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
-                    }
+            for (int hh = 0; hh < NH; ++hh) {
+                float loss = 0.f;
+                if (valid) {
+                    const float* vl = v + hh * CW + lrow;
+                    const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);
+                    float x[CMAX], mx = -INFINITY;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int j = j0 + u;
-                    const float* vl = vh + lrow[j];
-                    const float vg = vl[g], bnd = left ? bm : bp;
-                    const float xl = fmaf(T[j], left ? vg - vl[gm] : vl[gp] - vg, vg - bnd);  // label logit minus the bound
-                    float loss = (fast_log2(se[u]) - xl) * LN2_F;
-                    if (!(se[u] > 1e-30f))  // never taken for sane logits; out of line so the hot loop stays compact
-                        loss = ohem_pixel_exact(vh, C, Wl, g, left ? gm : gp, left ? -T[j] : T[j], lrow[j]);
-                    loss = valid[j] ? loss : 0.f;
+                    for (int c = 0; c < CMAX; ++c)
+                        if (EXACT || c < C) {
+                            x[c] = fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]);
+                            mx = fmaxf(mx, x[c]);
+                        }
+                    float se = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (EXACT || c < C) se += fast_exp2(x[c] - mx);
+                    loss = ((mx - xl) + fast_log2(se)) * LN2_F;
                     if (loss > thresh) {
                         my_above[hh] += 1;
                         my_sum[hh] += loss;
                     }
-                    out[j] = loss;
                 }
+                out[hh][j] = loss;
             }
+        }
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
             f32x4* op = reinterpret_cast<f32x4*>(hd.loss_px[hh] + pix);
-            op[0] = f32x4{out[0], out[1], out[2], out[3]};
-            op[1] = f32x4{out[4], out[5], out[6], out[7]};
+            op[0] = f32x4{out[hh][0], out[hh][1], out[hh][2], out[hh][3]};
+            op[1] = f32x4{out[hh][4], out[hh][5], out[hh][6], out[hh][7]};
         }
     }
     // ordered block reduction
@@ -497,19 +455,19 @@ hipError_t ohem_up_fwd_run(int nh, const float* const* low, const long long* lab
     for (int i = 0; i < nh; ++i) x8 = x8 && (reinterpret_cast<uintptr_t>(loss_px[i]) & 15) == 0;
     const int nt8 = Wl >= 256 ? 256 : ((Wl + 63) / 64) * 64;
     // both heads in one workgroup (shared label tile, two independent exp / log chains per thread) when their row buffers fit
-    const bool pair = nh == 2 && x8 && (size_t)2 * (C + 1) * Wl * sizeof(float) <= 60 * 1024;
+    const bool pair = nh == 2 && x8 && (size_t)2 * C * Wl * sizeof(float) <= 60 * 1024;
 #define OHEM_FWD(CM, EX)                                                                                                \
     do {                                                                                                                \
         if (pair) {                                                                                                     \
             OhemFwdHeads<2> hd{{low[0], low[1]}, {loss_px[0], loss_px[1]}, {blk_sum[0], blk_sum[1]}, {blk_cnt[0], blk_cnt[1]}}; \
-            hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX, 2>), dim3(H, B), dim3(nt8), (size_t)2 * (C + 1) * Wl * sizeof(float), \
+            hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX, 2>), dim3(H, B), dim3(nt8), (size_t)2 * C * Wl * sizeof(float), \
                                stream, hd, labels, C, Hl, Wl, H, W, (float)Hl / (float)H, thresh, ignore_lb);           \
         } else {                                                                                                        \
             for (int i = 0; i < nh; ++i) {                                                                              \
                 if (x8) {                                                                                               \
                     OhemFwdHeads<1> hd{{low[i]}, {loss_px[i]}, {blk_sum[i]}, {blk_cnt[i]}};                             \
                     hipLaunchKernelGGL((ohem_up_fwd_x8_kernel<CM, EX, 1>), dim3(H, B), dim3(nt8),                       \
-                                       (size_t)(C + 1) * Wl * sizeof(float), stream, hd, labels, C, Hl, Wl, H, W,        \
+                                       (size_t)C * Wl * sizeof(float), stream, hd, labels, C, Hl, Wl, H, W,              \
                                        (float)Hl / (float)H, thresh, ignore_lb);                                         \
                 } else {                                                                                                \
                     hipLaunchKernelGGL((ohem_up_fwd_kernel<CM, EX>), dim3(H, B), dim3(256), (size_t)C * Wl * sizeof(float), \
