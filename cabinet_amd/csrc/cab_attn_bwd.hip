@@ -866,12 +866,18 @@ __global__ __launch_bounds__(512) void cab_attn_bwd_dkdv_w8_kernel(
     }
 }
 
-// workgroups per tile so that a small batch still covers the chip (each wave keeps >= 2 tiles)
+// workgroups per key tile (each takes 1/split of the queries; ordered partial slabs): minimises the number of ROUNDS of
+// workgroups the chip needs, in units of a full-length workgroup (see attn_fwd_kvsplit), plus a charge for the slab traffic
 static int bwd_nsplit(int B, int n) {
-    const int nt = (n + 31) / 32;
-    int split = 1;
-    while (nt * B * split < 200 && split * 2 * 8 <= nt && split < 8) split *= 2;
-    return split;
+    const int nt = (n + 31) / 32, wgs = nt * B;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 8; s *= 2) {
+        if (s > 1 && s * 8 > nt) break;  // every wave keeps at least one query tile
+        const double cost = (double)((wgs * s + 255) / 256) / (double)s + (s > 1 ? 0.05 * s : 0.0);
+        if (cost < best_cost - 1e-9) best = s, best_cost = cost;
+    }
+    return best;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -541,11 +541,20 @@ static hipError_t launch_fwd(const float* q, const float* k, const float* v, flo
     return hipGetLastError();
 }
 
+// Workgroups per query tile (each takes 1/split of the keys; a merge pass combines the partial results).  One workgroup per CU
+// runs at a time, so a launch lasts ceil(workgroups / 256) rounds: 272 query tiles (the un-tiled 8704-position validation frame)
+// are TWO rounds of full-length workgroups with 240 CUs idle in the second; split 4 makes them five rounds of quarter length
+// (554 -> ~400 us).  The choice minimises rounds / split plus a small charge per partial result the merge has to read.
 int attn_fwd_kvsplit(int B, int n) {
-    const int nt = (n + 31) / 32;
-    int wgs = nt * B, split = 1;
-    while (wgs * split < 256 && split * 2 * 4 <= nt && split < 8) split *= 2;
-    return split;
+    const int nt = (n + 31) / 32, wgs = nt * B;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 8; s *= 2) {
+        if (s > 1 && s * 8 > nt) break;  // every wave of the 8-wave kernel keeps at least one key tile
+        const double cost = (double)((wgs * s + 255) / 256) / (double)s + (s > 1 ? 0.04 * s : 0.0);
+        if (cost < best_cost - 1e-9) best = s, best_cost = cost;
+    }
+    return best;
 }
 
 bool attn_shape_supported(int Kc, int Vc) {
