@@ -126,6 +126,15 @@ ATTN_PRECISION = _os.environ.get("CABINET_ATTN_PRECISION", "fp32")
 FFM_PRECISION = _os.environ.get("CABINET_FFM_PRECISION", "fp32")
 
 
+def _ffm_precision():
+    """``FFM_PRECISION`` -> CABINET_PREC_*; an unknown name raises (a typo such as ``bf16_6`` must not silently measure
+    fp32), exactly as ``_resolve_precision`` does for the attention switch."""
+    if FFM_PRECISION not in _PRECISIONS:
+        raise RuntimeError(f"ffm_fused_upsampled: unknown CABINET_FFM_PRECISION {FFM_PRECISION!r} "
+                           f"(one of {sorted(_PRECISIONS)})")
+    return _PRECISIONS[FFM_PRECISION]
+
+
 def _resolve_precision(precision, Kc, Vc):
     name = ATTN_PRECISION if precision is None else precision
     if name not in _PRECISIONS:
@@ -288,7 +297,7 @@ class _FfmUpFused(torch.autograd.Function):
         bn_w, bn_b = _f32c(bn_w), _f32c(bn_b)
         out, z, mean, invstd, pooled, gate = ffm_up_fwd_hip(fsp, low, w_blk2, bn_w, bn_b, run_mean, run_var,
                                                             w1_2, w2_2, training, momentum, eps,
-                                                            _PRECISIONS.get(FFM_PRECISION, PREC_FP32))
+                                                            _ffm_precision())
         fn_ctx.save_for_backward(fsp, low, w_blk2, bn_w, bn_b, w1_2, w2_2, z, mean, invstd, pooled, gate)
         fn_ctx.training = training
         fn_ctx.w_shapes = (w_blk.shape, w1.shape, w2.shape)

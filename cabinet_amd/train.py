@@ -56,10 +56,15 @@ class TrainStep:
     contract: call it once per micro-batch; every ``accum_steps``-th call reduces and steps the optimizer."""
 
     def __init__(self, net, criteria, reducer=None, optimizer=None, autocast=False, fused_loss=None, accum_steps=1,
-                 before_optimizer=None):
+                 before_optimizer=None, scaler=None):
         self.net, (self.crit_p, self.crit_16) = net, criteria
         self.reducer, self.optimizer, self.autocast = reducer, optimizer, autocast
         self.before_optimizer = before_optimizer  # e.g. gradient clipping (train.py:411-427), after the reduction
+        # scaler: a torch.amp.GradScaler -- the reference's real step (train.py:386,411-441): autocast forward,
+        # scaler.scale(loss).backward(), scaler.unscale_ before the clipping callback, scaler.step / update.  The hot-path
+        # operators compute in fp32 under autocast (custom_fwd(cast_inputs=float32) on every Function); only the stock
+        # convolutions around them run in the autocast dtype.
+        self.scaler = scaler
         # fused_loss: run the two final x8 upsamples inside the OHEM-CE kernels (device tensors only);
         # default = on whenever the model lives on a GPU
         self.fused_loss = fused_loss
@@ -79,9 +84,16 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.finish()
         if self.optimizer is not None:
-            if self.before_optimizer is not None:
-                self.before_optimizer()
-            self.optimizer.step()
+            if self.scaler is not None:
+                if self.before_optimizer is not None:  # clipping acts on the TRUE gradients (train.py:414-416)
+                    self.scaler.unscale_(self.optimizer)
+                    self.before_optimizer()
+                self.scaler.step(self.optimizer)  # skips the step when a gradient is inf / nan (early AMP calibration)
+                self.scaler.update()
+            else:
+                if self.before_optimizer is not None:
+                    self.before_optimizer()
+                self.optimizer.step()
         self._micro = 0
 
     def flush(self):
@@ -106,7 +118,7 @@ class TrainStep:
                     loss = self.crit_p(out, lb) + self.crit_16(out16, lb)
                 if self.accum_steps > 1:
                     loss = loss / self.accum_steps
-            loss.backward()
+            (loss if self.scaler is None else self.scaler.scale(loss)).backward()
         self._micro += 1
         if last:
             self._optimizer_step()
@@ -169,6 +181,8 @@ class _OptimizerSegment:
         if self.capture and optimizer is not None and not isinstance(optimizer, torch.optim.Optimizer):
             raise RuntimeError("capture_optimizer=True needs a plain torch.optim.Optimizer: a wrapper's Python-side "
                                "schedule (warm-up, decay, step counter) would be frozen at its capture-time values")
+        if self.capture and optimizer is not None and before is not None:  # at construction, not `warmup` steps later
+            raise RuntimeError("capture_optimizer=True cannot run a `before_optimizer` callback between the graphs")
 
     def record(self, pool):
         if self.optimizer is None or not self.capture:
@@ -224,6 +238,9 @@ class GraphedTrainStep:
         replay of graph A to learn the batch's OHEM branch, whose BatchNorm side effects are undone."""
         self.s_im, self.s_lb = im.clone(), lb.clone()
         self.snap = _BufferSnapshot(self.net)
+        # the gradients of the eager step that just ran: the static tensors bound below have only been RECORDED into, never
+        # executed, so a caller reading .grad after this step (grad-norm logging, NaN checks) would see uninitialised memory
+        eager_grads = {p: p.grad for p in self.net.parameters() if p.grad is not None}
         for p in self.net.parameters():
             p.grad = None
         size = tuple(im.shape[2:])
@@ -250,6 +267,12 @@ class GraphedTrainStep:
             self.s_loss = loss.detach()
         self.opt_seg.record(self.g_fwd.pool())
         self.s_grads = [(p, p.grad) for p in self.net.parameters() if p.grad is not None]
+        with torch.no_grad():
+            for p, g in self.s_grads:
+                if p in eager_grads:
+                    g.copy_(eager_grads[p])
+                else:
+                    g.zero_()
         torch.cuda.synchronize()
 
     @staticmethod

@@ -215,6 +215,80 @@ def test_reference_style_autocast_step_runs():
     assert abs(gnorms[1] - gnorms[0]) < 0.1 * gnorms[0]
 
 
+def test_reference_amp_gradscaler_clip_step():
+    """The reference's REAL step (train.py:386,411-441): autocast forward, ``scaler.scale(loss).backward()``,
+    ``scaler.unscale_`` + ``clip_grad_norm_``, ``scaler.step`` / ``update`` -- through ``TrainStep(autocast=True, scaler=...)``.
+    Checked: (i) autocast really is on (a stock convolution of the spatial branch emits fp16) while EVERY tensor handed to
+    the C ABI by the hot-path operators is fp32; (ii) the gradients the clipping callback sees are unscaled (their norm
+    equals the fp32 step's, not 65536x it) and point the same way; (iii) loss within 1e-2 of the fp32 step; (iv) the
+    scaler did not skip the steps and the weights moved and stayed finite."""
+    from cabinet_amd import functional
+    from cabinet_amd.train import TrainStep, build_model, make_criteria, synthetic_batch
+
+    im, lb = synthetic_batch(2, 256, 256, 8, "cuda", seed=11)
+    seen = {}
+
+    def spy(name):
+        real = getattr(functional, name)
+
+        def wrapped(*args, **kw):
+            seen.setdefault(name, set()).update(a.dtype for a in args if isinstance(a, torch.Tensor) and a.is_floating_point())
+            return real(*args, **kw)
+        return real, wrapped
+
+    names = ["attn_fwd_hip", "attn_bwd_hip", "ffm_up_fwd_hip", "ffm_up_bwd_hip", "cab_local_fwd_hip", "cab_local_bwd_hip",
+             "ohem_up_pair_fwd_hip", "ohem_up_pair_bwd_hip"]
+    results = {}
+    for amp in (False, True):
+        net = build_model("small", n_classes=8, seed=0, gamma=0.5, device="cuda").train()
+        w0 = [p.detach().clone() for p in net.parameters()]
+        opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.9)
+        norms, conv_dtypes = [], []
+        hook = net.sb.conv2.conv.register_forward_hook(lambda m, i, o: conv_dtypes.append(o.dtype))
+
+        flat = []
+
+        def clip():  # what the reference's _optimizer_step does between unscale_ and scaler.step (train.py:414-416)
+            flat.append(torch.cat([p.grad.flatten().double() for p in net.parameters() if p.grad is not None]))
+            norms.append(float(torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)))
+
+        scaler = torch.amp.GradScaler(device="cuda") if amp else None
+        step = TrainStep(net, make_criteria(2, 256, 256, "cuda"), optimizer=opt, autocast=amp, scaler=scaler,
+                         before_optimizer=clip)
+        saved = {}
+        if amp:
+            for n in names:
+                saved[n], w = spy(n)
+                setattr(functional, n, w)
+        try:
+            losses = [float(step(im, lb)) for _ in range(3)]
+        finally:
+            for n, real in saved.items():
+                setattr(functional, n, real)
+            hook.remove()
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+        moved = sum(float((p.detach() - w).abs().sum()) for p, w in zip(net.parameters(), w0))
+        results[amp] = dict(losses=losses, norms=norms, flat=flat, conv=conv_dtypes, moved=moved,
+                            scale=scaler.get_scale() if amp else None)
+    fp32, amp = results[False], results[True]
+    assert set(fp32["conv"]) == {torch.float32} and set(amp["conv"]) == {torch.float16}   # (i) autocast is active ...
+    for n in names:                                                                        # ... and the hot path is fp32
+        assert seen.get(n) == {torch.float32}, (n, seen.get(n))
+    # (iv) GradScaler skips a step whose fp16 gradients overflowed (early calibration, train.py:421-427) and halves its scale;
+    # the weights are then unchanged, so the first step it did NOT skip still starts from the fp32 run's initial weights
+    import math
+
+    first = next(i for i, v in enumerate(amp["norms"]) if math.isfinite(v))
+    assert first <= 1 and amp["scale"] >= 65536.0 / 2 and amp["moved"] > 0, (amp["norms"], amp["scale"])
+    # (ii) what the clipping callback saw: true (unscaled) gradients, same length and direction as the fp32 step's
+    assert abs(amp["norms"][first] - fp32["norms"][0]) < 5e-2 * fp32["norms"][0], (amp["norms"], fp32["norms"])
+    ga, gf = amp["flat"][first], fp32["flat"][0]
+    cos = float(torch.dot(ga, gf) / (ga.norm() * gf.norm()))
+    assert cos > 0.98, cos
+    # (iii) loss on identical weights: fp16 backbone noise only
+    assert abs(amp["losses"][first] - fp32["losses"][0]) < 1e-2 * abs(fp32["losses"][0]), (amp["losses"], fp32["losses"])
+
+
 def test_non_contiguous_and_channels_last_inputs_are_accepted():
     """Borrowed inputs are made dense NCHW by the binding (the C ABI itself only takes dense pointers)."""
     from cabinet_amd.functional import cab_attention
