@@ -78,7 +78,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 3: 8)")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1024, help="square image side (BASELINE config 3: 1024)")
+    ap.add_argument("--height", type=int, default=None, help="image height when not square (BASELINE config 5: "
+                    "--height 2048 --width 1024 --batch 2 --classes 19)")
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--mode", default="large", choices=["large", "small"])
     ap.add_argument("--classes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,9 +89,14 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--kernel-iters", type=int, default=30)
     ap.add_argument("--kernels-only", action="store_true", help="only time the hand-written kernels (dev aid)")
+    ap.add_argument("--all-kernels", action="store_true", help="also time the kernel groups the model's step does not run "
+                    "(plain FFM without the fused upsample, single-head OHEM)")
     ap.add_argument("--no-graph", action="store_true", help="single GPU: enqueue every step eagerly instead of replaying "
                     "the step's two captured hipGraphs")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.height = args.height or args.size
+    args.width = args.width or args.size
+    return args
 
 
 def time_kernel(fn, iters, warm=3, reps=5):
@@ -131,28 +139,35 @@ def time_kernel(fn, iters, warm=3, reps=5):
     return start.elapsed_time(stop) / iters
 
 
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_PROFILES = ("r04_pmc_traffic.json", "r04_config5_pmc_traffic.json")  # under profiles/: one per workload shape
 
 
-def load_traffic(batch, size):
-    """HBM bytes per launch of every kernel group, from the committed PMC profile (tools/pmc_traffic.sh: rocprofv3 --pmc
+def load_traffic(batch, height, width, classes):
+    """HBM bytes per launch of every kernel group, from the committed PMC profiles (tools/pmc_traffic.sh: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate passes, counters only; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950
-    FETCH calibration of MI355X_MICROARCH.md).  The profile records the digest of the kernel sources it was collected
-    on: it is used ONLY when that digest equals the one of the library this process loaded and the shape matches --
-    otherwise every `traffic` is null (stale evidence is not evidence)."""
+    FETCH calibration of MI355X_MICROARCH.md).  A profile records the workload shape and the digest of the kernel sources it
+    was collected on: it is used ONLY when both equal this run's -- otherwise every `traffic` is null (stale evidence is
+    not evidence)."""
     from cabinet_amd import build as _build
 
-    if not os.path.exists(TRAFFIC_PROFILE):
-        return {}, "none: profiles/r03_pmc_traffic.json absent"
-    prof = json.load(open(TRAFFIC_PROFILE))
-    if prof.get("source_digest") != _build.source_digest():
-        return {}, "none: profiles/r03_pmc_traffic.json was collected on other kernel sources (digest mismatch)"
-    if (prof.get("batch"), prof.get("size")) != (batch, size):
-        return {}, "none: profiles/r03_pmc_traffic.json was collected at another shape"
-    return prof.get("traffic", {}), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc, FETCH x2 calibrated, digest-checked)"
+    why = "none: no PMC traffic profile under profiles/"
+    for name in TRAFFIC_PROFILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        prof = json.load(open(path))
+        shape = (prof.get("batch"), prof.get("height", prof.get("size")), prof.get("width", prof.get("size")),
+                 prof.get("classes", 8))
+        if shape != (batch, height, width, classes):
+            continue
+        if prof.get("source_digest") != _build.source_digest():
+            why = f"none: profiles/{name} was collected on other kernel sources (digest mismatch)"
+            continue
+        return prof.get("traffic", {}), f"profiles/{name} (rocprofv3 --pmc, FETCH x2 calibrated, digest-checked)"
+    return {}, why
 
 
-def kernel_cases(batch, size):
+def kernel_cases(batch, height, width=None, classes=8, extra=False):
     """(Backward groups call the autograd Function's ``backward`` on the node their forward built: the same C-ABI calls as
     under autograd, issued from this thread on the current stream -- the autograd engine would run them on the forward's
     stream, outside a hipGraph capture.)
@@ -161,13 +176,17 @@ def kernel_cases(batch, size):
     (name, launch closure, algorithmic FLOPs, algorithmic bytes, bound) one group at a time (operands of a finished group
     are freed before the next is built).  Algorithmic work per launch: SURVEY.md section 8(d) / BASELINE.md section 3.
     Consumers: kernel_rooflines() below (HIP-event timing) and tools/run_kernels.py (the same launches under rocprofv3
-    for the PMC / kernel-trace passes)."""
+    for the PMC / kernel-trace passes).  ``height`` x ``width`` is the image (config 3: 1024 x 1024, config 5: 2048 x 1024),
+    ``classes`` the OHEM heads' class count; ``extra`` adds the groups the model's step does not run (plain FFM, single-head
+    OHEM).  Groups K7 .. K10 lie outside SURVEY.md section 8 (kernel_rooflines marks them)."""
     from cabinet_amd import functional as Fh
 
     dev = "cuda"
+    H, W = height, (width or height)
     B, Kc, Vc = batch, 128, 128
-    n = (size // 32) ** 2
-    h = w = size // 8
+    hl, wl = H // 32, W // 32
+    n = hl * wl
+    h, w = H // 8, W // 8
     P = h * w
     g = torch.Generator().manual_seed(3)
     q = torch.randn(B, Kc, n, generator=g).relu().to(dev)
@@ -187,25 +206,27 @@ def kernel_cases(batch, size):
 
     Cs, Cc, Co, Cm = 128, 256, 256, 64
     fsp = torch.randn(B, Cs, h, w, generator=g).to(dev)
-    fcp = torch.randn(B, Cc, h, w, generator=g).to(dev)
+    fcp = torch.randn(B, Cc, h, w, generator=g).to(dev) if extra else None
     wb = (torch.randn(Co, Cs + Cc, generator=g) * 0.07).to(dev)
     w1 = (torch.randn(Cm, Co, generator=g) * 0.1).to(dev)
     w2 = (torch.randn(Co, Cm, generator=g) * 0.1).to(dev)
     bw, bb = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
     rm, rv = torch.zeros(Co, device=dev), torch.ones(Co, device=dev)
     dout = torch.randn(B, Co, h, w, generator=g).to(dev)
-    fwd = lambda: Fh.ffm_fwd_hip(fsp, fcp, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
-    o, z, mean, invstd, pooled, gate = fwd()
-    # this build's pass structure: read fsp,fcp; write z; read z (stats); read z (pool); read z, write out
-    yield ("ffm_fwd (K3: 1x1 GEMM + BN stats, pool, gate)", fwd, 2.0 * B * P * (Cs + Cc) * Co,
-          4.0 * B * P * ((Cs + Cc) + 5 * Co), "mfma")
-    bwd = lambda: Fh.ffm_bwd_hip(dout, fsp, fcp, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
-    yield ("ffm_bwd (K4: reduce, dz, dX GEMM, dW split-K GEMM)", bwd, 4.0 * B * P * (Cs + Cc) * Co,
-          4.0 * B * P * (2 * Co + 2 * Co + Co + Co + (Cs + Cc) + Co + (Cs + Cc)), "mfma")
+    if extra:  # the plain FFM (reference signature forward(fsp, fcp)); CABiNet.forward runs the fused-upsample form below
+        fwd = lambda: Fh.ffm_fwd_hip(fsp, fcp, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
+        o, z, mean, invstd, pooled, gate = fwd()
+        # this build's pass structure: read fsp,fcp; write z; read z (stats); read z (pool); read z, write out
+        yield ("ffm_fwd (K3: 1x1 GEMM + BN stats, pool, gate)", fwd, 2.0 * B * P * (Cs + Cc) * Co,
+               4.0 * B * P * ((Cs + Cc) + 5 * Co), "mfma")
+        bwd = lambda: Fh.ffm_bwd_hip(dout, fsp, fcp, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
+        yield ("ffm_bwd (K4: reduce, dz, dX GEMM, dW split-K GEMM)", bwd, 4.0 * B * P * (Cs + Cc) * Co,
+               4.0 * B * P * (2 * Co + 2 * Co + Co + Co + (Cs + Cc) + Co + (Cs + Cc)), "mfma")
+        del o, z
+    del fcp
     # ---- the form CABiNet.forward uses: bilinear upsample of `low` fused into the FFM.
     # conv and resize commute, so the Cc part runs at low resolution: executed GEMM work drops 2.7x and the
     # op becomes HBM-bound; algorithmic bytes = this build's pass structure.
-    hl = wl = size // 32
     Pl = hl * wl
     low = torch.randn(B, Cc, hl, wl, generator=g).to(dev)
     upf = lambda: Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)  # noqa: E731
@@ -220,15 +241,15 @@ def kernel_cases(batch, size):
     fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
     by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))
     yield ("ffm_up_bwd (K4': reduce, dz, dfsp GEMM, U^T dz, low-res GEMMs, dW)", upb, fl_b, by_b, "hbm")
-    del fsp, fcp, dout, o, z, low
+    del fsp, dout, o, z, low
     torch.cuda.empty_cache()
 
     # ---- K7: BatchNorm + activation at the largest plane of the model (sb.conv1 / features.2: 64 x size/2 x size/2);
     # algorithmic bytes = the passes a training-mode BatchNorm cannot avoid: fwd read x twice + write y,
     # bwd read dy and x twice + write dx
-    Cb, hb = 64, size // 2
-    xb = torch.randn(B, Cb, hb, hb, generator=g).to(dev)
-    gb = torch.randn(B, Cb, hb, hb, generator=g).to(dev)
+    Cb, hb, wb2 = 64, H // 2, W // 2
+    xb = torch.randn(B, Cb, hb, wb2, generator=g).to(dev)
+    gb = torch.randn(B, Cb, hb, wb2, generator=g).to(dev)
     bnw, bnb = torch.ones(Cb, device=dev), torch.zeros(Cb, device=dev)
     brm, brv = torch.zeros(Cb, device=dev), torch.ones(Cb, device=dev)
     fwd = lambda: Fh._BnAct.apply(xb, bnw, bnb, brm, brv, 2, True, 0.1, 1e-5)  # noqa: E731
@@ -247,7 +268,7 @@ def kernel_cases(batch, size):
 
     conv = nn.Conv2d(Cb, Cb, 3, 2, 1, groups=Cb, bias=False).to(dev)
     bn = nn.BatchNorm2d(Cb).to(dev).train()
-    zb = torch.randn(B, Cb, hb, hb, generator=g).to(dev).requires_grad_(True)
+    zb = torch.randn(B, Cb, hb, wb2, generator=g).to(dev).requires_grad_(True)
     yb = Fh.bn_act_dwconv(zb, bn, "hardswish", conv)
     gy = torch.randn(yb.shape, generator=g).to(dev)
     nz, ny = 4.0 * zb.numel(), 4.0 * yb.numel()
@@ -259,7 +280,7 @@ def kernel_cases(batch, size):
 
     # ---- K9: 7x7/2 stem convolution (3 -> 64) at the image size; 2*B*Ho*Wo*64*147 FLOP each way
     stem = nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(dev)
-    img = torch.randn(B, 3, size, size, generator=g).to(dev)
+    img = torch.randn(B, 3, H, W, generator=g).to(dev)
     ys = Fh.stem_conv(img, stem)
     gs = torch.randn(ys.shape, generator=g).to(dev)
     fl_s = 2.0 * ys.numel() * 147
@@ -270,7 +291,7 @@ def kernel_cases(batch, size):
 
     # ---- K10: thin pointwise convolution 16 -> 64 on the size/2 plane (features.2 expansion)
     pw = nn.Conv2d(16, 64, 1, bias=False).to(dev)
-    xp = torch.randn(B, 16, hb, hb, generator=g).to(dev).requires_grad_(True)
+    xp = torch.randn(B, 16, hb, wb2, generator=g).to(dev).requires_grad_(True)
     yp = Fh.pwconv(xp, pw)
     gp = torch.randn(yp.shape, generator=g).to(dev)
     nx, nyp = 4.0 * xp.numel(), 4.0 * yp.numel()
@@ -279,30 +300,34 @@ def kernel_cases(batch, size):
     del xp, yp, gp
     torch.cuda.empty_cache()
 
-    # ---- f3: OHEM-CE fused with the final x8 upsample (per head)
-    ncls = 8
-    lowl = torch.randn(B, ncls, size // 8, size // 8, generator=g).to(dev)
-    lab = torch.randint(0, ncls, (B, size, size), generator=g).to(dev)
-    px = float(B * size * size)
-    yield ("ohem_up_fwd (f3: upsample + CE + OHEM partials)", lambda: Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255), px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
-    loss_px = Fh.ohem_up_fwd_hip(lowl, lab, (size, size), 0.7, 255)[0]
-    yield ("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)", lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (size, size), 0.7, 255, 1e-6), px * ncls * 16,
-          px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * size * (size // 8), "hbm")
-
-    lowl2 = torch.randn(B, ncls, size // 8, size // 8, generator=g).to(dev)
-    yield ("ohem_up_pair_fwd (f3: BOTH loss heads per launch, label tile shared)", lambda: Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (size, size), 0.7, 255),
-          2 * px * ncls * 12, px * (8 + 2 * 4) + 8.0 * lowl.numel(), "hbm")
-    loss_px2 = Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (size, size), 0.7, 255)[0]
-    yield ("ohem_up_pair_bwd (f3: both heads, x pass + y pass once)", lambda: Fh.ohem_up_pair_bwd_hip(lowl, lowl2, lab, loss_px2, (size, size), 0.7, 255, 1e-6),
-          2 * px * ncls * 16, px * (8 + 2 * 4) + 8.0 * lowl.numel() + 16.0 * B * ncls * size * (size // 8), "hbm")
+    # ---- f3: OHEM-CE fused with the final x8 upsample
+    ncls = classes
+    lowl = torch.randn(B, ncls, h, w, generator=g).to(dev)
+    lab = torch.randint(0, ncls, (B, H, W), generator=g).to(dev)
+    px = float(B * H * W)
+    if extra:  # one head per launch (OhemCELoss.forward_upsampled); the step runs the paired form below
+        yield ("ohem_up_fwd (f3: upsample + CE + OHEM partials)", lambda: Fh.ohem_up_fwd_hip(lowl, lab, (H, W), 0.7, 255),
+               px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
+        loss_px = Fh.ohem_up_fwd_hip(lowl, lab, (H, W), 0.7, 255)[0]
+        yield ("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)",
+               lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (H, W), 0.7, 255, 1e-6), px * ncls * 16,
+               px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * H * w, "hbm")
+    lowl2 = torch.randn(B, ncls, h, w, generator=g).to(dev)
+    yield ("ohem_up_pair_fwd (f3: BOTH loss heads per launch, label tile shared)",
+           lambda: Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255),
+           2 * px * ncls * 12, px * (8 + 2 * 4) + 8.0 * lowl.numel(), "hbm")
+    loss_px2 = Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255)[0]
+    yield ("ohem_up_pair_bwd (f3: both heads, x pass + y pass once)",
+           lambda: Fh.ohem_up_pair_bwd_hip(lowl, lowl2, lab, loss_px2, (H, W), 0.7, 255, 1e-6),
+           2 * px * ncls * 16, px * (8 + 2 * 4) + 8.0 * lowl.numel() + 16.0 * B * ncls * H * w, "hbm")
     del lowl2, loss_px2
 
     # ---- K5 / K6: the rest of the Context Aggregation Block at (B, 256, size/32, size/32)
     from cabinet_amd.models.cab import ContextAggregationBlock
 
     cab = ContextAggregationBlock(256, 128).to(dev).train()
-    xc = torch.randn(B, 256, size // 32, size // 32, generator=g).to(dev).requires_grad_(True)
-    gc = torch.randn(B, 256, size // 32, size // 32, generator=g).to(dev)
+    xc = torch.randn(B, 256, hl, wl, generator=g).to(dev).requires_grad_(True)
+    gc = torch.randn(B, 256, hl, wl, generator=g).to(dev)
     elems = float(xc.numel())
     yl = cab.local_attn(xc)
     yield ("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", lambda: cab.local_attn(xc.detach()), elems * 3 * 22, 8.0 * elems, "hbm")
@@ -318,10 +343,10 @@ def kernel_cases(batch, size):
 _NOTES = {
     "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
     "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
-    "cab_qkv_fwd": "5 dependent launches of <= 21 us each on 8192 positions: latency / small-tile MFMA bound",
+    "cab_qkv_fwd": "4 dependent launches of <= 21 us each on 8192 positions: latency / small-tile MFMA bound",
     "cab_qkv_bwd": "6 dependent launches on 8192 positions: latency / small-tile MFMA bound",
     "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
-                    "and the dq key-range slabs: it replaces recomputing S and dP for dq (4.3 GFLOP)",
+                    ": it replaces recomputing S and dP for dq (4.3 GFLOP)",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
     "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel), not HBM",
     "ohem_up_pair_bwd": "what the step runs: both heads per launch; exp and VALU bound (softmax recomputed per pixel)",
@@ -331,12 +356,16 @@ _NOTES = {
 }
 
 
-def kernel_rooflines(batch, size, iters):
+# kernel groups outside SURVEY.md section 8 (widening of earlier rounds: backbone / spatial-branch operators)
+_OUTSIDE_S8 = ("bn_act_", "bn_dwconv_", "stem_conv_", "pwconv_")
+
+
+def kernel_rooflines(batch, height, width, classes, iters, extra=False):
     """Per hand-written kernel group: launch duration from HIP events on the stream the kernels run on, achieved
     TFLOP/s / GB/s against the gfx950 peaks, and the measured HBM traffic when a PMC profile of THIS build exists."""
     out = []
-    traffic, traffic_src = load_traffic(batch, size)
-    for name, fn, flops, bytes_, bound in kernel_cases(batch, size):
+    traffic, traffic_src = load_traffic(batch, height, width, classes)
+    for name, fn, flops, bytes_, bound in kernel_cases(batch, height, width, classes, extra):
         if os.environ.get("CABINET_BENCH_VERBOSE") == "1":
             print(f"[bench] timing {name}", file=sys.stderr, flush=True)
         ms = time_kernel(fn, iters)
@@ -354,6 +383,7 @@ def kernel_rooflines(batch, size, iters):
         r["traffic_source"] = traffic_src
         if key in _NOTES:
             r["note"] = _NOTES[key]
+        r["scope"] = "outside SURVEY section 8 (widening)" if key.startswith(_OUTSIDE_S8) else "SURVEY section 8"
         r.update(kernel=name, ms_per_launch=round(ms, 4), algorithmic_gflop=round(flops / 1e9, 3),
                  algorithmic_mbytes=round(bytes_ / 1e6, 1), tflops=round(tf, 2), gbytes_per_s=round(gbs, 1))
         out.append(r)
@@ -363,13 +393,16 @@ def kernel_rooflines(batch, size, iters):
 def main():
     args = parse()
     t_start = time.perf_counter()
+    from cabinet_amd import ddp as ddp_mod
     from cabinet_amd.ddp import BucketedGradReducer, init_distributed
     from cabinet_amd.train import GraphedDDPStep, GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
 
-    if not torch.cuda.is_available():
+    # device_count() does not initialise the HIP runtime: with several ranks, init_distributed() pins the process to its
+    # GPU's NUMA node BEFORE the first GPU call so that the runtime's threads inherit the mask
+    if torch.cuda.device_count() == 0:
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if args.kernels_only:
-        for r in kernel_rooflines(args.batch, args.size, args.kernel_iters):
+        for r in kernel_rooflines(args.batch, args.height, args.width, args.classes, args.kernel_iters, args.all_kernels):
             print(f"{r['kernel'][:52]:52s} {r['ms_per_launch'] * 1e3:9.1f} us  {r['tflops']:7.2f} TF/s  "
                   f"frac {r['frac']:.3f}  {r['gbytes_per_s']:8.1f} GB/s")
         return
@@ -386,7 +419,7 @@ def main():
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-4, momentum=0.9,
                           weight_decay=5e-4)
     graphed = not args.no_graph
-    crit = make_criteria(args.batch, args.size, args.size, dev)
+    crit = make_criteria(args.batch, args.height, args.width, dev)
     reducer = None
     if graphed and ddp:
         # hipGraph segments with the bucket all-reduces issued between them: the decoder's 23 MB reduce while the encoders
@@ -397,7 +430,7 @@ def main():
     else:
         reducer = BucketedGradReducer(net, always_reduce=True) if ddp else None
         step = TrainStep(net, crit, reducer=reducer, optimizer=opt)
-    im, lb = synthetic_batch(args.batch, args.size, args.size, args.classes, dev, seed=1 + rank)
+    im, lb = synthetic_batch(args.batch, args.height, args.width, args.classes, dev, seed=1 + rank)
 
     def sync():
         if ddp:
@@ -452,23 +485,29 @@ def main():
     result = None
     if rank == 0:
         images = world * args.batch * args.steps
+        H, W = args.height, args.width
+        headline = (H, W, args.mode) == (1024, 1024, "large")
+        config5 = (args.batch, H, W, args.classes, args.mode, world) == (2, 2048, 1024, 19, "large", 1)
+        which = "configs[4]" if config5 else f"configs[{2 if world == 1 else 3}]"
         result = {
-            "metric": "1024x1024 images/sec fwd+bwd (CABiNet-MobileNetV3-Large)" if args.size == 1024 and args.mode == "large"
-            else f"{args.size}x{args.size} images/sec fwd+bwd (CABiNet-MobileNetV3-{args.mode})",
+            "metric": "1024x1024 images/sec fwd+bwd (CABiNet-MobileNetV3-Large)" if headline
+            else f"{H}x{W} images/sec fwd+bwd (CABiNet-MobileNetV3-{args.mode.capitalize()})",
             "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[{2 if world == 1 else 3}]: CABiNet-MobileNetV3-{args.mode.capitalize()}, "
-                             f"{args.batch}x3x{args.size}x{args.size} synthetic {args.classes}-class per GPU, "
+                "workload": (f"BASELINE {which}: CABiNet-MobileNetV3-{args.mode.capitalize()}, "
+                             f"{args.batch}x3x{H}x{W} synthetic {args.classes}-class per GPU, "
                              "fwd + 2x OhemCE + bwd + grad all-reduce + SGD step, HIP CAB/FFM kernels, fp32, "
                              "random-init (model seed 0, gamma=0.5)"),
-                "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image_size": args.size,
+                "per_gpu_batch": args.batch, "global_batch": args.batch * world, "image_size": [H, W],
                 "n_classes": args.classes, "parallelism": f"dp{world}",
                 "grad_buckets_mb": [round(x, 2) for x in reducer.bucket_megabytes] if reducer else None,
                 "host_path": ("hipGraph segments, bucket all-reduces between them (GraphedDDPStep)" if graphed and ddp
                               else "two captured hipGraphs per step around the one OHEM read-back (GraphedTrainStep)"
                               if graphed else "eager enqueue (TrainStep)"),
+                "dist_backend": torch.distributed.get_backend() if ddp else None,
+                "cpu_affinity": ddp_mod.AFFINITY if world > 1 else None,
             },
             "final_loss": round(final_loss, 5),
             "fwd_loss_bwd_only": {"value": round(images / dt_nopt, 3), "unit": "images/s",
@@ -480,38 +519,44 @@ def main():
     if rank == 0 and not args.no_kernel_roofline:
         del step, opt
         torch.cuda.empty_cache()
-        ks = kernel_rooflines(args.batch, args.size, args.kernel_iters)
+        ks = kernel_rooflines(args.batch, args.height, args.width, args.classes, args.kernel_iters, args.all_kernels)
         log("kernel rooflines measured")
         result["kernels"] = ks
-        # `roofline` = the CAB affinity+aggregate kernel the north_star sets its MFMA target on; the
-        # longest-running hand-written group is named alongside it
-        dom = max(ks, key=lambda r: r["ms_per_launch"])
+        # `roofline` = the CAB affinity+aggregate kernel the north_star sets its MFMA target on; next to it the
+        # longest-running hand-written group INSIDE SURVEY section 8 (the hot path's dominant cost) and, for context, the
+        # longest group overall (an out-of-scope backbone operator)
         k1 = ks[0]
+        s8 = [r for r in ks if r["scope"] == "SURVEY section 8" and "_bf16x" not in r["kernel"].split(" ")[0]]
+        dom8 = max(s8, key=lambda r: r["ms_per_launch"])
+        dom = max(ks, key=lambda r: r["ms_per_launch"])
         result["roofline"] = {k: k1[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
         result["roofline"].update(kernel=k1["kernel"], ms_per_launch=k1["ms_per_launch"],
                                   algorithmic_bytes=round(k1["algorithmic_mbytes"] * 1e6),
                                   traffic_source=k1["traffic_source"],
                                   peak_is="dense fp32 MFMA (v_mfma_f32_32x32x2_f32), not bf16",
-                                  longest_kernel_group=dom["kernel"], longest_kernel_frac=dom["frac"])
+                                  longest_section8_group={k: dom8[k] for k in ("kernel", "ms_per_launch", "bound", "achieved",
+                                                                              "peak", "unit", "frac", "traffic")},
+                                  longest_kernel_group=dom["kernel"], longest_kernel_frac=dom["frac"],
+                                  longest_kernel_scope=dom["scope"])
     if ddp:
         torch.distributed.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model_ref
         sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-        cb = model_ref.time_cpu_baseline(sd, args.mode, args.cpu_batch, args.size, args.classes)
+        cb = model_ref.time_cpu_baseline(sd, args.mode, args.cpu_batch, (args.height, args.width), args.classes)
         # the timed HIP model, on the very sample the CPU leg just ran, from the same weights: the model that was timed is
         # checked in the run that timed it
         import copy
 
         net_chk = copy.deepcopy(net).train()
-        xs, ls = model_ref.baseline_sample(args.cpu_batch, args.size, args.classes)
-        chk = TrainStep(net_chk, make_criteria(args.cpu_batch, args.size, args.size, dev))
+        xs, ls = model_ref.baseline_sample(args.cpu_batch, (args.height, args.width), args.classes)
+        chk = TrainStep(net_chk, make_criteria(args.cpu_batch, args.height, args.width, dev))
         loss_gpu = float(chk(xs.to(dev), ls.to(dev)))
         del net_chk, chk
         result["cpu_baseline"] = {
             "value": round(cb["value"], 4), "unit": "images/s", "cores": cb["cores"], "kind": "port",
             "sample": (f"oracle/model_ref.py (PyTorch-CPU fp32 restatement of the reference, pinned to reference "
-                       f"vectors): B={args.cpu_batch} {args.size}x{args.size}, 1 warm-up + {cb['timed_steps']} timed steps "
+                       f"vectors): B={args.cpu_batch} {args.height}x{args.width}, 1 warm-up + {cb['timed_steps']} timed steps "
                        f"({cb['seconds']:.1f} s) of fwd + 2x OhemCE + bwd"),
             "seconds_per_step": round(cb["seconds_per_step"], 3),
             "loss_cpu": round(cb["loss"], 6), "loss_gpu_same_sample": round(loss_gpu, 6),

@@ -256,23 +256,116 @@ class BucketedGradReducer:
                  len(b.params)) for b in self.buckets]
 
 
+def _parse_cpulist(text):
+    """'0-7,16-23' -> {0..7, 16..23} (the format of sysfs ``local_cpulist``)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(local_rank, sysfs="/sys/class/drm", visible=None):
+    """CPUs of the NUMA node the ``local_rank``-th visible AMD GPU hangs off, read from sysfs WITHOUT touching the HIP runtime
+    (``<sysfs>/card*/device/{vendor, numa_node, local_cpulist}``; GPUs ordered by PCI address, ``HIP_VISIBLE_DEVICES`` /
+    ``ROCR_VISIBLE_DEVICES`` index lists honoured).  Returns (cpu set | None, numa node | None)."""
+    import os
+
+    cards = {}
+    try:
+        names = sorted(os.listdir(sysfs))
+    except OSError:
+        return None, None
+    for name in names:
+        if not name.startswith("card") or not name[4:].isdigit():
+            continue
+        dev = os.path.join(sysfs, name, "device")
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip().lower() != "0x1002":
+                continue
+            if not os.path.exists(os.path.join(dev, "mem_info_vram_total")):
+                continue  # an AMD display function without VRAM: not a compute device
+            cards[os.path.basename(os.path.realpath(dev))] = dev
+        except OSError:
+            continue
+    devs = [cards[k] for k in sorted(cards)]
+    if visible is None:
+        visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if visible:
+        try:
+            devs = [devs[int(i)] for i in visible.split(",") if i.strip() != ""]
+        except (ValueError, IndexError):
+            return None, None  # UUID lists etc.: do not guess
+    if not 0 <= local_rank < len(devs):
+        return None, None
+    try:
+        node = int(open(os.path.join(devs[local_rank], "numa_node")).read().strip())
+        cpus = _parse_cpulist(open(os.path.join(devs[local_rank], "local_cpulist")).read())
+    except (OSError, ValueError):
+        return None, None
+    return (cpus or None), (node if node >= 0 else None)
+
+
+AFFINITY = {"set": False, "why": "not attempted"}  # what init_distributed did, for the bench line
+
+
+def set_rank_affinity(local_rank, sysfs="/sys/class/drm"):
+    """Pin this process (and every thread it creates from now on: HIP runtime, RCCL proxies, autograd) to the cores of its
+    GPU's NUMA node -- eight ranks' Python, MIOpen database copies and OHEM read-backs otherwise land wherever the scheduler
+    puts them, across the socket from the GPU they feed (the scaling risk is host-side).  Called
+    BEFORE the first GPU call so that the runtime's threads inherit the mask.  Never fails: without the sysfs data, with a
+    single NUMA node, or with CABINET_NO_AFFINITY=1 the mask is left alone."""
+    import os
+
+    global AFFINITY
+    if os.environ.get("CABINET_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        AFFINITY = {"set": False, "why": "disabled"}
+        return AFFINITY
+    cpus, node = gpu_local_cpus(local_rank, sysfs)
+    if not cpus:
+        AFFINITY = {"set": False, "why": "no NUMA information for this GPU in sysfs"}
+        return AFFINITY
+    allowed = os.sched_getaffinity(0)
+    target = cpus & allowed
+    if not target or target == allowed:
+        AFFINITY = {"set": False, "numa_node": node, "why": "the GPU's node covers every allowed core" if target else
+                    "none of the node's cores is allowed for this process"}
+        return AFFINITY
+    try:
+        os.sched_setaffinity(0, target)
+    except OSError as e:
+        AFFINITY = {"set": False, "why": f"sched_setaffinity: {e}"}
+        return AFFINITY
+    AFFINITY = {"set": True, "numa_node": node, "cpus": len(target)}
+    return AFFINITY
+
+
 def init_distributed(backend: Optional[str] = None):
-    """Initialise from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    """Initialise from torchrun's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  ``backend`` (or the
+    environment variable CABINET_DIST_BACKEND) selects the transport: ``nccl`` (= RCCL over xGMI, the default on GPUs, one
+    rank per device) or ``gloo`` (device tensors staged through the host: lets several ranks share ONE GPU, which RCCL
+    refuses -- the two-rank rehearsal of ``bench.py --gpus 2`` on a single-GPU box)."""
     import os
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force = os.environ.get("CABINET_FORCE_DDP") == "1"  # exercise the RCCL path on a single GPU (tests / bring-up)
+    if world > 1:
+        set_rank_affinity(local)  # before the first GPU call below
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("CABINET_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("CABINET_SHARE_GPU") == "1":  # every rank on device 0 (gloo rehearsal on a single-GPU box)
+        local = 0
     return rank, local, world

@@ -283,9 +283,10 @@ def usable_cpu_threads(cap=64):
 
 def baseline_sample(batch, size, n_classes):
     """The bounded sample the CPU baseline is timed on (and the HIP model is checked on, in the same bench run)."""
+    h, w = (size, size) if isinstance(size, int) else size
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(batch, 3, size, size, generator=g)
-    lb = torch.randint(0, n_classes, (batch, size, size), generator=g)
+    x = torch.randn(batch, 3, h, w, generator=g)
+    lb = torch.randint(0, n_classes, (batch, h, w), generator=g)
     return x, lb
 
 

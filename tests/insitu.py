@@ -98,6 +98,44 @@ def replay_head(low, labels, size, n_min, dtype, thresh=0.7):
     return float(loss.detach()), lo.grad
 
 
+def replay_b2(sd, z, r_gpu, d_r, training=True, eps=1e-5):
+    """The fusion head's BatchNorm + ReLU (reference cabinet.py:90-91; here K7 ``bn_act``) on the captured b1 output ``z``
+    and the captured gradient ``d_r`` of its ReLU output, in fp64, TWICE: with the mask the fp64 forward produces and with
+    the mask the GPU's own forward produced (``r_gpu > 0``).  A gradient that equals the own-mask replay is exact BatchNorm /
+    ReLU backward arithmetic; whatever separates it from the fp64-mask replay is flipped units, not arithmetic.
+    -> dict(out, flips, units, own=(dz, dgamma, dbeta), f64=(dz, dgamma, dbeta))"""
+    z = z.detach().cpu().double()
+    g = d_r.detach().cpu().double()
+    gamma = sd["ab.b2.weight"].double().view(1, -1, 1, 1)
+    beta = sd["ab.b2.bias"].double().view(1, -1, 1, 1)
+    if training:
+        mean = z.mean(dim=(0, 2, 3), keepdim=True)
+        var = z.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    else:
+        mean = sd["ab.b2.running_mean"].double().view(1, -1, 1, 1)
+        var = sd["ab.b2.running_var"].double().view(1, -1, 1, 1)
+    invstd = (var + eps).rsqrt()
+    xhat = (z - mean) * invstd
+    y = gamma * xhat + beta
+    mask64 = y > 0
+    mask_own = r_gpu.detach().cpu() > 0
+
+    def backward(mask):
+        dy = g * mask
+        dgamma, dbeta = (dy * xhat).sum(dim=(0, 2, 3)), dy.sum(dim=(0, 2, 3))
+        if training:
+            dz = gamma * invstd * (dy - dy.mean(dim=(0, 2, 3), keepdim=True) - xhat * (dy * xhat).mean(dim=(0, 2, 3), keepdim=True))
+        else:
+            dz = gamma * invstd * dy
+        return dz, dgamma, dbeta
+
+    return dict(out=y.clamp_min(0), flips=int((mask64 != mask_own).sum()), units=mask64.numel(),
+                own=backward(mask_own), f64=backward(mask64))
+
+
+B2_OWN_MASK_TOL = 1e-5  # K7's backward against the fp64 replay with K7's own ReLU mask (VERDICT r03 item 3)
+
+
 def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True, training=True):
     """Every output, input gradient and parameter gradient of the three hot-path entries, as the model produced them,
     against the fp64 oracle replayed on the model's own captured tensors.  rows: name -> {gpu_vs_f64[, cpu32_vs_f64], norm}"""
@@ -129,6 +167,17 @@ def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True, training=T
     for k, v in g64.items():
         put("ffm." + k, grads["ffm." + k], v, g32.get(k))
     del res
+    # ---- the fusion head's BatchNorm + ReLU next to the CAB (K7; outside section 8, but the chain tables put the entry point
+    # of the gradient noise between d.ab.r and d.ab.b1o: own-mask replay = arithmetic, fp64-mask replay = arithmetic + flips)
+    b2 = replay_b2(sd, cap["ab.b1o"], cap["ab.r"], cap["d.ab.r"], training)
+    put("ab.b2.out", cap["ab.r"], b2["out"])
+    put("ab.b2.dx_own_mask", cap["d.ab.b1o"], b2["own"][0])
+    put("ab.b2.weight_own_mask", grads["ab.b2.weight"], b2["own"][1])
+    put("ab.b2.bias_own_mask", grads["ab.b2.bias"], b2["own"][2])
+    rows["ab.b2.dx_own_mask"].update(
+        flipped_units_vs_f64_mask=b2["flips"], units=b2["units"], gpu_vs_f64_mask_replay=rel(cap["d.ab.b1o"], b2["f64"][0]),
+        own_mask_vs_f64_mask_replay=rel(b2["own"][0], b2["f64"][0]))
+    del b2
     # ---- the two fused OHEM heads (upstream gradient of each is exactly 1: loss = head + head16)
     losses = {}
     for name in ("head", "head16"):
@@ -155,6 +204,6 @@ def judge_operator_table(rows, tol, training=True):
             r["analytic_zero"] = True
             if not (r["norm"] < 1e-3 * scale_ref and r["gpu_vs_f64"] * r["norm"] < 1e-3 * scale_ref):
                 bad[k] = r
-        elif not r["gpu_vs_f64"] <= tol:
+        elif not r["gpu_vs_f64"] <= (B2_OWN_MASK_TOL if k == "ab.b2.dx_own_mask" else tol):
             bad[k] = r
     return bad

@@ -1,8 +1,12 @@
 """bench.py's per-kernel roofline loop at a tiny size: every kernel group must launch and report finite numbers
 (the default `python bench.py` runs this loop at config 3 after the timed region)."""
 import importlib.util
+import json
 import math
 import os
+import socket
+import subprocess
+import sys
 
 import pytest
 
@@ -15,7 +19,7 @@ def test_kernel_rooflines_run_at_a_small_size():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    rows = bench.kernel_rooflines(2, 256, 2)
+    rows = bench.kernel_rooflines(2, 256, 256, 8, 2, extra=True)
     names = [r["kernel"].split(" ")[0] for r in rows]
     for want in ("cab_attn_fwd", "cab_attn_bwd", "ffm_up_fwd", "ffm_up_bwd", "bn_act_fwd", "bn_act_bwd", "bn_dwconv_fwd",
                  "bn_dwconv_bwd", "stem_conv_fwd", "stem_conv_wrw", "pwconv_fwd", "pwconv_bwd", "ohem_up_fwd",
@@ -24,4 +28,50 @@ def test_kernel_rooflines_run_at_a_small_size():
     for r in rows:
         assert r["bound"] in ("hbm", "mfma") and r["ms_per_launch"] > 0
         assert all(math.isfinite(r[k]) for k in ("achieved", "peak", "frac", "tflops", "gbytes_per_s"))
-        assert r["traffic"] is None  # PMC traffic is only attached at the shape it was measured at (config 3)
+        assert r["traffic"] is None  # PMC traffic is only attached at the shape it was measured at (config 3 / config 5)
+        assert r["scope"].startswith("SURVEY section 8") != r["kernel"].startswith(("bn_act", "bn_dwconv", "stem_conv", "pwconv"))
+
+
+def test_kernel_rooflines_rectangular_19_classes():
+    """BASELINE config 5's geometry (H != W, H' x W' = 2:1, 19 classes) at a small size: default group set (what the step runs)."""
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = bench.kernel_rooflines(2, 512, 256, 19, 2)
+    names = [r["kernel"].split(" ")[0] for r in rows]
+    assert "ffm_fwd" not in names and "ohem_up_fwd" not in names  # only behind --all-kernels
+    for want in ("cab_attn_fwd", "cab_attn_bwd", "ffm_up_fwd", "ffm_up_bwd", "ohem_up_pair_fwd", "ohem_up_pair_bwd",
+                 "cab_local_fwd", "cab_local_bwd", "cab_qkv_fwd", "cab_qkv_bwd"):
+        assert want in names, want
+    assert all(r["ms_per_launch"] > 0 and math.isfinite(r["frac"]) for r in rows)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(1200)
+def test_bench_main_with_two_ranks_on_one_gpu():
+    """bench.py's own main() under torchrun with WORLD_SIZE = 2 -- the launch line the driver uses for N > 1 -- rehearsed on a
+    single-GPU box: both ranks on device 0, gloo instead of RCCL (RCCL refuses two ranks per device).  What it proves is
+    everything around the transport: the torchrun environment, the rank != 0 branch, per-rank MIOpen database copies,
+    GraphedDDPStep's segments and buckets, max-over-ranks timing, ONE JSON line as the last line of stdout."""
+    env = dict(os.environ, CABINET_DIST_BACKEND="gloo", CABINET_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MIOPEN_USER_DB_PATH", None)  # let bench.py make its per-process copies
+    env.pop("MIOPEN_CUSTOM_CACHE_DIR", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "2", "--size", "256", "--no-cpu-baseline", "--no-kernel-roofline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1100, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    r = json.loads(lines[-1])  # the JSON line is the LAST line of the job's stdout
+    assert sum(ln.lstrip().startswith("{") for ln in lines) == 1
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["dist_backend"] == "gloo" and r["config"]["grad_buckets_mb"]
+    assert "GraphedDDPStep" in r["config"]["host_path"]
+    assert r["value"] > 0 and math.isfinite(r["final_loss"]) and r["ms_per_step"] > 0
+    assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-2 * r["value"]  # whole-job images / max-over-ranks time

@@ -97,12 +97,35 @@ def _full_step(mode, batch, height, width, ncls, tag):
     ref32 = {k: v.clone() for k, v in w32.grads().items()}
     bufs_ref = {k: v.clone() for k, v in w32.buffers().items()}
     del w32, out_ref, out16_ref, out, out16
+    # reference vs reference: the SAME fp32 CPU oracle on the same inputs with ONE intra-op thread
+    # instead of all cores -- ATen's reductions then sum in another order, a few ReLU units land on the other side of zero,
+    # and the reference's own gradients move.  Where that spread exceeds 1e-3 the literal "1e-3 against the PyTorch-CPU
+    # reference" clause is not decidable by any implementation, the reference included.
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    w32b = model_ref.Weights(sd)
+    model_ref.train_step(w32b, im, lb, mode)
+    ref32_1t = {k: v.clone() for k, v in w32b.grads().items()}
+    del w32b
+    torch.set_num_threads(threads)
     w64 = model_ref.Weights(sd, dtype=torch.float64)
     taps64 = {}
     _, _, loss64 = model_ref.train_step(w64, im.double(), lb, mode, taps=taps64)
     taps64 = _tap_copies(taps64)
     ref64 = w64.grads()
     rows = gradient_table(net, ref32, ref64)
+    spread = []
+    for k, r in rows.items():
+        ediff, _ = rel_pair(ref32_1t[k], ref32[k])
+        r["ref32_1thread_vs_ref32_allthreads"] = ediff / max(r["norm"], 1e-300)
+        if not r["analytic_zero"]:
+            spread.append(r["ref32_1thread_vs_ref32_allthreads"])
+    spread.sort()
+    ref_vs_ref = dict(threads=[threads, 1], tensors=len(spread), past_1e3=sum(x > TOL for x in spread),
+                      median=spread[len(spread) // 2], p90=spread[int(0.9 * len(spread))], max=spread[-1],
+                      what="||g_ref32(1 thread) - g_ref32(all threads)|| / ||g_f64|| per gradient tensor: the fp32 PyTorch-CPU "
+                           "reference against ITSELF with another summation order")
+    del ref32_1t
     failures, listed = judge_gradients(rows, load_allowlist()[tag])
     worst = sorted(((r["gpu_vs_f64"], k) for k, r in rows.items() if not r["analytic_zero"]), reverse=True)[:10]
     # Where the gradient noise enters: distance from the fp64 model of every tensor either side of the
@@ -128,7 +151,7 @@ def _full_step(mode, batch, height, width, ncls, tag):
         tolerance=TOL, allow_factor=ALLOW_FACTOR, rule=load_allowlist()[tag],
         past_1e3_within_bound=listed, failures=[k for k, _ in failures], worst_vs_f64=worst,
         chain_either_side_of_the_hot_path=chain, relu_mask_flips_vs_f64=flips, hip_cab_on_fp64_model_inputs=cross,
-        tensors=rows))
+        reference_vs_reference=ref_vs_ref, tensors=rows))
     assert e <= TOL * d, f"final_logit rel {e / d:.3e}"
     assert e16 <= TOL * d16, f"high_res_logit_up rel {e16 / d16:.3e}"
     assert abs(loss - float(loss_ref)) <= TOL * abs(float(loss_ref)), (loss, float(loss_ref))

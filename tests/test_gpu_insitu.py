@@ -4,7 +4,9 @@ The full-model gradient tables (tests/test_gpu_fullsize.py) cannot tell "ReLU-ma
 hot-path kernel is 1e-3 off at n = 2048": both move a parameter gradient by the same amount.  Here the REAL model runs its
 real step (config 3: Large 8x3x1024x1024, 8 classes; config 5: Large 2x3x2048x1024, 19 classes; gamma = 0.5), and at the
 three places the section-8 hot path is entered -- the CAB (K6 -> K1/K2 -> conv1x1 -> K5), the fused-upsample FFM, the two
-fused OHEM heads -- the input AND the incoming gradient are captured (tests/insitu.py).  The fp64 oracle is then replayed on
+fused OHEM heads -- the input AND the incoming gradient are captured (tests/insitu.py); since round 4 also the fusion head's
+BatchNorm + ReLU next to the CAB (K7 on ``ab.b2``, reference cabinet.py:88-92: its backward must equal the fp64 replay with
+its OWN ReLU mask to 1e-5 -- "one flipped unit, not K7 arithmetic" as a replay instead of a count).  The fp64 oracle is then replayed on
 exactly those captured tensors, and every output, input gradient and parameter gradient the model produced in place must be
 within 1e-3 (||a-b||/||b||) of it.  Measured: 1e-7 .. 6e-5, i.e. as close to fp64 as the fp32 CPU reference replayed on the
 same tensors (column cpu32_vs_f64); the table of every run is written to gpurun_out/insitu_<tag>.json (committed copy:
@@ -53,7 +55,7 @@ def _insitu(mode, batch, height, width, ncls, tag):
         tensors=rows))
     assert abs(float(loss) - loss64) <= 1e-5 * abs(loss64), (float(loss), loss64)
     assert not bad, {k: {n: (f"{v:.2e}" if isinstance(v, float) else v) for n, v in r.items()} for k, r in bad.items()}
-    assert len(rows) == 2 + 20 + 3 + 5 + 2, sorted(rows)
+    assert len(rows) == 2 + 20 + 3 + 5 + 4 + 2, sorted(rows)
 
 
 @pytest.mark.timeout(1800)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Launch ONE hand-written kernel group of bench.py at BASELINE config-3 shapes `iters` times (for rocprofv3 passes).
+"""Launch ONE hand-written kernel group of bench.py `iters` times (for rocprofv3 passes) at the workload shape the environment
+names: CAB_B x 3 x CAB_H x CAB_W, CAB_CLASSES classes (defaults = BASELINE config 3: 8 x 3 x 1024 x 1024, 8 classes;
+config 5: CAB_B=2 CAB_H=2048 CAB_W=1024 CAB_CLASSES=19).
 
     python tools/run_kernels.py <iters> <group>      group = first word of a bench.py kernel name, e.g. cab_attn_fwd
 
@@ -17,9 +19,11 @@ import bench  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
 B = int(os.environ.get("CAB_B", "8"))
-size = int(os.environ.get("CAB_SIZE", "1024"))
+H = int(os.environ.get("CAB_H", os.environ.get("CAB_SIZE", "1024")))
+W = int(os.environ.get("CAB_W", os.environ.get("CAB_SIZE", "1024")))
+ncls = int(os.environ.get("CAB_CLASSES", "8"))
 found = False
-for name, fn, flops, nbytes, bound in bench.kernel_cases(B, size):
+for name, fn, flops, nbytes, bound in bench.kernel_cases(B, H, W, ncls, extra=True):
     key = name.split(" ")[0]
     if which in ("all", key):
         found = True

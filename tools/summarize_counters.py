@@ -43,7 +43,9 @@ def main(root, out_path):
             kernels[k] = row
         groups[g] = kernels
     out = {"source_digest": build.source_digest(), "batch": int(os.environ.get("CAB_B", "8")),
-           "size": int(os.environ.get("CAB_SIZE", "1024")),
+           "height": int(os.environ.get("CAB_H", os.environ.get("CAB_SIZE", "1024"))),
+           "width": int(os.environ.get("CAB_W", os.environ.get("CAB_SIZE", "1024"))),
+           "classes": int(os.environ.get("CAB_CLASSES", "8")),
            "method": "rocprofv3 --pmc, three separate counter-only passes per kernel group over tools/run_kernels.py 4 <group> "
                      "(tools/pmc_counters.sh); per-launch averages per kernel; kernels launched fewer than 4 times in a group's "
                      "run (operand set-up of earlier groups) are dropped",

@@ -48,7 +48,9 @@ def main(root, out_path):
             detail[g]["FETCH_SIZE_KiB_per_launch"] = round(vals["FETCH_SIZE"], 1)
             detail[g]["WRITE_SIZE_KiB_per_launch"] = round(vals["WRITE_SIZE"], 1)
     out = {"source_digest": build.source_digest(), "batch": int(os.environ.get("CAB_B", "8")),
-           "size": int(os.environ.get("CAB_SIZE", "1024")),
+           "height": int(os.environ.get("CAB_H", os.environ.get("CAB_SIZE", "1024"))),
+           "width": int(os.environ.get("CAB_W", os.environ.get("CAB_SIZE", "1024"))),
+           "classes": int(os.environ.get("CAB_CLASSES", "8")),
            "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes, counters only), 6-launch minus 3-launch sums "
                      "over cabinet:: dispatches / 3; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH calibration)",
            "traffic": traffic, "per_kernel_KiB": detail}
