@@ -25,7 +25,7 @@ struct GemmKArgs {
 
 // tails in M and P are masked; if K % 16 != 0 the A operand must hold align16(K) rows, the extra ones zero
 // (the B row index is clamped to K-1, so the tail products vanish)
-void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream);
+hipError_t gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream);
 
 // dW[:, col_off : col_off+Cx] = sum over images and pixels of dzv (B,Co,P) x xs (B,Cx,P)^T, written with row
 // stride ldo; `part` holds the split-K slabs: dw_part_floats(...) floats

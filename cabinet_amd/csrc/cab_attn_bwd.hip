@@ -872,11 +872,14 @@ static int bwd_nsplit(int B, int n) {
     const int nt = (n + 31) / 32, wgs = nt * B;
     int best = 1;
     double best_cost = 1e30;
+    double cost1 = 0.0;
     for (int s = 1; s <= 8; s *= 2) {
         if (s > 1 && s * 8 > nt) break;  // every wave keeps at least one query tile
         const double cost = (double)((wgs * s + 255) / 256) / (double)s + (s > 1 ? 0.05 * s : 0.0);
+        if (s == 1) cost1 = cost;
         if (cost < best_cost - 1e-9) best = s, best_cost = cost;
     }
+    if (best > 1 && best_cost > 0.85 * cost1) best = 1;  // only for a clear win: the slabs and their ordered sum are not free
     return best;
 }
 

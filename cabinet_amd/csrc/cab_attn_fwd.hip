@@ -549,11 +549,17 @@ int attn_fwd_kvsplit(int B, int n) {
     const int nt = (n + 31) / 32, wgs = nt * B;
     int best = 1;
     double best_cost = 1e30;
+    double cost1 = 0.0;
     for (int s = 1; s <= 8; s *= 2) {
         if (s > 1 && s * 8 > nt) break;  // every wave of the 8-wave kernel keeps at least one key tile
         const double cost = (double)((wgs * s + 255) / 256) / (double)s + (s > 1 ? 0.04 * s : 0.0);
+        if (s == 1) cost1 = cost;
         if (cost < best_cost - 1e-9) best = s, best_cost = cost;
     }
+    // a split pays a partial-ctx round trip and a merge launch that this round model only charges roughly: take it only for a
+    // clear win (>= 15 % fewer rounds).  B = 8 frames of n = 8704 would otherwise split 2 for 9 -> 8.58 rounds (5 %) at the
+    // price of 71 MB of partial results -- a case nobody measured.
+    if (best > 1 && best_cost > 0.85 * cost1) best = 1;
     return best;
 }
 

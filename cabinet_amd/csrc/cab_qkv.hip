@@ -852,7 +852,7 @@ hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int 
     a.src0 = a.src1 = x, a.K0 = Ci;
     a.dst0 = a.dst1 = y, a.M0 = Co;
     a.P = P;
-    gemm_kmajor(a, B, stream);
+    if (hipError_t ge = gemm_kmajor(a, B, stream); ge != hipSuccess) return ge;
     return hipGetLastError();
 }
 
@@ -890,7 +890,7 @@ hipError_t conv1x1_bwd_run(const float* dy, const float* x, const float* wgt, in
         a.src0 = a.src1 = dy, a.K0 = Co;
         a.dst0 = a.dst1 = dx, a.M0 = Ci;
         a.P = P;
-        gemm_kmajor(a, B, stream);
+        if (hipError_t ge = gemm_kmajor(a, B, stream); ge != hipSuccess) return ge;
     }
     if (dw) return dw_product(dy, x, B, Co, Ci, P, part, dw, Ci, 0, stream);
     return hipGetLastError();

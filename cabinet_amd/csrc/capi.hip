@@ -3,6 +3,7 @@
 #include "../../include/cabinet_hip.h"
 
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 
 #include "cab_local.hpp"
@@ -120,6 +121,15 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// 128-bit loads / stores on activation rows: every tensor pointer named must be 16-byte aligned (include/cabinet_hip.h)
+template <typename... P>
+static bool aligned16(P... p) {
+    return ((reinterpret_cast<uintptr_t>(p) | ...) & 15) == 0;
+}
+#define CABINET_REQUIRE_ALIGNED(what, ...)                                                                            \
+    if (!aligned16(__VA_ARGS__))                                                                                      \
+    return fail(CABINET_ERR_INVALID_ARG, what ": tensor pointers must be 16-byte aligned (128-bit loads / stores)")
+
 static int hip_status(hipError_t e, const char* what) {
     if (e == hipSuccess) return CABINET_OK;
     return fail(CABINET_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
@@ -169,6 +179,7 @@ int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float s
     if (!cabinet_cab_attn_precision_supported(Kc, Vc, precision))
         return fail(CABINET_ERR_UNSUPPORTED, "cab_attn_fwd: precision %d is not built for (Kc=%d, Vc=%d)", precision, Kc, Vc);
     if (!q || !k || !v || !ctx || !lse) return fail(CABINET_ERR_INVALID_ARG, "cab_attn_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("cab_attn_fwd", q, k, v, ctx, lse);
     const size_t need = cabinet_cab_attn_fwd_workspace_bytes(B, Kc, Vc, n, precision);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "cab_attn_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -199,6 +210,7 @@ int cabinet_cab_attn_bwd(const float* dctx, const float* q, const float* k, cons
     if (int rc = check_attn_shape(B, Kc, Vc, n)) return rc;
     if (!dctx || !q || !k || !v || !ctx || !lse || !dq || !dk || !dv)
         return fail(CABINET_ERR_INVALID_ARG, "cab_attn_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("cab_attn_bwd", dctx, q, k, v, ctx, lse, dq, dk, dv);
     const size_t need = cabinet_cab_attn_bwd_workspace_bytes(B, Kc, Vc, n);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "cab_attn_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -353,6 +365,7 @@ int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels, int B,
     if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
     if (!logits_low || !labels || !loss_px || !blk_sum || !blk_cnt)
         return fail(CABINET_ERR_INVALID_ARG, "ohem_up_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ohem_up_fwd", logits_low, labels, loss_px);
     return hip_status(cabinet::ohem_up_fwd_run(1, &logits_low, labels, B, C, Hl, Wl, H, W, thresh, ignore_lb, &loss_px, &blk_sum,
                                                &blk_cnt, static_cast<hipStream_t>(stream)),
                       "ohem_up_fwd launch");
@@ -369,6 +382,7 @@ int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const 
     if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
     if (!logits_low || !labels || !loss_px || !dlogits_low)
         return fail(CABINET_ERR_INVALID_ARG, "ohem_up_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ohem_up_bwd", logits_low, labels, loss_px, dlogits_low);
     const size_t need = cabinet_ohem_up_bwd_workspace_bytes(B, C, Hl, Wl, H, W);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "ohem_up_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -384,6 +398,7 @@ int cabinet_ohem_up_pair_fwd(const float* logits_low_a, const float* logits_low_
     if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
     if (!logits_low_a || !logits_low_b || !labels || !loss_px || !blk_sum || !blk_cnt)
         return fail(CABINET_ERR_INVALID_ARG, "ohem_up_pair_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ohem_up_pair_fwd", logits_low_a, logits_low_b, labels, loss_px);
     const int nblk = cabinet::ohem_blocks(B, H, W);
     const float* low[2] = {logits_low_a, logits_low_b};
     float* lp[2] = {loss_px, loss_px + (size_t)B * H * W};
@@ -404,6 +419,7 @@ int cabinet_ohem_up_pair_bwd(const float* logits_low_a, const float* logits_low_
     if (int rc = check_ohem(B, C, Hl, Wl, H, W)) return rc;
     if (!logits_low_a || !logits_low_b || !labels || !loss_px || !dlogits_low)
         return fail(CABINET_ERR_INVALID_ARG, "ohem_up_pair_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ohem_up_pair_bwd", logits_low_a, logits_low_b, labels, loss_px, dlogits_low);
     const size_t need = cabinet_ohem_up_pair_bwd_workspace_bytes(B, C, Hl, Wl, H, W);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "ohem_up_pair_bwd: workspace %zu < %zu bytes", workspace_bytes, need);

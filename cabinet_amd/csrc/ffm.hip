@@ -205,37 +205,34 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
 }
 
 template <int WM, bool INTERIOR, int UP>
-static void launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
+static hipError_t launch_gemm_k(const GemmKArgs& a, int B, hipStream_t stream) {
     constexpr int MT = 128 * WM;
     const size_t lds = (size_t)(2 * GK_BK * MT + 2 * GK_BK * GK_NT) * sizeof(float);
     static lds_attr_mask attr_mask{0};
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR, UP>), lds, attr_mask);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_kmajor_kernel<WM, INTERIOR, UP>), lds, attr_mask);
+        e != hipSuccess)
+        return e;  // wrong device / LDS above the limit: report THIS, not the unrelated launch failure that would follow
     dim3 grid(ceil_div(a.P, GK_NT), ceil_div(a.M, MT), B);
     hipLaunchKernelGGL((gemm_kmajor_kernel<WM, INTERIOR, UP>), grid, dim3(512), lds, stream, a);
+    return hipSuccess;
 }
 
 template <int WM>
-static void launch_gemm_k_wm(const GemmKArgs& a, int B, bool interior, hipStream_t stream) {
+static hipError_t launch_gemm_k_wm(const GemmKArgs& a, int B, bool interior, hipStream_t stream) {
     // the row form of the upsample epilogue needs full tiles that are segments of one output row, and room for vrow
     const bool row_up = a.up_src && interior && (a.W % GK_NT) == 0 && a.Wl == 32;
-    if (!a.up_src)
-        interior ? launch_gemm_k<WM, true, 0>(a, B, stream) : launch_gemm_k<WM, false, 0>(a, B, stream);
-    else if (row_up)
-        launch_gemm_k<WM, true, 1>(a, B, stream);
-    else
-        interior ? launch_gemm_k<WM, true, 2>(a, B, stream) : launch_gemm_k<WM, false, 2>(a, B, stream);
+    if (!a.up_src) return interior ? launch_gemm_k<WM, true, 0>(a, B, stream) : launch_gemm_k<WM, false, 0>(a, B, stream);
+    if (row_up) return launch_gemm_k<WM, true, 1>(a, B, stream);
+    return interior ? launch_gemm_k<WM, true, 2>(a, B, stream) : launch_gemm_k<WM, false, 2>(a, B, stream);
 }
 
-void gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
+hipError_t gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
     int wm = a.M <= 128 ? 1 : (a.M > 256 && a.M <= 384) ? 3 : 2;
     if (wm > 1 && (a.M % 128) == 0 && ceil_div(a.P, GK_NT) * B * ceil_div(a.M, 128 * wm) < 200) wm = 1;  // small grid
     const bool interior = (a.P % GK_NT) == 0 && (a.M % (128 * wm)) == 0 && (a.lda % 4) == 0;
-    if (wm == 1)
-        launch_gemm_k_wm<1>(a, B, interior, stream);
-    else if (wm == 3)
-        launch_gemm_k_wm<3>(a, B, interior, stream);
-    else
-        launch_gemm_k_wm<2>(a, B, interior, stream);
+    if (wm == 1) return launch_gemm_k_wm<1>(a, B, interior, stream);
+    if (wm == 3) return launch_gemm_k_wm<3>(a, B, interior, stream);
+    return launch_gemm_k_wm<2>(a, B, interior, stream);
 }
 
 // =====================================================================================
@@ -393,16 +390,25 @@ struct DzArgs {
     float* dz;
     int C;
 };
+// LDS layout of the horizontal pass (round 4): the vertical sums of a row are stored DE-INTERLEAVED by the resize ratio
+// R = W / Wl (when it is an integer; else R = 1): output column ox sits at (ox % R) * plane + ox / R.  Source column xs
+// receives from the taps ox = b_lo(xs) + t with b_lo advancing by R per lane, so in tap step t every lane of a wave reads
+// the same phase at consecutive words; the tap weights and these permuted indices are tabulated tap-major ([XT][Wl]: a lane
+// = a source column reads consecutive words).  Round 3 read tcol[b_lo + t] (lane stride R = 4 words) and wxw[xs * XT + t]
+// (lane stride XT = 12 words): both 4-way bank conflicts, 576 extra LDS cycles per workgroup = the 4.7 M
+// SQ_LDS_BANK_CONFLICT cycles per launch of profiles/r03_pmc_counters.json.  plane = 32 / R (mod 32) keeps the phase-major
+// WRITES of the vertical pass conflict-free as well.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __restrict__ hi, float* __restrict__ lo,
                                                                 int H, int W, int Hl, int Wl, float rh, float rw,
-                                                                int max_rows, int XT, DzArgs d) {
+                                                                int max_rows, int XT, int R, int plane, DzArgs d) {
     extern __shared__ __attribute__((aligned(16))) float rows[];  // [max_rows][W] staged output rows
-    float* tcol = rows + (size_t)max_rows * W;   // [ADJ_BAND][W] vertical sums
-    float* wyt = tcol + ADJ_BAND * W;            // [ADJ_BAND][max_rows] vertical weights
-    float* wxw = wyt + ADJ_BAND * max_rows;      // [Wl][XT] horizontal weights of the taps ox = xlo[xs] + t
-    int* xlo = reinterpret_cast<int*>(wxw + Wl * XT);  // [Wl]
-    int* yr = xlo + Wl;                          // [ADJ_BAND] r_lo | r_hi << 16 (staged-row range with non-zero weight)
+    const int TW = R * plane;
+    float* tcol = rows + (size_t)max_rows * W;   // [ADJ_BAND][R][plane] vertical sums, de-interleaved by R
+    float* wyt = tcol + ADJ_BAND * TW;           // [ADJ_BAND][max_rows] vertical weights
+    float* wxw = wyt + ADJ_BAND * max_rows;      // [XT][Wl] horizontal weights of the taps ox = b_lo(xs) + t
+    int* xidx = reinterpret_cast<int*>(wxw + Wl * XT);  // [XT][Wl] position of that tap's vertical sum inside a tcol row
+    int* yr = xidx + Wl * XT;                    // [ADJ_BAND] r_lo | r_hi << 16 (staged-row range with non-zero weight)
     const int bands = (Hl + ADJ_BAND - 1) / ADJ_BAND, pl = blockIdx.x / bands;
     const int ys_lo = (blockIdx.x % bands) * ADJ_BAND, ys_hi = min(ys_lo + ADJ_BAND, Hl) - 1;
     const int oy_lo = max(0, (int)floorf(((float)ys_lo - 0.5f) / rh - 0.5f) - 1);
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
     const int nrows = oy_hi - oy_lo + 1, n_in = nrows * W, nys = ys_hi - ys_lo + 1, tid = threadIdx.x;
     // every index split below is a division by a run-time width (~40 emulated instructions each; they were half of this
     // kernel's 1035 VALU instructions per wave, on a pass that should be HBM-bound): exact reciprocal forms instead
-    const float inv_W = 1.f / (float)W, inv_Wl = 1.f / (float)Wl, inv_mr = 1.f / (float)max_rows, inv_XT = 1.f / (float)XT;
+    const float inv_W = 1.f / (float)W, inv_Wl = 1.f / (float)Wl, inv_mr = 1.f / (float)max_rows;
     if (FUSED) {
         const int c = pl % d.C;
         const float mu = d.mean[c], is = d.invstd[c], gw = d.bn_w[c], gb = d.bn_b[c];
@@ -466,8 +472,9 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
         }
         wyt[i] = wgt;
     }
+    const float inv_R = 1.f / (float)R;
     for (int i = tid; i < Wl * XT; i += 256) {
-        const int xs = idiv_small(i, inv_XT), t = i - xs * XT;
+        const int t = idiv_small(i, inv_Wl), xs = i - t * Wl;
         const int b_lo = max(0, (int)floorf(((float)xs - 0.5f) / rw - 0.5f) - 1), ox = b_lo + t;
         float wgt = 0.f;
         if (ox < W) {
@@ -477,7 +484,8 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
             wgt = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
         }
         wxw[i] = wgt;
-        if (t == 0) xlo[xs] = b_lo;
+        const int oc = min(ox, W - 1), q = idiv_small(oc, inv_R);  // weights past the row end are zero
+        xidx[i] = (oc - q * R) * plane + q;
     }
     if (tid < nys) {
         const int ys = ys_lo + tid;
@@ -492,15 +500,15 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
         const float* wv = wyt + yi * max_rows;
         float acc = 0.f;
         for (int r = rr & 0xffff; r <= (rr >> 16); ++r) acc += wv[r] * rows[r * W + ox];
-        tcol[o] = acc;
+        const int q = idiv_small(ox, inv_R);
+        tcol[yi * TW + (ox - q * R) * plane + q] = acc;
     }
     __syncthreads();
     for (int o = tid; o < nys * Wl; o += 256) {
-        const int yi = idiv_small(o, inv_Wl), xs = o - yi * Wl, b_lo = xlo[xs];
-        const float* wh = wxw + xs * XT;
-        const float* tr = tcol + yi * W;
+        const int yi = idiv_small(o, inv_Wl), xs = o - yi * Wl;
+        const float* tr = tcol + yi * TW;
         float acc = 0.f;
-        for (int t = 0; t < XT; ++t) acc += wh[t] * tr[min(b_lo + t, W - 1)];  // weights past the row end are zero
+        for (int t = 0; t < XT; ++t) acc += wxw[t * Wl + xs] * tr[xidx[t * Wl + xs]];
         lo[((size_t)pl * Hl + ys_lo + yi) * Wl + xs] = acc;
     }
 }
@@ -1025,7 +1033,7 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
     a.src0 = fsp, a.src1 = fcp, a.K0 = s.Cs;
     a.dst0 = z, a.dst1 = z, a.M0 = s.Co;
     a.P = P;
-    gemm_kmajor(a, s.B, stream);
+    if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
                  save_invstd, pooled, gate, stream);
     return hipGetLastError();
@@ -1056,7 +1064,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
         a.src0 = low, a.src1 = low, a.K0 = s.Cc;
         a.dst0 = ylow, a.dst1 = ylow, a.M0 = s.Co;
         a.P = Pl;
-        gemm_kmajor(a, s.B, stream);
+        if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     }
     if (precision != 0 && gemm_bf16_supported(s.Co, s.Cs, P, s.W, Wl, true)) {
         // z = W_s . fsp + U(y_low) on the bf16 matrix pipe (operands split into bf16 pieces, gemm_bf16.hip)
@@ -1072,7 +1080,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
         a.P = P;
         a.up_src = ylow, a.Hl = Hl, a.Wl = Wl, a.W = s.W;
         a.rh = (float)Hl / (float)s.H, a.rw = (float)Wl / (float)s.W;
-        gemm_kmajor(a, s.B, stream);
+        if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     }
     ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
                  save_invstd, pooled, gate, stream);
@@ -1186,7 +1194,7 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
     a.src0 = dz, a.src1 = dz, a.K0 = s.Co;
     a.dst0 = dfsp, a.dst1 = dfcp, a.M0 = s.Cs;
     a.P = P;
-    gemm_kmajor(a, s.B, stream);
+    if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     // G3: dW = dz X^T per source tensor, split over pixel chunks, ordered slab reduction
     hipError_t e = dw_product(dz, fsp, s.B, s.Co, s.Cs, P, part, dw_blk, Cin, 0, stream);
     if (e != hipSuccess) return e;
@@ -1212,18 +1220,23 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
                  dw1, dw2, stream, !fuse_dz);
     // dz_low = U^T dz  (adjoint of the bilinear upsample), then everything on the Cc side is low resolution
     {
-        const size_t lds = ((size_t)(max_rows + ADJ_BAND) * s.W + (size_t)ADJ_BAND * max_rows + (size_t)Wl * XT + Wl +
-                            ADJ_BAND) * sizeof(float);
-        static size_t attr_lds = 0;
-        if (lds > attr_lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(upsample_adjoint_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_lds = lds;
-        }
+        // de-interleave factor of the horizontal pass: the integer resize ratio (the model's x4), else 1 (plain layout)
+        const int R = (Wl > 0 && s.W % Wl == 0 && s.W / Wl <= 32) ? s.W / Wl : 1;
+        int plane = ceil_div(s.W, R);
+        const int want = (R & (R - 1)) == 0 ? 32 / R : 1;  // phase stride in banks (see the kernel header)
+        plane += (want - plane % 32 + 32) % 32;
+        const size_t lds = ((size_t)max_rows * s.W + (size_t)ADJ_BAND * R * plane + (size_t)ADJ_BAND * max_rows +
+                            (size_t)2 * Wl * XT + ADJ_BAND) * sizeof(float);
+        // the staged band grows with the resize ratio: the attribute is set to the device maximum once (per device), so
+        // that a small first call cannot pin it below what a later, larger geometry needs
+        static lds_attr_mask mask_fused{0}, mask_plain{0};
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(upsample_adjoint_kernel<true>), 160 * 1024, mask_fused);
+            e != hipSuccess)
+            return e;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(upsample_adjoint_kernel<false>), 160 * 1024, mask_plain);
+            e != hipSuccess)
+            return e;
         DzArgs da{};
         const dim3 grid(s.B * s.Co * ((Hl + ADJ_BAND - 1) / ADJ_BAND));
         if (fuse_dz) {
@@ -1232,10 +1245,10 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
             da.mean_dy = reinterpret_cast<float*>(base + L.mdy), da.mean_dyx = reinterpret_cast<float*>(base + L.mdyx);
             da.dz = dz, da.C = s.Co;
             hipLaunchKernelGGL(upsample_adjoint_kernel<true>, grid, dim3(256), lds, stream, dz, dzl, s.H, s.W, Hl, Wl,
-                               (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, da);
+                               (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, R, plane, da);
         } else {
             hipLaunchKernelGGL(upsample_adjoint_kernel<false>, grid, dim3(256), lds, stream, dz, dzl, s.H, s.W, Hl, Wl,
-                               (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, da);
+                               (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, R, plane, da);
         }
     }
     {   // dfsp = W_s^T dz
@@ -1244,7 +1257,7 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
         a.src0 = dz, a.src1 = dz, a.K0 = s.Co;
         a.dst0 = dfsp, a.dst1 = dfsp, a.M0 = s.Cs;
         a.P = P;
-        gemm_kmajor(a, s.B, stream);
+        if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     }
     const bool small = small_grid(s.B, s.Cc, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0 && (s.Co % 4) == 0;
     if (small) {  // dlow = W_c^T dz_low: the (Co x Cin) weight is the K-major A operand as stored
@@ -1258,7 +1271,7 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
         a.src0 = dzl, a.src1 = dzl, a.K0 = s.Co;
         a.dst0 = dlow, a.dst1 = dlow, a.M0 = s.Cc;
         a.P = Pl;
-        gemm_kmajor(a, s.B, stream);
+        if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     }
     hipError_t e = dw_product(dz, fsp, s.B, s.Co, s.Cs, P, part, dw_blk, Cin, 0, stream);
     if (e != hipSuccess) return e;

@@ -13,6 +13,7 @@
 //           dlow[b][c][ys][xs] = sum_oy wy(oy,ys) T[b][c][oy][xs]
 //         no atomics -> bitwise reproducible (PyTorch's own upsample backward uses atomicAdd).
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -294,8 +295,12 @@ constexpr int OBX_T = 256;
 //     the clamped source index folds the window of the first / last column) -- no tap evaluation, no phase bookkeeping;
 //   * every i / FR, i % FR is a shift or a mask.
 // FR == 0 is the general resize ratio (taps evaluated per term).
-// grid.z = NH * B: blockIdx.z / B selects the head (its logits, per-pixel losses and T slab); with NH = 2 the two heads of an
-// output row run as neighbouring workgroups of one launch (shared labels stay in L2) instead of two dependent launches.
+// 1-D grid, decoded XCD-aware: the dispatcher deals blocks round-robin over the 8 XCDs, so block n runs on XCD n % 8.  Each XCD
+// walks a CONTIGUOUS chunk of the (image, output row, segment) list -- it then touches one eighth of the `low` planes instead
+// of all of them (every XCD's private L2 used to fetch all of both heads' logits: +64 MB per launch at config 3) -- and the
+// NH heads of one item are consecutive slots of the SAME XCD (blocks n and n + 8), so the label / validity tile the heads
+// share is fetched from HBM once (round 3 ran head 1 as a second z-half of the grid, 16384 blocks later: its label reads
+// missed L2, +67 MB; measured pair traffic 436 MB against 277 MB algorithmic).  Speed only, never correctness.
 struct OhemBwdHeads {
     const float* low[2];
     const float* loss_px[2];
@@ -303,17 +308,19 @@ struct OhemBwdHeads {
 };
 
 template <int CMAX, bool EXACT, int FR>
-__global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(OhemBwdHeads hd, const long long* __restrict__ labels, int B,
+__global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(OhemBwdHeads hd, const long long* __restrict__ labels, int NH, int B,
                                                              int C, int Hl, int Wl, int H, int W, float rh, float rw, float thresh,
                                                              int ignore_lb, float coef, int SX, int nox_max, int R_,
                                                              int gplane) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int R = FR ? FR : R_;
-    const int head = blockIdx.z / B;
+    const int nseg = (Wl + SX - 1) / SX, items = nseg * H * B, per_xcd = (items + 7) >> 3;
+    const int slot = blockIdx.x >> 3, head = slot % NH, item = (blockIdx.x & 7) * per_xcd + slot / NH;
+    if (item >= items) return;  // the grid is rounded up to 8 x NH x per_xcd blocks (uniform per workgroup)
     const float* __restrict__ low = hd.low[head];
     const float* __restrict__ loss_px = hd.loss_px[head];
     float* __restrict__ T = hd.T[head];
-    const int b = blockIdx.z - head * B, oy = blockIdx.y, xs0 = blockIdx.x * SX, P = H * W;
+    const int seg = item % nseg, row = item / nseg, oy = row % H, b = row / H, xs0 = seg * SX, P = H * W;
     const int nxs = min(SX, Wl - xs0);
     // output pixels whose taps can touch [xs0, xs0 + nxs)
     const int ox_lo = FR ? FR * xs0 - 3 * (FR / 2) : max(0, (int)floorf(((float)xs0 - 0.5f) / rw - 0.5f) - 1);
@@ -411,6 +418,166 @@ __global__ __launch_bounds__(OBX_T) void ohem_up_bwd_x_kernel(OhemBwdHeads hd, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// x pass for the model's x8 resize with whole source rows per wave (W == 8 Wl, Wl == 64 IPL, IPL in {1, 2, 4}) -- round 4.
+//
+// The segment kernel above is VALU-issue bound (592 vector instructions per wave and 512 output pixels; the counters of
+// profiles/r03_pmc_counters.json put the VALU at ~100 % of the SIMD cycles), and most of that is not the softmax: per pixel
+// and class it evaluates the horizontal taps twice (2 LDS reads + 2 multiply-adds), stores G, and gathers it again with 16
+// more LDS reads per (class, column).  Here G never exists:
+//   * a thread of the class phase owns IPL CONSECUTIVE source intervals g of one class row (a wave = one whole class row), and
+//     for each interval the eight output pixels ox = 8 g + j.  Those read only the staged columns g-1, g, g+1, so the class'
+//     eight upsampled logits are  x_j = fma(t_j, d, v_g)  from ONE difference per side (exactly the forward kernel's expression,
+//     so that lse = loss + x_label reconstructs the forward's own log-sum-exp bit for bit);
+//   * the adjoint of the resize is applied in registers: pixel j < 4 sends (1 - lam_j) G_j to column g - 1 and lam_j G_j to
+//     column g, pixel j >= 4 sends (1 - lam_j) to g and lam_j to g + 1 (clamped taps at the two borders fold into the border
+//     column), i.e. three weighted sums L_g, M_g, R_g per interval and  T[xs] = R_{xs-1} + M_xs + L_{xs+1}  with the neighbour
+//     terms of the lane's first / last interval fetched by one wave shuffle each -- fixed summation order, no atomics;
+//   * everything that does not depend on the class is done ONCE per pixel by the per-interval threads of the first phase:
+//     lse_j = loss_j log2 e + x_label (or +inf for a pixel that is not selected: exp2(x - inf) = 0 switches it off), kept in
+//     LDS and then in 8 IPL registers of the class-phase lane for all classes; and the one-hot part of (softmax - onehot),
+//     which only touches the label's class: its three weighted sums go to oh{L,M,R}[label][g], owned by the interval's thread.
+// Per pixel and class this leaves fma + sub + v_exp_f32 + ~2 fma.
+template <int IPL>
+__global__ __launch_bounds__(256) void ohem_up_bwd_x8row_kernel(OhemBwdHeads hd, const long long* __restrict__ labels, int NH,
+                                                                int B, int C, int Hl, int H, float rh, float thresh,
+                                                                int ignore_lb, float coef) {
+    constexpr int Wl = 64 * IPL, W = 8 * Wl;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* v = smem;                 // [C][Wl]  vertically interpolated logits of this output row, exp2 domain
+    float* lse = v + C * Wl;         // [W]      per pixel: loss log2 e + x_label, +inf when the pixel is not selected
+    float* ohL = lse + W;            // [C][Wl]  one-hot part of L / M / R (sums of tap weights of the selected pixels of class c)
+    float* ohM = ohL + C * Wl;
+    float* ohR = ohM + C * Wl;
+    const int items = H * B, per_xcd = (items + 7) >> 3;
+    const int slot = blockIdx.x >> 3, head = slot % NH, item = (blockIdx.x & 7) * per_xcd + slot / NH;
+    if (item >= items) return;  // grid rounded up to 8 x NH x per_xcd blocks
+    const int oy = item % H, b = item / H, tid = threadIdx.x, CW = C * Wl;
+    const float* __restrict__ low = hd.low[head];
+    const float* __restrict__ loss_px = hd.loss_px[head];
+    float* __restrict__ T = hd.T[head];
+    const size_t plane = (size_t)Hl * Wl;
+    int y0, y1;
+    float ly;
+    bilinear_taps(oy, rh, Hl, y0, y1, ly);
+    {   // stage v: the rows of v are contiguous in the source (class-major planes, Wl floats per row): independent 16-byte loads
+        const float* low_b = low + (size_t)b * C * plane;
+        const int q4 = CW >> 2;
+        for (int i0 = tid; i0 < q4; i0 += 4 * 256) {
+            f32x4 a0[4], a1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * 256, q4 - 1), c = (4 * i) / Wl, xs = 4 * i - c * Wl;
+                const float* p = low_b + (size_t)c * plane + xs;
+                a0[u] = *reinterpret_cast<const f32x4*>(p + y0 * Wl);
+                a1[u] = *reinterpret_cast<const f32x4*>(p + y1 * Wl);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < q4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = ((1.f - ly) * a0[u][e] + ly * a1[u][e]) * LOG2E_F;
+                    *reinterpret_cast<f32x4*>(v + 4 * (i0 + u * 256)) = o;
+                }
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: one thread per source interval g (eight pixels): lse and the one-hot sums
+    for (int g = tid; g < Wl; g += 256) {
+        const size_t pix = ((size_t)b * H + oy) * W + 8 * g;
+        long long lb[8];
+        float ls[8];
+        {
+            const longlong2* lp = reinterpret_cast<const longlong2*>(labels + pix);
+            const f32x4* sp = reinterpret_cast<const f32x4*>(loss_px + pix);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const longlong2 t = lp[u];
+                lb[2 * u] = t.x, lb[2 * u + 1] = t.y;
+            }
+            const f32x4 s0 = sp[0], s1 = sp[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ls[e] = s0[e], ls[4 + e] = s1[e];
+        }
+        for (int c = 0; c < C; ++c) ohL[c * Wl + g] = 0.f, ohM[c * Wl + g] = 0.f, ohR[c * Wl + g] = 0.f;
+        const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
+        float out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float lam = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+            const float t = j < 4 ? -(1.f - lam) : lam;
+            const bool sel = lb[j] != (long long)ignore_lb && ls[j] > thresh;
+            const bool inrange = lb[j] >= 0 && lb[j] < (long long)C;
+            const int lrow = inrange ? (int)lb[j] * Wl : 0;
+            const float* vl = v + lrow;
+            const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);  // the forward's x_label
+            out[j] = sel ? fmaf(ls[j], LOG2E_F, xl) : INFINITY;
+            if (sel && inrange) {  // one-hot part: this thread owns column g of every class row (j ascending: a fixed order)
+                if (j < 4) {
+                    ohL[lrow + g] += 1.f - lam;
+                    ohM[lrow + g] += lam;
+                } else {
+                    ohM[lrow + g] += 1.f - lam;
+                    ohR[lrow + g] += lam;
+                }
+            }
+        }
+        f32x4* lp4 = reinterpret_cast<f32x4*>(lse + 8 * g);
+        lp4[0] = f32x4{out[0], out[1], out[2], out[3]};
+        lp4[1] = f32x4{out[4], out[5], out[6], out[7]};
+    }
+    __syncthreads();
+    // ---- phase 2: a wave per class row, a lane per IPL consecutive intervals
+    const int wave = tid >> 6, lane = tid & 63, g0 = lane * IPL;
+    float lr[8 * IPL];
+#pragma unroll
+    for (int u = 0; u < 2 * IPL; ++u) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(lse + 8 * g0 + 4 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lr[4 * u + e] = t[e];
+    }
+    for (int c = wave; c < C; c += 4) {
+        const float* vc = v + c * Wl;
+        float Lg[IPL], Mg[IPL], Rg[IPL];
+#pragma unroll
+        for (int u = 0; u < IPL; ++u) {
+            const int g = g0 + u;
+            const float xc = vc[g], dm = xc - vc[max(g - 1, 0)], dp = vc[min(g + 1, Wl - 1)] - xc;
+            float L = 0.f, M = 0.f, R = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lam = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+                const float e = fast_exp2(fmaf(j < 4 ? -(1.f - lam) : lam, j < 4 ? dm : dp, xc) - lr[8 * u + j]);
+                if (j < 4) {
+                    L = fmaf(1.f - lam, e, L);
+                    M = fmaf(lam, e, M);
+                } else {
+                    M = fmaf(1.f - lam, e, M);
+                    R = fmaf(lam, e, R);
+                }
+            }
+            Lg[u] = coef * (L - ohL[c * Wl + g]);
+            Mg[u] = coef * (M - ohM[c * Wl + g]);
+            Rg[u] = coef * (R - ohR[c * Wl + g]);
+        }
+        // T[xs] = R_{xs-1} + M_xs + L_{xs+1}; the clamped taps of the first / last column fold L_0 / R_{Wl-1} into that column
+        float rprev = __shfl_up(Rg[IPL - 1], 1, 64), lnext = __shfl_down(Lg[0], 1, 64);
+        if (lane == 0) rprev = Lg[0];
+        if (lane == 63) lnext = Rg[IPL - 1];
+        float o[IPL];
+#pragma unroll
+        for (int u = 0; u < IPL; ++u) o[u] = ((u > 0 ? Rg[u - 1] : rprev) + Mg[u]) + (u + 1 < IPL ? Lg[u + 1] : lnext);
+        float* dst = T + (((size_t)b * C + c) * H + oy) * Wl + g0;
+        if (IPL == 1)
+            dst[0] = o[0];
+        else if (IPL == 2)
+            *reinterpret_cast<float2*>(dst) = float2{o[0], o[IPL > 1 ? 1 : 0]};
+        else
+            *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[IPL > 1 ? 1 : 0], o[IPL > 2 ? 2 : 0], o[IPL > 3 ? 3 : 0]};
+    }
+}
+
 // dlow[b][c][ys][xs] = sum_oy wy(oy, ys) * T[b][c][oy][xs]
 __global__ __launch_bounds__(256) void ohem_up_bwd_y_kernel(const float* __restrict__ T, int planes, int Hl, int Wl, int H,
                                                              float rh, int fastR, float* __restrict__ dlow) {
@@ -499,7 +666,12 @@ static void ohem_segment(int C, int Wl, int W, int& SX, int& nox_max, int& R, in
     for (SX = 64; SX >= 1; SX >>= 1) {
         nox_max = (int)((float)(SX + 2) / rw) + 8;
         gplane = ceil_div(nox_max, R);
-        gplane += (8 - gplane % 32 + 32) % 32;  // plane stride = 8 mod 32 banks: the phase-major writes stay 2-way
+        // plane stride = 32 / R (mod 32) banks for a power-of-two R <= 32: the 32 lanes ds_write_b32 serves per LDS cycle are
+        // 32 consecutive pixels = R phases x 32 / R consecutive groups, i.e. bank = phase * 32 / R + group: all 32 distinct.
+        // (Round 3 used 8 (mod 32) for every R: two-way on the x8 writes -- harmless in time, a 2-way store hides under the
+        // instruction's own 4 issue cycles, but it is what SQ_LDS_BANK_CONFLICT counted, 150 cycles per workgroup.)
+        const int want = (R <= 32 && (R & (R - 1)) == 0) ? 32 / R : 8;
+        gplane += (want - gplane % 32 + 32) % 32;
         lds = ((size_t)C * (SX + 4) + (size_t)C * R * gplane) * sizeof(float);
         if (lds <= 60 * 1024) return;
     }
@@ -511,6 +683,12 @@ bool ohem_up_supported(int C, int Wl, int W) {
     size_t lds;
     ohem_segment(C, Wl, W, SX, nox, R, gplane, lds);
     return SX > 0 && (size_t)C * Wl * sizeof(float) <= 60 * 1024;
+}
+
+// CABINET_OHEM_SEGMENT_KERNEL=1 forces the round-3 segment kernel for the x pass (A/B timing, tests of the general form)
+static bool os_row_kernel_enabled() {
+    const char* e = getenv("CABINET_OHEM_SEGMENT_KERNEL");  // read per call: a test toggles it inside one process
+    return !(e && e[0] == '1');
 }
 
 // nh heads: dlow is (nh, B, C, Hl, Wl) contiguous, the workspace holds nh T slabs
@@ -526,15 +704,39 @@ hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* lab
     ohem_segment(C, Wl, W, SX, nox_max, R, gplane, lds);
     const int fast_y = (Hl > 0 && H % Hl == 0 && ((H / Hl) & 1) == 0) ? H / Hl : 0;  // integer, even ratio: closed-form weights
     const bool x8 = Wl > 0 && W == 8 * Wl && 8 * (SX + 3) <= nox_max && SX + 3 <= gplane;  // the model's x8 upsample
+    const int xgrid = 8 * nh * ceil_div(ceil_div(Wl, SX) * H * B, 8);  // XCD-chunked, the heads of an item adjacent per XCD
+    // whole source rows per wave (see ohem_up_bwd_x8row_kernel): the model's geometry at every BASELINE configuration
+    const int ipl = (Wl > 0 && W == 8 * Wl && Wl % 64 == 0) ? Wl / 64 : 0;
+    const size_t lds_row = ((size_t)4 * C * Wl + (size_t)W) * sizeof(float);
+    bool aligned = (reinterpret_cast<uintptr_t>(labels) & 15) == 0;
+    for (int i = 0; i < nh; ++i)
+        aligned = aligned && ((reinterpret_cast<uintptr_t>(low[i]) | reinterpret_cast<uintptr_t>(loss_px[i]) |
+                               reinterpret_cast<uintptr_t>(hd.T[i])) & 15) == 0;
+    if ((ipl == 1 || ipl == 2 || ipl == 4) && aligned && lds_row <= 64 * 1024 && os_row_kernel_enabled()) {
+        const int rgrid = 8 * nh * ceil_div(H * B, 8);
+        static lds_attr_mask m1{0}, m2{0}, m4{0};
+#define OHEM_ROW(I, M)                                                                                                   \
+        do {                                                                                                             \
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ohem_up_bwd_x8row_kernel<I>), 64 * 1024, M);  \
+                e != hipSuccess)                                                                                         \
+                return e;                                                                                                \
+            hipLaunchKernelGGL((ohem_up_bwd_x8row_kernel<I>), dim3(rgrid), dim3(256), lds_row, stream, hd, labels, nh, B, C, Hl, \
+                               H, (float)Hl / (float)H, thresh, ignore_lb, coef);                                        \
+        } while (0)
+        if (ipl == 1) OHEM_ROW(1, m1);
+        else if (ipl == 2) OHEM_ROW(2, m2);
+        else OHEM_ROW(4, m4);
+#undef OHEM_ROW
+    } else {
 #define OHEM_BWD(CM, EX)                                                                                                 \
     do {                                                                                                                 \
         if (x8)                                                                                                          \
-            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 8>), dim3(ceil_div(Wl, SX), H, nh * B), dim3(OBX_T), lds, stream, \
-                               hd, labels, B, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh,       \
+            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 8>), dim3(xgrid), dim3(OBX_T), lds, stream,                 \
+                               hd, labels, nh, B, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh,   \
                                ignore_lb, coef, SX, nox_max, R, gplane);                                                  \
         else                                                                                                             \
-            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 0>), dim3(ceil_div(Wl, SX), H, nh * B), dim3(OBX_T), lds, stream, \
-                               hd, labels, B, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh,       \
+            hipLaunchKernelGGL((ohem_up_bwd_x_kernel<CM, EX, 0>), dim3(xgrid), dim3(OBX_T), lds, stream,                 \
+                               hd, labels, nh, B, C, Hl, Wl, H, W, (float)Hl / (float)H, (float)Wl / (float)W, thresh,   \
                                ignore_lb, coef, SX, nox_max, R, gplane);                                                  \
     } while (0)
     if (C == 8) OHEM_BWD(8, true);
@@ -544,6 +746,7 @@ hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* lab
     else if (C <= 20) OHEM_BWD(20, false);
     else OHEM_BWD(32, false);
 #undef OHEM_BWD
+    }
     // the T slabs are contiguous only when slab == B*C*H*Wl exactly; run the y pass per head otherwise
     const size_t plane_floats = (size_t)B * C * H * Wl;
     if (nh == 1 || slab == plane_floats) {

@@ -48,10 +48,14 @@ def _workspace(nbytes, device):
 
 
 def _f32c(t):
-    """Borrowed inputs must be dense fp32 (same rule the C ABI documents)."""
+    """Borrowed inputs must be dense fp32 and 16-byte aligned (the rules the C ABI documents): a contiguous VIEW that starts
+    4 or 8 bytes into its allocation (``x[1:]``, ``x.flatten()[1:]``) is copied."""
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() & 15:
+        t = t.clone()
+    return t
 
 
 # --------------------------------------------------------------------------- attention core

@@ -11,6 +11,10 @@
  * Conventions
  *  - All tensors are dense fp32, NCHW-contiguous, resident on the current HIP
  *    device.  Pointers are borrowed; nothing is retained after the call returns.
+ *  - Tensor pointers must be 16-byte aligned: the kernels move rows with 128-bit
+ *    loads and stores.  (Any allocator's base pointer is; a view that starts 4 or
+ *    8 bytes into an allocation is not -- copy it first.)  The attention and OHEM
+ *    entry points check it and return CABINET_ERR_INVALID_ARG.
  *  - Every call is asynchronous on `stream` (a hipStream_t; NULL = the default
  *    stream).  No call synchronises, allocates device memory or uses a private
  *    stream, so calls are hipGraph-capturable and re-entrant.

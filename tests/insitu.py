@@ -136,6 +136,18 @@ def replay_b2(sd, z, r_gpu, d_r, training=True, eps=1e-5):
 B2_OWN_MASK_TOL = 1e-5  # K7's backward against the fp64 replay with K7's own ReLU mask
 
 
+def cab_table(net, sd, cap, training=True):
+    """The CAB rows of operator_table alone (fp64 replay only): cheap enough for the full-step tests, whose gradient rule
+    asks which CAB gradients are exact in situ (tests/parity_rules.py)."""
+    rows = {}
+    grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    y64, dx64, g64 = replay_cab(sd, cap["cab.x"], cap["d.cab.y"], torch.float64, training)
+    for name, gpu, f64 in [("cab.out", cap["cab.y"], y64), ("cab.dx", cap["d.cab.x"], dx64)] + \
+            [("ab.a2block." + k, grads["ab.a2block." + k], v) for k, v in g64.items()]:
+        rows[name] = dict(gpu_vs_f64=rel(gpu, f64), norm=float(f64.double().norm()), numel=f64.numel())
+    return rows
+
+
 def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True, training=True):
     """Every output, input gradient and parameter gradient of the three hot-path entries, as the model produced them,
     against the fp64 oracle replayed on the model's own captured tensors.  rows: name -> {gpu_vs_f64[, cpu32_vs_f64], norm}"""

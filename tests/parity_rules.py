@@ -17,12 +17,16 @@ Rule, per gradient tensor -- no per-configuration floor, no blanket bound:
   pass  if within TOL = 1e-3 of the fp32 reference, or of the fp64 oracle;
   else  its distance from the fp64 oracle must not exceed ALLOW_FACTOR x the fp32 reference's OWN distance from fp64 ON THIS
         TENSOR, measured live ("as close to the truth as the reference's own fp32 arithmetic is on this tensor");
-  else  the tensor must be NAMED in tests/golden/grad_allowlist.json[tag]["tensors"] with its measured numbers, and is then
-        bounded by the effect of FLIPS single-unit ReLU flips on the CAB grid, FLIPS / sqrt(256 x CAB positions).  Only
-        parameters inside the CAB may be listed (tests/test_oracle_golden.py enforces names, count and sizes): those are the
-        tensors for which the in-situ tests prove the kernels exact on the model's own inputs, so that what remains is the
-        incoming gradient's flip noise (config 5: d(cab.y) is 2.1e-3 from fp64 on the GPU and 5.9e-4 on the CPU at ~1 flipped
-        unit per million either way -- and the reverse, 4.9e-4 vs 2.1e-3, at config 3).
+  else  it must be a parameter INSIDE the CAB whose gradient the SAME run proves exact in situ -- the fp64 oracle replayed on
+        the tensors the model itself fed the CAB reproduces the model's own gradient of this parameter to EXACT_IN_SITU = 2e-5
+        (tests/insitu.py; measured 6e-8 .. 6e-6) -- or a tensor NAMED in tests/golden/grad_allowlist.json[tag]["tensors"]
+        with its measured numbers (the cases seen so far, kept as the record; only CAB parameters may be listed,
+        tests/test_oracle_golden.py enforces names, count and sizes).  Such a tensor is bounded by the effect of FLIPS
+        single-unit ReLU flips on the CAB grid, FLIPS / sqrt(256 x CAB positions): the operator being exact on its own inputs,
+        what remains is the incoming gradient's flip noise, which differs from run to run (MIOpen's backward kernels use
+        atomics: the same test, same seeds, gave 4.0e-4 on one box and 2.1e-3 on the next for refine.1's BatchNorm bias at
+        Small 4x512^2, with the in-situ row at 2.5e-7 both times; config 5: d(cab.y) is 2.1e-3 from fp64 on the GPU and 5.9e-4
+        on the CPU at ~1 flipped unit per million either way -- and the reverse, 4.9e-4 vs 2.1e-3, at config 3).
 Every run writes the full per-tensor table (gpurun_out/parity_<tag>.json; committed copies under profiles/)."""
 import json
 import os
@@ -34,6 +38,7 @@ ALLOW_FACTOR = 3.0
 FLIPS = 3.0            # single-unit ReLU flips on the CAB grid the bound makes room for
 MAX_NAMED = 8          # named exceptions per configuration
 MAX_BOUND = 1.5e-2     # no tensor is ever allowed further than this from the fp64 oracle
+EXACT_IN_SITU = 2e-5   # a CAB gradient this close to the fp64 replay on the model's own tensors is "exact in situ"
 
 
 def rel_pair(a, b):
@@ -93,19 +98,30 @@ def flip_bound(cfg):
     return FLIPS / (256.0 * cfg["cab_positions"]) ** 0.5
 
 
-def tensor_bound(name, row, cfg):
+def exact_in_situ(insitu_rows):
+    """Names of the CAB parameters whose in-place gradient equals the fp64 replay on the model's own tensors (rows of
+    tests/insitu.py::operator_table / cab_table of the SAME run) to EXACT_IN_SITU."""
+    return {k for k, r in (insitu_rows or {}).items()
+            if k.startswith("ab.a2block.") and not r.get("analytic_zero") and r["gpu_vs_f64"] <= EXACT_IN_SITU}
+
+
+def tensor_bound(name, row, cfg, exact=()):
     """Largest admissible distance of the GPU gradient from the fp64 oracle for one tensor (module docstring)."""
-    named = flip_bound(cfg) if name in cfg.get("tensors", {}) else 0.0
-    return min(max(TOL, ALLOW_FACTOR * row["ref32_vs_f64"], named), MAX_BOUND)
+    flips = flip_bound(cfg) if (name in cfg.get("tensors", {}) or name in exact) else 0.0
+    return min(max(TOL, ALLOW_FACTOR * row["ref32_vs_f64"], flips), MAX_BOUND)
 
 
-def judge_gradients(rows, cfg):
-    """Apply the rule of the module docstring; returns (failures, tensors that needed more than TOL)."""
+def judge_gradients(rows, cfg, insitu_rows=None):
+    """Apply the rule of the module docstring; returns (failures, tensors that needed more than TOL).  ``insitu_rows``: the
+    in-situ operator table of the same run (which CAB gradients are exact on the model's own tensors)."""
     failures, listed = [], []
+    exact = exact_in_situ(insitu_rows)
     for k, r in rows.items():
         if r["analytic_zero"] or min(r["gpu_vs_ref32"], r["gpu_vs_f64"]) <= TOL:
             continue
-        bound = tensor_bound(k, r, cfg)
+        bound = tensor_bound(k, r, cfg, exact)
+        if k in exact:
+            r["exact_in_situ"] = insitu_rows[k]["gpu_vs_f64"]
         if r["gpu_vs_f64"] <= bound:
             listed.append(k)
             continue

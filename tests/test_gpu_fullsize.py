@@ -23,7 +23,7 @@ import pytest
 import torch
 
 from conftest import assert_close
-from insitu import instrument, judge_operator_table, operator_table, rel
+from insitu import cab_table, instrument, judge_operator_table, operator_table, rel
 from parity_rules import TOL, ALLOW_FACTOR, gradient_table, host_memory_gb, judge_gradients, load_allowlist, rel_pair, write_table
 
 TAPS = ("mob", "cab.x", "cab.y", "ab.b1o", "ab.r", "ffm.fsp", "ffm.low", "ffm.y", "head.low", "head16.low")
@@ -126,7 +126,8 @@ def _full_step(mode, batch, height, width, ncls, tag):
                       what="||g_ref32(1 thread) - g_ref32(all threads)|| / ||g_f64|| per gradient tensor: the fp32 PyTorch-CPU "
                            "reference against ITSELF with another summation order")
     del ref32_1t
-    failures, listed = judge_gradients(rows, load_allowlist()[tag])
+    cab_insitu = cab_table(net, sd, cap)  # which CAB gradients of THIS run are exact on the model's own tensors
+    failures, listed = judge_gradients(rows, load_allowlist()[tag], cab_insitu)
     worst = sorted(((r["gpu_vs_f64"], k) for k, r in rows.items() if not r["analytic_zero"]), reverse=True)[:10]
     # Where the gradient noise enters: distance from the fp64 model of every tensor either side of the
     # hot path, for the HIP model and for the fp32 CPU reference ...
@@ -151,7 +152,7 @@ def _full_step(mode, batch, height, width, ncls, tag):
         tolerance=TOL, allow_factor=ALLOW_FACTOR, rule=load_allowlist()[tag],
         past_1e3_within_bound=listed, failures=[k for k, _ in failures], worst_vs_f64=worst,
         chain_either_side_of_the_hot_path=chain, relu_mask_flips_vs_f64=flips, hip_cab_on_fp64_model_inputs=cross,
-        reference_vs_reference=ref_vs_ref, tensors=rows))
+        reference_vs_reference=ref_vs_ref, cab_insitu_vs_f64_replay=cab_insitu, tensors=rows))
     assert e <= TOL * d, f"final_logit rel {e / d:.3e}"
     assert e16 <= TOL * d16, f"high_res_logit_up rel {e16 / d16:.3e}"
     assert abs(loss - float(loss_ref)) <= TOL * abs(float(loss_ref)), (loss, float(loss_ref))
@@ -225,7 +226,7 @@ def test_model_eval_bn_gradients(mode, batch, size, ncls):
     assert not bad, {k: {n: (f"{v:.2e}" if isinstance(v, float) else v) for n, v in r.items()} for k, r in bad.items()}
     rows = gradient_table(net, ref32, refs[torch.float64][3])
     assert len(rows) > 150
-    failures, listed = judge_gradients(rows, load_allowlist()[tag])
+    failures, listed = judge_gradients(rows, load_allowlist()[tag], insitu)
     write_table(f"parity_{tag}.json", dict(past_1e3_within_bound=listed, failures=[k for k, _ in failures], tensors=rows,
                                            insitu_operators_vs_f64_replay=insitu))
     assert not failures, [(k, {n: f"{v:.2e}" for n, v in r.items() if isinstance(v, float)}) for k, r in failures]

@@ -131,7 +131,7 @@ def test_model_vs_oracle_logits_and_grads(mode, batch, size, ncls):
     if mode == "large":
         rows = {k: r for k, r in rows.items() if k.startswith(("ab.a2block.", "ffm."))}
         assert len(rows) >= 25
-    failures, listed = judge_gradients(rows, load_allowlist()[tag])
+    failures, listed = judge_gradients(rows, load_allowlist()[tag], insitu)
     write_table(f"parity_{tag}.json", dict(past_1e3_within_bound=listed, failures=[k for k, _ in failures], tensors=rows,
                                            insitu_operators_vs_f64_replay=insitu))
     assert not failures, [(k, {n: f"{v:.2e}" for n, v in r.items() if isinstance(v, float)}) for k, r in failures]

@@ -25,6 +25,9 @@ TOL = 1e-3
     (1, 19, 16, 136, 128, 1088, 0.1, 0.7, 128 * 1088 // 16),      # x8, three column segments (64 + 64 + 8), 19 classes
     (1, 8, 8, 8, 48, 48, 0.0, 0.7, 48 * 48 // 16),                # x6: an even ratio whose reciprocal is inexact in fp32
     (1, 8, 1, 1, 8, 8, 0.0, 0.7, 4),                              # one source pixel: every weight is 1 (both borders at once)
+    (1, 8, 4, 64, 32, 512, 0.05, 0.7, 32 * 512 // 16),            # x8 with whole source rows per wave: one interval per lane
+    (2, 19, 3, 128, 24, 1024, 0.1, 0.7, 2 * 24 * 1024 // 16),     # ... two intervals per lane (the model's 1024-wide rows), 19 classes
+    (1, 5, 2, 256, 16, 2048, 0.0, 0.7, 16 * 2048 // 16),          # ... four intervals per lane, 5 classes (waves 1-3 get one class or none)
 ])
 def test_fused_ohem_vs_oracle(B, C, Hl, Wl, H, W, ignore_frac, thresh, n_min):
     from cabinet_amd.loss import OhemCELoss
@@ -47,6 +50,33 @@ def test_fused_ohem_vs_oracle(B, C, Hl, Wl, H, W, ignore_frac, thresh, n_min):
         assert_close(x.grad, ref_in.grad, TOL, "dlogits_low", atol=1e-9)
     else:
         assert x.grad is None or float(x.grad.abs().sum()) == 0.0
+
+
+def test_row_kernel_equals_segment_kernel():
+    """The round-4 x pass (whole source rows per wave, resize adjoint in registers) against the round-3 segment kernel it
+    replaces for W == 8 Wl, Wl % 64 == 0 -- same forward state, both heads, ignored pixels, a border-heavy narrow case."""
+    import os
+
+    from cabinet_amd import functional as Fn
+
+    for B, C, Hl, Wl in [(2, 8, 8, 128), (1, 19, 4, 64), (1, 3, 2, 256)]:
+        H, W = 8 * Hl, 8 * Wl
+        g = torch.Generator().manual_seed(C + Wl)
+        la = (torch.randn(B, C, Hl, Wl, generator=g) * 2).cuda()
+        lb_ = (torch.randn(B, C, Hl, Wl, generator=g) * 2).cuda()
+        lab = torch.randint(0, C, (B, H, W), generator=g)
+        lab[torch.rand(B, H, W, generator=g) < 0.1] = 255
+        lab = lab.cuda()
+        loss_px, _ = Fn.ohem_up_pair_fwd_hip(la, lb_, lab, (H, W), 0.7, 255)
+        new = Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37)
+        os.environ["CABINET_OHEM_SEGMENT_KERNEL"] = "1"
+        try:
+            old = Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37)
+        finally:
+            del os.environ["CABINET_OHEM_SEGMENT_KERNEL"]
+        torch.cuda.synchronize()
+        assert_close(new, old, 2e-6, f"dlow {B}x{C}x{Hl}x{Wl}", atol=1e-9)
+        assert torch.equal(new, Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37))  # bit-reproducible
 
 
 def test_fused_ohem_is_deterministic_and_scales_with_upstream_grad():
