@@ -47,6 +47,12 @@ def _workspace(nbytes, device):
     return ws, nbytes
 
 
+def _aligned(t):
+    """A dense tensor of any dtype at a 16-byte aligned address (labels, internal slices such as ``loss_px[1]``)."""
+    t = t.contiguous()
+    return t.clone() if t.data_ptr() & 15 else t
+
+
 def _f32c(t):
     """Borrowed inputs must be dense fp32 and 16-byte aligned (the rules the C ABI documents): a contiguous VIEW that starts
     4 or 8 bytes into its allocation (``x[1:]``, ``x.flatten()[1:]``) is copied."""
@@ -391,6 +397,7 @@ def ohem_up_fwd_hip(logits_low, labels, size, thresh, ignore_lb):
     """Per-pixel CE of bilinear_upsample(logits_low -> size) vs labels, never materialising the upsample.
     Returns loss_px (B,H,W) and the three reduced statistics as ONE device tensor [n_valid, n_above, sum_above]."""
     lib = _lib.load()
+    logits_low, labels = _f32c(logits_low), _aligned(labels)
     B, C, Hl, Wl = logits_low.shape
     H, W = size
     dev = logits_low.device
@@ -408,6 +415,7 @@ def ohem_up_fwd_hip(logits_low, labels, size, thresh, ignore_lb):
 
 def ohem_up_bwd_hip(logits_low, labels, loss_px, size, thresh, ignore_lb, coef):
     lib = _lib.load()
+    logits_low, labels, loss_px = _f32c(logits_low), _aligned(labels), _f32c(loss_px)
     B, C, Hl, Wl = logits_low.shape
     H, W = size
     dev = logits_low.device
@@ -445,6 +453,7 @@ def ohem_up_pair_fwd_hip(low_a, low_b, labels, size, thresh, ignore_lb):
     """Both loss heads over the same labels in ONE launch (reference train.py:435 on the outputs of cabinet.py:240-245).
     Returns loss_px (2,B,H,W) and stats (2,3) = per head [n_valid, n_above, sum_above] as one device tensor."""
     lib = _lib.load()
+    low_a, low_b, labels = _f32c(low_a), _f32c(low_b), _aligned(labels)
     B, C, Hl, Wl = low_a.shape
     H, W = size
     dev = low_a.device
@@ -462,6 +471,7 @@ def ohem_up_pair_fwd_hip(low_a, low_b, labels, size, thresh, ignore_lb):
 
 def ohem_up_pair_bwd_hip(low_a, low_b, labels, loss_px, size, thresh, ignore_lb, coef):
     lib = _lib.load()
+    low_a, low_b, labels, loss_px = _f32c(low_a), _f32c(low_b), _aligned(labels), _f32c(loss_px)
     B, C, Hl, Wl = low_a.shape
     H, W = size
     dev = low_a.device
