@@ -21,6 +21,7 @@ struct GemmKArgs {
     const float* up_src;
     int Hl, Wl, W;
     float rh, rw;      // Hl / H, Wl / W
+    int wt_store;      // 1: output stored write-through (sc1) instead of non-temporal (set by gemm_kmajor from the environment)
 };
 
 // tails in M and P are masked; if K % 16 != 0 the A operand must hold align16(K) rows, the extra ones zero

@@ -70,6 +70,25 @@ __device__ __forceinline__ float bload(buf_rsrc r, int voff_bytes, int soff_byte
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
 }
 
+// ---- write-through ("sc1") stores for STREAMED outputs -------------------------------------------------------------------
+// A plain (or non-temporal) store leaves its line dirty in the XCD's 4 MB L2; a kernel that streams hundreds of MB of reads
+// through that L2 at the same time then pays the write-back of a dirty victim IN THE MISS PATH of its own loads.  Measured in
+// round 4 on the fused FFM backward (ffm_bwd_fused.hip): 228 us with plain stores of its 67 MB output, 188 us write-through.
+// sc1 stores do not keep the line (MI355X_MICROARCH.md, "stores of each flavour"); use them only for outputs the SAME kernel
+// never re-reads, 4 or 16 bytes per lane with whole 128-byte lines written per instruction.  It pays where loads are on a
+// short leash (an MFMA kernel whose next operand tile must arrive within one tile of arithmetic: the fused FFM backward, the
+// epilogue of gemm_kmajor: -6 us on the FFM forward); on pure streaming passes it measured nothing (BatchNorm apply, FFM gate,
+// the upsample adjoint's dz rows) or -2 % (BatchNorm backward dx): those keep plain stores.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
+}
+// row: wave-uniform base of a dense row; byte_off: this lane's 16-byte aligned offset into it (< 2 GB)
+__device__ __forceinline__ void store_wt4(float* row, int byte_off, f32x4 v) {
+    const buf_rsrc r = __builtin_amdgcn_make_buffer_rsrc(row, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 16);  // buffer_store_dwordx4 ... sc1
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Map the linear
 // block id to a tile index so that each XCD walks a CONTIGUOUS chunk of the tile list (bijective for
 // any total): tiles that share an operand panel then share one L2.  Speed only, never correctness.
@@ -99,6 +118,13 @@ static inline hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, lds_at
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess && tracked) mask.fetch_or(1ull << dev, std::memory_order_release);
     return e;
+}
+
+// host side: are streamed outputs stored write-through?  CABINET_WT_STREAM=0 restores plain stores (A/B timing)
+#include <stdlib.h>
+static inline int stream_wt() {
+    const char* e = getenv("CABINET_WT_STREAM");
+    return (e && e[0] == '0') ? 0 : 1;
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -18,6 +18,8 @@
 // contiguous (pixel or output-channel) index on the lane: G1/G2 are "K-major" products
 // (A_t[k][m], B[k][p]) that need no transposition at all; G3 contracts over pixels, so both
 // operands go through padded (stride 33) LDS images.
+#include <stdlib.h>
+
 #include "blocks.hpp"
 #include "common.hpp"
 
@@ -155,9 +157,14 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
                                              : a.dst1 + ((size_t)b * (M - a.M0) + (m - a.M0)) * P;
                     const int off = (i * 32 + acc_row(r)) * 32;  // compile-time: an immediate LDS offset
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        __builtin_nontemporal_store(acc[i][j][r] + ((1.f - lx[j]) * v0[j][off] + lx[j] * v1[j][off]),
-                                                    drow + p0 + wn * 64 + j * 32 + li);  // streamed: read back a kernel later
+                    for (int j = 0; j < 2; ++j) {
+                        const float val = acc[i][j][r] + ((1.f - lx[j]) * v0[j][off] + lx[j] * v1[j][off]);
+                        float* dptr = drow + p0 + wn * 64 + j * 32 + li;
+                        if (a.wt_store)
+                            store_wt(dptr, val);  // write-through: no dirty line in the way of the operand stream (common.hpp)
+                        else
+                            __builtin_nontemporal_store(val, dptr);
+                    }
                 }
             }
             return;  // INTERIOR: every row and column of the tile exists, nothing left to store
@@ -198,7 +205,12 @@ __global__ __launch_bounds__(512) void gemm_kmajor_kernel(GemmKArgs a) {
                 float val = acc[i][j][r];
                 if (UP == 2)
                     val += w00[j] * src[o00[j]] + w01[j] * src[o01[j]] + w10[j] * src[o10[j]] + w11[j] * src[o11[j]];
-                if (p < P) __builtin_nontemporal_store(val, drow + p);  // streamed output (2 % on the big products)
+                if (p < P) {
+                    if (a.wt_store)
+                        store_wt(drow + p, val);
+                    else
+                        __builtin_nontemporal_store(val, drow + p);
+                }
             }
         }
     }
@@ -226,7 +238,9 @@ static hipError_t launch_gemm_k_wm(const GemmKArgs& a, int B, bool interior, hip
     return interior ? launch_gemm_k<WM, true, 2>(a, B, stream) : launch_gemm_k<WM, false, 2>(a, B, stream);
 }
 
-hipError_t gemm_kmajor(const GemmKArgs& a, int B, hipStream_t stream) {
+hipError_t gemm_kmajor(const GemmKArgs& a_in, int B, hipStream_t stream) {
+    GemmKArgs a = a_in;
+    a.wt_store = stream_wt();
     int wm = a.M <= 128 ? 1 : (a.M > 256 && a.M <= 384) ? 3 : 2;
     if (wm > 1 && (a.M % 128) == 0 && ceil_div(a.P, GK_NT) * B * ceil_div(a.M, 128 * wm) < 200) wm = 1;  // small grid
     const bool interior = (a.P % GK_NT) == 0 && (a.M % (128 * wm)) == 0 && (a.lda % 4) == 0;
@@ -514,9 +528,14 @@ __global__ __launch_bounds__(256) void upsample_adjoint_kernel(const float* __re
 }
 
 // enough pixel-range splits that (output tiles x splits) covers the chip ~3x
+// NEVER more than 128: the workspace holds 128 slabs (bwd_layout, conv1x1's part).  Round 3 returned total_chunks itself
+// whenever it was below `want`, i.e. up to 383 slabs for a 128-column product (B*P/32 between 129 and 383 chunks, e.g.
+// 3 x 32 x 96 pixels): the slabs ran over the end of `part` into the low-resolution dz behind it -- found in round 4 by the
+// fused-vs-chain test (tests/test_gpu_ffm.py::test_ffm_bwd_fused_equals_chain); no BASELINE configuration is in that range.
 static int dw_nsplit(int total_chunks, int tiles) {
-    const int want = ceil_div(768, tiles);
-    return total_chunks < want ? total_chunks : (want < 128 ? want : 128);
+    int n = ceil_div(768, tiles);
+    if (n > total_chunks) n = total_chunks;
+    return n < 128 ? n : 128;
 }
 
 // =====================================================================================
@@ -1087,6 +1106,18 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
     return hipGetLastError();
 }
 
+// ffm_bwd_fused.hip: dfsp, dlow and dW from one staged dz tile (one persistent launch + an ordered slab sum)
+bool ffm_bwd_fused_supported(int B, int Cs, int Cc, int Co, int P, int Pl);
+size_t ffm_bwd_fused_slab_floats(int B, int Cs, int Cc, int P, int Pl);
+hipError_t ffm_bwd_fused_run(const float* dz, const float* dzl, const float* fsp, const float* low, const float* w, int B,
+                             int Cs, int Cc, int P, int Pl, float* dfsp, float* dlow, float* dw, float* slabs,
+                             hipStream_t stream);
+// CABINET_FFM_BWD_UNFUSED=1 keeps the round-3 chain of five launches (A/B timing; the tests run both forms)
+static bool ffm_bwd_fused_enabled() {
+    const char* e = getenv("CABINET_FFM_BWD_UNFUSED");
+    return !(e && e[0] == '1');
+}
+
 struct BwdWs {
     size_t sums, a1, a2, mdy, mdyx, dw1p, dw2p, dbnp, dz, part, dzl, total;
 };
@@ -1110,7 +1141,12 @@ static BwdWs bwd_layout(const FfmShape& s, int Hl, int Wl) {  // Hl == 0: plain 
     w.dbnp = take((size_t)s.B * 2 * s.Co * sizeof(float));
     w.dz = take((size_t)s.B * s.Co * P * sizeof(float));
     (void)total_chunks;
-    w.part = take((size_t)128 * s.Co * (s.Cs > s.Cc ? s.Cs : s.Cc) * sizeof(float));  // worst-case slabs of one dw_product
+    size_t part_floats = (size_t)128 * s.Co * (s.Cs > s.Cc ? s.Cs : s.Cc);  // worst-case slabs of one dw_product
+    if (Hl && ffm_bwd_fused_supported(s.B, s.Cs, s.Cc, s.Co, P, Hl * Wl)) {
+        const size_t f = ffm_bwd_fused_slab_floats(s.B, s.Cs, s.Cc, P, Hl * Wl);  // one dW tile per workgroup and segment
+        part_floats = f > part_floats ? f : part_floats;
+    }
+    w.part = take(part_floats * sizeof(float));
     w.dzl = take(Hl ? (size_t)s.B * s.Co * Hl * Wl * sizeof(float) : 0);
     w.total = off;
     return w;
@@ -1251,6 +1287,10 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
                                (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, R, plane, da);
         }
     }
+    if (fuse_dz && ffm_bwd_fused_enabled() && ffm_bwd_fused_supported(s.B, s.Cs, s.Cc, s.Co, P, Pl))
+        // dfsp = W_s^T dz, dlow = W_c^T dz_low, dW = [dz fsp^T | dz_low low^T]: both products of every dz tile from ONE
+        // staging of it, the low-resolution side as further segments of the same persistent launch
+        return ffm_bwd_fused_run(dz, dzl, fsp, low, w_blk, s.B, s.Cs, s.Cc, P, Pl, dfsp, dlow, dw_blk, part, stream);
     {   // dfsp = W_s^T dz
         GemmKArgs a{};
         a.at = w_blk, a.lda = Cin, a.M = s.Cs, a.K = s.Co;

@@ -120,8 +120,14 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         const int cs = u - s.unit_lo, b = cs / s.chunks_per_img, p0 = (cs - b * s.chunks_per_img) * XW_PX;
         const float* rp = red + ((size_t)(rbuf * 4 + ci) * 16) * 64 + lane;
         float* dp = s.dx + ((size_t)b * s.x_rows + s.x_c0 + 32 * ci + 4 * h) * s.P + p0 + xw_slot_to_px(li);
+        // WRITE-THROUGH stores (sc1: the line is not kept dirty in the XCD's L2).  With plain or non-temporal stores this
+        // kernel took 228 us instead of 188: every 128-byte row piece stays in L2 as a dirty line, and the streaming reads of dz
+        // and X (268 MB through a 4 MB L2) then pay a write-back on eviction IN THEIR OWN MISS PATH -- the loads of the next
+        // chunk came back later than one whole chunk of MFMAs (measured with the stand-alone probe: chunk loads served from
+        // cache 190 us, no dX stores 192 us, both as they are 241 us, sc1 stores 201 us; all + 13 us slab sum).
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp[(size_t)acc_row(r) * s.P] = dxa[r] + rp[r * 64];
+        for (int r = 0; r < 16; ++r)
+            store_wt(dp + (size_t)acc_row(r) * s.P, dxa[r] + rp[r * 64]);
     };
 
     int k_cur = seg_of(u_lo);
@@ -143,33 +149,47 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
-        // ---- dW += dz_chunk . X_chunk^T   (contraction over the 32 pixels: 16 k-steps, both operands 16 consecutive floats)
-        {
-            const float* zrow = dzs + ((size_t)buf * XW_CO + 32 * wave + li) * XW_PITCH + 16 * h;
-            float af[16];
+        // Eight blocks of 16 MFMAs per chunk: blocks 0-3 = dW column blocks j (operands: 16 consecutive floats of the wave's dz
+        // row and of X row 32 j + li), blocks 4-7 = quarters of the dX half-contraction (operand: one float per k-step from the
+        // dz rows, pixel slot on the lane).  The operands of block n + 1 are requested BEFORE the MFMAs of block n are issued
+        // and the order is pinned with scheduling barriers: left to itself the compiler emitted  read -> wait -> 2 MFMAs  for
+        // the dX part (every LDS round trip exposed, both waves of a SIMD stalling in lockstep) and the fused kernel was no
+        // faster than the five launches it replaces.
+        const float* zrow = dzs + ((size_t)buf * XW_CO + 32 * wave + li) * XW_PITCH + 16 * h;
+        const float* xrow = xs + ((size_t)buf * XW_CX + li) * XW_PITCH + 16 * h;
+        const float* zcol = dzs + ((size_t)buf * XW_CO + 128 * kh + h) * XW_PITCH + li;
+        float af[16], bf[2][16];
+        auto read16 = [&](const float* p, float* d) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(zrow + 4 * q);
-                af[4 * q] = t[0], af[4 * q + 1] = t[1], af[4 * q + 2] = t[2], af[4 * q + 3] = t[3];
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+                d[4 * q] = t[0], d[4 * q + 1] = t[1], d[4 * q + 2] = t[2], d[4 * q + 3] = t[3];
             }
+        };
+        auto read_col = [&](int blk, float* d) {   // k-steps 16 blk .. 16 blk + 15 of the dX contraction
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float* xrow = xs + ((size_t)buf * XW_CX + 32 * j + li) * XW_PITCH + 16 * h;
-                float bf[16];
+            for (int s = 0; s < 16; ++s) d[s] = zcol[(size_t)(2 * (16 * blk + s)) * XW_PITCH];
+        };
+        read16(zrow, af);
+        read16(xrow, bf[0]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(xrow + 4 * q);
-                    bf[4 * q] = t[0], bf[4 * q + 1] = t[1], bf[4 * q + 2] = t[2], bf[4 * q + 3] = t[3];
-                }
+        for (int j = 0; j < 4; ++j) {
+            if (j < 3)
+                read16(xrow + (size_t)32 * (j + 1) * XW_PITCH, bf[(j + 1) & 1]);
+            else
+                read_col(0, bf[0]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) dw[j] = mfma32(af[s], bf[s], dw[j]);
-            }
+            for (int s = 0; s < 16; ++s) dw[j] = mfma32(af[s], bf[j & 1][s], dw[j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- dX partial = W[half]^T . dz_chunk[half]   (contraction over 128 output channels: 64 k-steps)
-        {
-            const float* zcol = dzs + ((size_t)buf * XW_CO + 128 * kh + h) * XW_PITCH + li;
 #pragma unroll
-            for (int s = 0; s < 64; ++s) dxa = mfma32(wf[s], zcol[(size_t)(2 * s) * XW_PITCH], dxa);
+        for (int blk = 0; blk < 4; ++blk) {
+            if (blk < 3) read_col(blk + 1, bf[(blk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dxa = mfma32(wf[16 * blk + s], bf[blk & 1][s], dxa);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kh == 1) {   // upper contraction half: hand the partial tile to the lower half's wave
             float* rp = red + ((size_t)(buf * 4 + ci) * 16) * 64 + lane;

@@ -118,6 +118,7 @@ def test_ffm_vs_oracle(B, Cs, Cc, Co, Cm, H, W, training):
     (2, 64, 96, 96, 24, 16, 16, 16, 16, True),       # identity resize, generic channels
     (1, 128, 256, 256, 64, 8, 128, 2, 32, True),     # W = 128: one-output-row tiles (LDS row-lerp epilogue)
     (2, 128, 256, 256, 64, 4, 256, 1, 64, False),    # W = 256, Wl = 64, single source row
+    (3, 128, 256, 256, 64, 32, 96, 8, 24, True),     # three images, 6 low-resolution chunks per image (not a power of two)
 ])
 def test_ffm_upsampled_vs_oracle(B, Cs, Cc, Co, Cm, H, W, Hl, Wl, training):
     """Fused upsample + FFM (reference cabinet.py:228-230 + :236) vs oracle FFM on F.interpolate(low).
@@ -239,3 +240,37 @@ def test_ffm_up_fwd_split_bf16_vs_fp64(B):
     assert err[PREC_BF16X6] <= max(2 * err[PREC_FP32], 1e-6), err
     assert err[PREC_BF16X3] < 5e-5, err
     assert rel_err(outs[PREC_BF16X6], outs[PREC_FP32]) < 5e-6 and rel_err(outs[PREC_BF16X3], outs[PREC_FP32]) < 2e-4
+
+
+@pytest.mark.parametrize("B,H,W,Hl,Wl", [(4, 64, 64, 16, 16), (3, 32, 96, 8, 24), (1, 32, 32, 8, 8)])
+def test_ffm_bwd_fused_equals_chain(B, H, W, Hl, Wl):
+    """Round 4: dfsp, dlow and dW_blk from ONE persistent launch over staged dz tiles (ffm_bwd_fused.hip) against the
+    round-3 chain of five launches it replaces (gemm_kmajor, small-GEMM jobs, split-K dW products) -- same operator state,
+    workgroup runs that cross the full-resolution / low-resolution segment boundaries, B = 1 (fewer chunks than CUs)."""
+    import os
+
+    from cabinet_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(B * 1000 + H + W)
+    Cs, Cc, Co, Cm = 128, 256, 256, 64
+    fsp = torch.randn(B, Cs, H, W, generator=gen).cuda()
+    low = torch.randn(B, Cc, Hl, Wl, generator=gen).cuda()
+    wb = (torch.randn(Co, Cs + Cc, generator=gen) * 0.07).cuda()
+    w1 = (torch.randn(Cm, Co, generator=gen) * 0.1).cuda()
+    w2 = (torch.randn(Co, Cm, generator=gen) * 0.1).cuda()
+    g = torch.randn(B, Co, H, W, generator=gen).cuda()
+    bw, bb = torch.rand(Co, generator=gen).cuda() + 0.5, (torch.rand(Co, generator=gen).cuda() - 0.5)
+    rm, rv = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
+    out, z, mean, invstd, pooled, gate = Fn.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)
+    args = (g, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)
+    fused = Fn.ffm_up_bwd_hip(*args)
+    os.environ["CABINET_FFM_BWD_UNFUSED"] = "1"
+    try:
+        chain = Fn.ffm_up_bwd_hip(*args)
+    finally:
+        del os.environ["CABINET_FFM_BWD_UNFUSED"]
+    again = Fn.ffm_up_bwd_hip(*args)
+    torch.cuda.synchronize()
+    for name, a, b, c in zip(("dfsp", "dlow", "dw_blk", "dbn_w", "dbn_b", "dw1", "dw2"), fused, chain, again):
+        assert_close(a, b, 2e-6, name, atol=1e-9)
+        assert torch.equal(a, c), name  # bit-reproducible (ordered slab sum, no atomics)
