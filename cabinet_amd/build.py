@@ -68,6 +68,7 @@ def build(force=False, save_temps=False, verbose=True):
              "-Wall", "-Wno-unused-function"]
     if save_temps:
         flags.append("-save-temps=obj")
+    flags += os.environ.get("CABINET_EXTRA_HIPCC_FLAGS", "").split()  # dev aid: -D switches of A/B experiments
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
