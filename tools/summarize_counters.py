@@ -36,6 +36,12 @@ def main(root, out_path):
             waves = row.get("SQ_WAVES", 0.0)
             if row.get("GRBM_GUI_ACTIVE"):
                 row["mfma_busy_share"] = round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * 256 * row["GRBM_GUI_ACTIVE"] / 8.0), 4)
+            wc = row.get("SQ_WAVE_CYCLES", 0.0)
+            if wc:  # where a wave's lifetime goes (quad-cycle units cancel): issuing / stalled at issue / parked at a waitcnt or barrier
+                for c, name in (("SQ_ACTIVE_INST_ANY", "share_issuing"), ("SQ_WAIT_INST_ANY", "share_issue_stall"),
+                                ("SQ_WAIT_ANY", "share_waitcnt_or_barrier")):
+                    if c in row:
+                        row[name] = round(row[c] / wc, 4)
             if waves:
                 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
                     if c in row:
@@ -46,7 +52,7 @@ def main(root, out_path):
            "height": int(os.environ.get("CAB_H", os.environ.get("CAB_SIZE", "1024"))),
            "width": int(os.environ.get("CAB_W", os.environ.get("CAB_SIZE", "1024"))),
            "classes": int(os.environ.get("CAB_CLASSES", "8")),
-           "method": "rocprofv3 --pmc, three separate counter-only passes per kernel group over tools/run_kernels.py 4 <group> "
+           "method": "rocprofv3 --pmc, four separate counter-only passes per kernel group over tools/run_kernels.py 4 <group> "
                      "(tools/pmc_counters.sh); per-launch averages per kernel; kernels launched fewer than 4 times in a group's "
                      "run (operand set-up of earlier groups) are dropped",
            "groups": groups}
