@@ -240,7 +240,7 @@ def kernel_cases(batch, height, width=None, classes=8, extra=False):
     upb = lambda: Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
     fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
     by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))
-    yield ("ffm_up_bwd (K4': reduce, dz, dfsp GEMM, U^T dz, low-res GEMMs, dW)", upb, fl_b, by_b, "hbm")
+    yield ("ffm_up_bwd (K4': reduce, U^T dz with dz in flight, dfsp + dlow + dW from one staged dz tile, slab sum)", upb, fl_b, by_b, "hbm")
     del fsp, dout, o, z, low
     torch.cuda.empty_cache()
 
@@ -317,7 +317,7 @@ def kernel_cases(batch, height, width=None, classes=8, extra=False):
            lambda: Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255),
            2 * px * ncls * 12, px * (8 + 2 * 4) + 8.0 * lowl.numel(), "hbm")
     loss_px2 = Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255)[0]
-    yield ("ohem_up_pair_bwd (f3: both heads, x pass + y pass once)",
+    yield ("ohem_up_pair_bwd (f3: both heads; x pass = whole source rows per wave, resize adjoint in registers; y pass)",
            lambda: Fh.ohem_up_pair_bwd_hip(lowl, lowl2, lab, loss_px2, (H, W), 0.7, 255, 1e-6),
            2 * px * ncls * 16, px * (8 + 2 * 4) + 8.0 * lowl.numel() + 16.0 * B * ncls * H * w, "hbm")
     del lowl2, loss_px2
@@ -349,7 +349,11 @@ _NOTES = {
                     ": it replaces recomputing S and dP for dq (4.3 GFLOP)",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
     "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel), not HBM",
-    "ohem_up_pair_bwd": "what the step runs: both heads per launch; exp and VALU bound (softmax recomputed per pixel)",
+    "ohem_up_pair_bwd": "what the step runs: both heads per launch; x pass VALU bound (fma + sub + exp + 2 fma per pixel and "
+                        "class), y pass HBM bound (T written once, read once)",
+    "ffm_up_bwd": "bound by its two 8.6 GFLOP products on the 1/16-rate fp32 matrix pipe (109 us at peak) between two HBM passes "
+                  "(reduce; upsample adjoint computing dz in flight)",
+    "ffm_up_fwd": "z product (fp32 MFMA, write-through output stores) + three HBM passes over z that BatchNorm's batch statistics force",
     "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
     "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
     "bn_dwconv_bwd": "the depthwise stencil backward is VALU bound; the BatchNorm dx pass is HBM bound",
