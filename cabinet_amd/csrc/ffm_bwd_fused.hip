@@ -14,11 +14,11 @@
 //   * dX: wave w owns output channels 32 (w & 3) .. + 31 and HALF of the contraction (o in 128 (w >> 2) .. + 127); its A
 //     operand W[o][c] (64 values per lane) is loaded once per segment and stays in registers; the two halves are added
 //     through LDS one chunk later (double-buffered: no extra barrier).
-// Both operands of the pixel contraction need "row on the lane, pixel along the instruction's k": the staged rows are
-// stored DE-INTERLEAVED (even pixels, then odd pixels), so the 16 values a lane needs for the 16 k-steps of a chunk are 16
-// consecutive floats = four 16-byte LDS reads (row pitch 36 floats: conflict-free for ds_read_b128).  The dX product reads
-// the same rows with the pixel slot on the lane (consecutive words: conflict-free); its output columns are the slots, mapped
-// back to pixels in the store.
+// Both operands of the pixel contraction need "row on the lane, pixel along the instruction's k".  Which two pixels an MFMA
+// step contracts is free as long as A and B agree, so k-step s takes pixel s from the lanes 0-31 and pixel s + 16 from the
+// lanes 32-63: the 16 values a lane needs for the 16 k-steps of a chunk are then 16 CONSECUTIVE floats of its row in plain
+// pixel order = four 16-byte LDS reads (row pitch 36 floats: conflict-free for ds_read_b128), and the staged rows need no
+// re-ordering at all.  The dX product reads the same rows with the pixel on the lane (consecutive words: conflict-free).
 // Work is dealt in equal contiguous runs of chunks over <= 256 workgroups (one per CU); a workgroup writes its dW tile as
 // one slab per segment it touched, and an ordered slab sum finishes dW: no atomics, bit-reproducible.
 // Exact fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout.
@@ -48,13 +48,11 @@ struct XwArgs {
     float* slabs;      // [(workgroup + segment)][XW_CO][XW_CX] partial dW tiles
 };
 
-__device__ __forceinline__ int xw_slot_to_px(int slot) { return slot < 16 ? 2 * slot : 2 * (slot - 16) + 1; }
-
 __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzs = smem;                                   // [2][256][36]
     float* xs = dzs + 2 * XW_CO * XW_PITCH;              // [2][128][36]
-    float* red = xs + 2 * XW_CX * XW_PITCH;              // [2][4 waves][16 regs][64 lanes]
+    float* red = xs + 2 * XW_CX * XW_PITCH;              // [2][4 channel blocks][2 halves][8 regs][64 lanes] / [16 rows][32 px]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int ci = wave & 3, kh = wave >> 2;             // dX: channel block, contraction half
     const int u_lo = blockIdx.x * a.units_per_wg, u_hi = min(u_lo + a.units_per_wg, a.total_units);
@@ -63,32 +61,51 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
     // staging assignment: dz chunk = 256 rows x 32 px, two threads per row (16 px each); X chunk = 128 rows, four threads per row
     const int zr = tid >> 1, zh = tid & 1, xr = tid >> 2, xq = tid & 3;
     f32x4 rz[4], rx[2];
-    auto seg_of = [&](int u) {
+    // Where a unit (chunk) lives: wave-uniform base pointers of its image and segment + the pixel offset, advanced
+    // INCREMENTALLY from chunk to chunk.  The first version located every chunk from scratch -- a scalar-load loop over the
+    // segment table and an integer division, three times per iteration (next chunk's loads, previous chunk's stores, this
+    // chunk's segment): ~9 dependent scalar-memory round trips right behind the barrier, during which none of the eight waves
+    // issues an MFMA (the kernel ran at 0.65 MFMA busy where tools/mfma_probe2.hip shows 0.9 for the bare block structure).
+    struct UnitRef {
+        const float* z;   // dz rows of the unit's image, at the chunk's first pixel
+        const float* x;   // X rows (the segment's 128 channels) of the image, at the chunk's first pixel
+        float* dx;        // the same 128 channels of the output gradient
+        int P, k, left;   // row pitch; segment; chunks left in this image after this one
+    };
+    auto make_ref = [&](int u) {
         int k = 0;
         while (k + 1 < a.nseg && u >= a.seg[k + 1].unit_lo) ++k;
-        return k;
-    };
-    auto load_chunk = [&](int u) {
-        const int k = seg_of(u);
         const XwSeg& s = a.seg[k];
-        const int cs = u - s.unit_lo, b = cs / s.chunks_per_img, p0 = (cs - b * s.chunks_per_img) * XW_PX;
-        const float* zp = s.dz + ((size_t)b * XW_CO + zr) * s.P + p0 + zh * 16;
-        const float* xp = s.x + ((size_t)b * s.x_rows + s.x_c0 + xr) * s.P + p0 + xq * 8;
+        const int cs = u - s.unit_lo, b = cs / s.chunks_per_img, ci_ = cs - b * s.chunks_per_img, p0 = ci_ * XW_PX;
+        UnitRef r;
+        r.z = s.dz + (size_t)b * XW_CO * s.P + p0;
+        r.x = s.x + ((size_t)b * s.x_rows + s.x_c0) * s.P + p0;
+        r.dx = s.dx + ((size_t)b * s.x_rows + s.x_c0) * s.P + p0;
+        r.P = s.P, r.k = k, r.left = s.chunks_per_img - 1 - ci_;
+        return r;
+    };
+    auto advance = [&](UnitRef& r, int u_next) {   // r describes unit u_next - 1
+        if (r.left > 0) {
+            r.z += XW_PX, r.x += XW_PX, r.dx += XW_PX, r.left -= 1;
+        } else {
+            r = make_ref(u_next);   // next image or next segment: rare (once per >= 32 chunks)
+        }
+    };
+    auto load_chunk = [&](const UnitRef& r) {
+        const float* zp = r.z + (size_t)zr * r.P + zh * 16;
+        const float* xp = r.x + (size_t)xr * r.P + xq * 8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) rz[q] = *reinterpret_cast<const f32x4*>(zp + 4 * q);
 #pragma unroll
         for (int q = 0; q < 2; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp + 4 * q);
     };
-    auto store_chunk = [&](int buf) {
-        // de-interleave: pixel p of the row -> slot (p & 1) * 16 + (p >> 1)
-        float* zd = dzs + ((size_t)buf * XW_CO + zr) * XW_PITCH + zh * 8;
-        *reinterpret_cast<f32x4*>(zd) = f32x4{rz[0][0], rz[0][2], rz[1][0], rz[1][2]};
-        *reinterpret_cast<f32x4*>(zd + 4) = f32x4{rz[2][0], rz[2][2], rz[3][0], rz[3][2]};
-        *reinterpret_cast<f32x4*>(zd + 16) = f32x4{rz[0][1], rz[0][3], rz[1][1], rz[1][3]};
-        *reinterpret_cast<f32x4*>(zd + 20) = f32x4{rz[2][1], rz[2][3], rz[3][1], rz[3][3]};
-        float* xd = xs + ((size_t)buf * XW_CX + xr) * XW_PITCH + xq * 4;
-        *reinterpret_cast<f32x4*>(xd) = f32x4{rx[0][0], rx[0][2], rx[1][0], rx[1][2]};
-        *reinterpret_cast<f32x4*>(xd + 16) = f32x4{rx[0][1], rx[0][3], rx[1][1], rx[1][3]};
+    auto store_chunk = [&](int buf) {   // rows keep their pixel order (see the header: k-step s pairs pixels s and s + 16)
+        float* zd = dzs + ((size_t)buf * XW_CO + zr) * XW_PITCH + zh * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(zd + 4 * q) = rz[q];
+        float* xd = xs + ((size_t)buf * XW_CX + xr) * XW_PITCH + xq * 8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(xd + 4 * q) = rx[q];
     };
 
     f32x16 dw[4];      // dW tile rows 32 wave .. +31, columns 32 j .. +31
@@ -100,106 +117,134 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dw[j][r] = 0.f;
     };
+    // load_w / flush_dw run once per segment.  Their per-lane addresses are recomputed INSIDE them from a lane index made
+    // opaque by an empty asm: left visible, the compiler hoisted the 64-bit pointers out of the chunk loop as loop invariants,
+    // ran out of registers, spilled them, and put the scratch reloads -- each followed by s_waitcnt vmcnt(0), i.e. a wait for
+    // the chunk loads issued a few instructions earlier -- on the loop's common path.
     auto load_w = [&](int k) {
-        const float* wp = a.w + (size_t)(128 * kh + h) * a.ldw + a.seg[k].w_c0 + 32 * ci + li;
+        int ln = lane, wv = wave;
+        asm volatile("" : "+v"(ln), "+v"(wv));
+        const float* wp = a.w + (size_t)(128 * (wv >> 2) + (ln >> 5)) * a.ldw + a.seg[k].w_c0 + 32 * (wv & 3) + (ln & 31);
 #pragma unroll
         for (int s = 0; s < 64; ++s) wf[s] = wp[(size_t)(2 * s) * a.ldw];
     };
     auto flush_dw = [&](int k) {
-        float* slab = a.slabs + (size_t)(blockIdx.x + k) * XW_CO * XW_CX;
+        int ln = lane, wv = wave;
+        asm volatile("" : "+v"(ln), "+v"(wv));
+        float* slab = a.slabs + (size_t)(blockIdx.x + k) * XW_CO * XW_CX + (size_t)(32 * wv + 4 * (ln >> 5)) * XW_CX + (ln & 31);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                slab[(size_t)(32 * wave + acc_row(r) + 4 * h) * XW_CX + 32 * j + li] = dw[j][r];
+            for (int r = 0; r < 16; ++r) slab[(size_t)acc_row(r) * XW_CX + 32 * j] = dw[j][r];
     };
-    // finish the dX tile of a chunk: waves 0-3 add the upper half's partial (LDS) to their own and store the rows
-    auto store_dx = [&](int u, int rbuf) {
-        const int k = seg_of(u);
-        const XwSeg& s = a.seg[k];
-        const int cs = u - s.unit_lo, b = cs / s.chunks_per_img, p0 = (cs - b * s.chunks_per_img) * XW_PX;
-        const float* rp = red + ((size_t)(rbuf * 4 + ci) * 16) * 64 + lane;
-        float* dp = s.dx + ((size_t)b * s.x_rows + s.x_c0 + 32 * ci + 4 * h) * s.P + p0 + xw_slot_to_px(li);
-        // WRITE-THROUGH stores (sc1: the line is not kept dirty in the XCD's L2).  With plain or non-temporal stores this
-        // kernel took 228 us instead of 188: every 128-byte row piece stays in L2 as a dirty line, and the streaming reads of dz
-        // and X (268 MB through a 4 MB L2) then pay a write-back on eviction IN THEIR OWN MISS PATH -- the loads of the next
-        // chunk came back later than one whole chunk of MFMAs (measured with the stand-alone probe: chunk loads served from
-        // cache 190 us, no dX stores 192 us, both as they are 241 us, sc1 stores 201 us; all + 13 us slab sum).
+    // Finish the dX tile of a chunk (32 channels x 32 pixels, two contraction halves): the upper-half wave hands its partial
+    // tile to the lower-half wave of its pair through LDS at the end of the chunk (double-buffered: no extra barrier); the
+    // lower-half wave adds and stores the rows at the start of the next iteration.
+    // WRITE-THROUGH stores (sc1: the line is not kept dirty in the XCD's L2).  With plain or non-temporal stores this kernel
+    // took 228 us instead of 188: every row piece stays in L2 as a dirty line, and the streaming reads of dz and X (268 MB
+    // through a 4 MB L2) then pay a write-back on eviction IN THEIR OWN MISS PATH -- the loads of the next chunk came back
+    // later than one whole chunk of MFMAs (stand-alone probe: chunk loads served from cache 190 us, no dX stores 192 us,
+    // both as they are 241 us, sc1 stores 201 us; all + 13 us slab sum; profiles/r04_ffm_bwd_probe.txt).
+    // Buffer stores with a SCALAR row offset: one SALU multiply per row instead of 64-bit vector address arithmetic.
+    // (Measured and not kept: BOTH waves of a pair finalising half a tile each, the sums transposed through LDS so that the
+    // tile leaves as two 16-byte stores per wave: 217 us against 185 -- three dependent LDS round trips in all eight waves
+    // right behind the barrier, and 16-byte sc1 stores that touch eight rows each.)
+    auto hand_over = [&](int rbuf) {
+        if (kh == 1) {
+            float* rp = red + ((size_t)(rbuf * 4 + ci) * 16) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            store_wt(dp + (size_t)acc_row(r) * s.P, dxa[r] + rp[r * 64]);
+            for (int q = 0; q < 16; ++q) rp[q * 64] = dxa[q];
+        }
+    };
+    auto store_dx = [&](const UnitRef& r, int rbuf, bool valid) {
+        if (!valid || kh != 0) return;
+        const float* rp = red + ((size_t)(rbuf * 4 + ci) * 16) * 64 + lane;
+        const buf_rsrc rs = make_rsrc(r.dx, 0x7fffffffu);
+        const int voff = ((32 * ci + 4 * h) * r.P + li) * 4;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dxa[q] + rp[q * 64]), rs, voff, acc_row(q) * r.P * 4, 16);
     };
 
-    int k_cur = seg_of(u_lo);
+    UnitRef nxt = make_ref(u_lo), cur = nxt, prv = nxt;
+    int k_cur = cur.k;
     zero_dw();
     load_w(k_cur);
-    load_chunk(u_lo);
+    load_chunk(nxt);
     store_chunk(0);
     __syncthreads();
     for (int u = u_lo; u < u_hi; ++u) {
         const int buf = (u - u_lo) & 1;
-        if (u + 1 < u_hi) load_chunk(u + 1);
-        if (u > u_lo && kh == 0) store_dx(u - 1, buf ^ 1);   // the previous chunk's tile: its upper half landed before the barrier
-        const int k = seg_of(u);
-        if (k != k_cur) {   // wave-uniform: a new segment starts with this chunk
+        store_dx(prv, buf ^ 1, u > u_lo);   // the previous chunk's tile: both halves' hand-overs landed before the barrier
+        if (u + 1 < u_hi) {   // (behind the finalisation: its temporaries and the 24 staging registers are never live together)
+            advance(nxt, u + 1);
+            load_chunk(nxt);
+        }
+        if (cur.k != k_cur) {   // wave-uniform: a new segment starts with this chunk
             flush_dw(k_cur);
             zero_dw();
-            load_w(k);
-            k_cur = k;
+            load_w(cur.k);
+            k_cur = cur.k;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
-        // Eight blocks of 16 MFMAs per chunk: blocks 0-3 = dW column blocks j (operands: 16 consecutive floats of the wave's dz
-        // row and of X row 32 j + li), blocks 4-7 = quarters of the dX half-contraction (operand: one float per k-step from the
-        // dz rows, pixel slot on the lane).  The operands of block n + 1 are requested BEFORE the MFMAs of block n are issued
-        // and the order is pinned with scheduling barriers: left to itself the compiler emitted  read -> wait -> 2 MFMAs  for
-        // the dX part (every LDS round trip exposed, both waves of a SIMD stalling in lockstep) and the fused kernel was no
-        // faster than the five launches it replaces.
+        // Sixteen half-blocks of 8 MFMAs per chunk: half-blocks 0-7 = dW column block j = t / 2, k-steps 8 (t & 1) .. + 7
+        // (operands: 8 consecutive floats of the wave's dz row and of X row 32 j + li), half-blocks 8-15 = eighths of the dX
+        // half-contraction (operand: one float per k-step from the dz rows, pixel on the lane).  The operands of half-block
+        // t + 1 are requested BEFORE the MFMAs of t are issued and the order is pinned with scheduling barriers: left to itself
+        // the compiler emitted  read -> wait -> 2 MFMAs  for the dX part (every LDS round trip exposed, both waves of a SIMD
+        // stalling in lockstep).  Eight MFMAs = 512 cycles cover an LDS round trip; 16-deep blocks cost 16 more registers and
+        // spilled once the balanced dX finalisation was in.
         const float* zrow = dzs + ((size_t)buf * XW_CO + 32 * wave + li) * XW_PITCH + 16 * h;
         const float* xrow = xs + ((size_t)buf * XW_CX + li) * XW_PITCH + 16 * h;
         const float* zcol = dzs + ((size_t)buf * XW_CO + 128 * kh + h) * XW_PITCH + li;
-        float af[16], bf[2][16];
-        auto read16 = [&](const float* p, float* d) {
+        float af[8], bf[2][8];
+        auto read8 = [&](const float* p, float* d) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2; ++q) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
                 d[4 * q] = t[0], d[4 * q + 1] = t[1], d[4 * q + 2] = t[2], d[4 * q + 3] = t[3];
             }
         };
-        auto read_col = [&](int blk, float* d) {   // k-steps 16 blk .. 16 blk + 15 of the dX contraction
+        auto read_col = [&](int e, float* d) {   // k-steps 8 e .. 8 e + 7 of the dX contraction
 #pragma unroll
-            for (int s = 0; s < 16; ++s) d[s] = zcol[(size_t)(2 * (16 * blk + s)) * XW_PITCH];
+            for (int s = 0; s < 8; ++s) d[s] = zcol[(size_t)(2 * (8 * e + s)) * XW_PITCH];
         };
-        read16(zrow, af);
-        read16(xrow, bf[0]);
+        // half-block t of dW: pixel half hf = t >> 2 (k-steps 8 hf .. + 7), column block j = t & 3.  Only ONE half of the wave's
+        // dz row (8 registers) is resident: the second half is read once the MFMAs of t = 3 are issued (one exposed LDS round
+        // trip per chunk) -- with both halves resident the kernel needed 8 registers more than the 256 a wave has at two per
+        // SIMD, and a scratch reload in the loop makes the compiler wait for vmcnt(0), i.e. for the chunk loads just issued.
+        read8(zrow, af);
+        read8(xrow, bf[0]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < 3)
-                read16(xrow + (size_t)32 * (j + 1) * XW_PITCH, bf[(j + 1) & 1]);
+        for (int t = 0; t < 8; ++t) {
+            const int j = t & 3;
+            if (t < 7)
+                read8(xrow + (size_t)32 * ((t + 1) & 3) * XW_PITCH + 8 * ((t + 1) >> 2), bf[(t + 1) & 1]);
             else
                 read_col(0, bf[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) dw[j] = mfma32(af[s], bf[j & 1][s], dw[j]);
+            for (int s = 0; s < 8; ++s) dw[j] = mfma32(af[s], bf[t & 1][s], dw[j]);
             __builtin_amdgcn_sched_barrier(0);
+            if (t == 3) read8(zrow + 8, af);
         }
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            if (blk < 3) read_col(blk + 1, bf[(blk + 1) & 1]);
+        for (int e = 0; e < 8; ++e) {
+            if (e < 7) read_col(e + 1, bf[(e + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 16; ++s) dxa = mfma32(wf[16 * blk + s], bf[blk & 1][s], dxa);
+            for (int s = 0; s < 8; ++s) dxa = mfma32(wf[8 * e + s], bf[e & 1][s], dxa);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kh == 1) {   // upper contraction half: hand the partial tile to the lower half's wave
-            float* rp = red + ((size_t)(buf * 4 + ci) * 16) * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rp[r * 64] = dxa[r];
-        }
+        hand_over(buf);
+        // (staging the next chunk here, at the end, or between the two products -- its 16-byte LDS writes draining under the
+        // dX MFMAs -- measured the same: 183 against 185 us)
         if (u + 1 < u_hi) store_chunk(buf ^ 1);
         __syncthreads();
+        prv = cur, cur = nxt;
     }
-    if (kh == 0) store_dx(u_hi - 1, (u_hi - 1 - u_lo) & 1);
+    store_dx(prv, (u_hi - 1 - u_lo) & 1, true);
     flush_dw(k_cur);
 }
 
@@ -211,6 +256,8 @@ struct XwSumArgs {
     int col_off[XW_MAXSEG], wg_lo[XW_MAXSEG], wg_hi[XW_MAXSEG];
 };
 __global__ __launch_bounds__(256) void ffm_bwd_xw_sum_kernel(XwSumArgs a) {
+    // one element per thread, eight slabs in flight, ascending order in eight interleaved partial sums (a fixed association).
+    // (Four elements per thread with 16-byte loads left 96 workgroups for 34 MB: 33 us against 13.5 -- reverted.)
     const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;   // i over XW_CO * XW_CX
     if (k >= a.nseg || i >= XW_CO * XW_CX) return;
     const size_t stride = (size_t)XW_CO * XW_CX;

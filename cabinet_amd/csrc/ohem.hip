@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x8row_kernel(OhemBwdHeads hd,
     constexpr int Wl = 64 * IPL, W = 8 * Wl;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* v = smem;                 // [C][Wl]  vertically interpolated logits of this output row, exp2 domain
-    float* lse = v + C * Wl;         // [W]      per pixel: loss log2 e + x_label, +inf when the pixel is not selected
+    float* lse = v + C * Wl;         // [2 IPL][64][4]  per pixel: loss log2 e + x_label, +inf when the pixel is not selected
     float* ohL = lse + W;            // [C][Wl]  one-hot part of L / M / R (sums of tap weights of the selected pixels of class c)
     float* ohM = ohL + C * Wl;
     float* ohR = ohM + C * Wl;
@@ -523,9 +523,11 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x8row_kernel(OhemBwdHeads hd,
                 }
             }
         }
-        f32x4* lp4 = reinterpret_cast<f32x4*>(lse + 8 * g);
-        lp4[0] = f32x4{out[0], out[1], out[2], out[3]};
-        lp4[1] = f32x4{out[4], out[5], out[6], out[7]};
+        // stored per (quarter of a lane's pixels, lane): the class phase reads its 8 IPL values as 2 IPL 16-byte loads with a
+        // lane stride of 16 bytes (conflict-free; [pixel]-major rows made that a 4-way conflict at IPL = 2)
+        const int gl = g / IPL, gu = g - gl * IPL;
+        *reinterpret_cast<f32x4*>(lse + ((2 * gu) * 64 + gl) * 4) = f32x4{out[0], out[1], out[2], out[3]};
+        *reinterpret_cast<f32x4*>(lse + ((2 * gu + 1) * 64 + gl) * 4) = f32x4{out[4], out[5], out[6], out[7]};
     }
     __syncthreads();
     // ---- phase 2: a wave per class row, a lane per IPL consecutive intervals
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x8row_kernel(OhemBwdHeads hd,
     float lr[8 * IPL];
 #pragma unroll
     for (int u = 0; u < 2 * IPL; ++u) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(lse + 8 * g0 + 4 * u);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(lse + (u * 64 + lane) * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) lr[4 * u + e] = t[e];
     }
