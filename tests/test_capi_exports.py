@@ -72,6 +72,15 @@ def test_workspace_queries_and_argument_errors_need_no_gpu(lib_path):
     assert rc == -1 and b"null" in lib.cabinet_last_error()
     rc = lib.cabinet_cab_attn_fwd(None, None, None, 1.0, 1, 48, 128, 16, 0, None, None, None, 0, None)
     assert rc == -2 and b"instantiation" in lib.cabinet_last_error()
+    # 16-byte alignment contract of the attention / OHEM entry points (128-bit loads and stores): a pointer 4 bytes into an
+    # allocation is an invalid argument, not a fault -- checked before any HIP call (the addresses below are never touched)
+    A, M = 0x10000, 0x10004
+    rc = lib.cabinet_cab_attn_fwd(A, A, M, 1.0, 1, 128, 128, 16, 0, A, A, None, 0, None)
+    assert rc == -1 and b"16-byte aligned" in lib.cabinet_last_error()
+    rc = lib.cabinet_cab_attn_bwd(A, A, A, A, A, A, 1.0, 1, 128, 128, 16, A, M, A, None, 0, None)
+    assert rc == -1 and b"16-byte aligned" in lib.cabinet_last_error()
+    rc = lib.cabinet_ohem_up_pair_fwd(A, A, A, 1, 8, 4, 4, 32, 32, 0.7, 255, M, A, A, None)
+    assert rc == -1 and b"16-byte aligned" in lib.cabinet_last_error()
     rc = lib.cabinet_ffm_fwd(*([None] * 9), 1, 100, 256, 256, 64, 8, 8, 1, 0.1, 1e-5, *([None] * 6), None, 0, None)
     assert rc == -2
     with pytest.raises(RuntimeError, match="code -2"):
