@@ -101,4 +101,10 @@ inline SdJob sd_make(const float* a, int a_rows, const float* x, int x_rows, int
 // true when a product over P positions per image is too small to fill the chip with the 128-wide tiles of gemm_kmajor
 inline bool small_grid(int B, int M, int P) { return (long long)((P + 127) / 128) * B * ((M + 127) / 128) < 400; }
 
+// What turns (dout, z) into dz inside ffm_bwd_fused.hip (ffm.hip::ffm_dz_kernel has the expression): the incoming gradient,
+// the saved BatchNorm statistics and affine, the batch means of dy and dy xhat, and a1, a2 per (image, channel).
+struct XwDzCoef {
+    const float *g, *mean, *invstd, *bn_w, *bn_b, *mean_dy, *mean_dyx, *coef_a1, *coef_a2;
+};
+
 }  // namespace cabinet

@@ -674,9 +674,28 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__
         if (b == 0 && threadIdx.x == 0) fin.save_mean[c] = mu, fin.save_invstd[c] = inv;
     } else {
         double s1 = 0.0, s2 = 0.0;
-        for (int bb = 0; bb < fin.B; ++bb) {
-            s1 += fin.stat_part[(size_t)c * fin.B + bb];
-            s2 += fin.stat_part[((size_t)C + c) * fin.B + bb];
+        if (fin.B <= 16) {   // one partial per image: every thread sums them itself
+            for (int bb = 0; bb < fin.B; ++bb) {
+                s1 += fin.stat_part[(size_t)c * fin.B + bb];
+                s2 += fin.stat_part[((size_t)C + c) * fin.B + bb];
+            }
+        } else {   // one partial per workgroup of the fused forward: a fixed-order tree over the 256 threads
+            __shared__ double s_d[2][256];
+            double p1 = 0.0, p2 = 0.0;
+            for (int bb = threadIdx.x; bb < fin.B; bb += 256) {
+                p1 += fin.stat_part[(size_t)c * fin.B + bb];
+                p2 += fin.stat_part[((size_t)C + c) * fin.B + bb];
+            }
+            s_d[0][threadIdx.x] = p1, s_d[1][threadIdx.x] = p2;
+            __syncthreads();
+            for (int o = 128; o >= 1; o >>= 1) {
+                if ((int)threadIdx.x < o) {
+                    s_d[0][threadIdx.x] += s_d[0][threadIdx.x + o];
+                    s_d[1][threadIdx.x] += s_d[1][threadIdx.x + o];
+                }
+                __syncthreads();
+            }
+            s1 = s_d[0][0], s2 = s_d[1][0];
         }
         const double mean = s1 / (double)fin.count;
         double var = s2 / (double)fin.count - mean * mean;
@@ -1002,8 +1021,20 @@ __global__ __launch_bounds__(256) void ffm_dz_kernel(const float* __restrict__ g
 // bilinearly sampled, in the epilogue of the Cs-channel GEMM; in backward dlow = W_c^T . U^T(dz) and
 // dW_c = U^T(dz) . low^T, again at low resolution.  GEMM FLOPs drop from 3 x 2*B*P*Cin*Co to
 // 3 x 2*B*P*Cs*Co + 3 x 2*B*Pl*Cc*Co  (25.8 -> 9.7 GFLOP per product at config 3).
+// ffm_fwd_fused.hip: z = W_s fsp + U(y_low) as a persistent kernel with the BatchNorm sums in its epilogue
+bool ffm_fwd_fused_supported(int B, int Cs, int Co, int H, int W, int Hl, int Wl);
+int ffm_fwd_fused_nwg(int B, int P);
+hipError_t ffm_fwd_fused_run(const float* fsp, const float* w, int ldw, const float* ylow, int B, int H, int W, int Hl, int Wl,
+                             float* z, double* stat_part, hipStream_t stream);
+// CABINET_FFM_FWD_UNFUSED=1 keeps round 3's gemm_kmajor + bn_rowstats pair (A/B timing; the tests run both forms)
+static bool ffm_fwd_fused_enabled() {
+    const char* e = getenv("CABINET_FFM_FWD_UNFUSED");
+    return !(e && e[0] == '1');
+}
+
 static size_t wt_bytes(const FfmShape& s) { return align_up((size_t)(s.Cs + s.Cc) * s.Co * sizeof(float), 256); }
-static size_t stat_bytes(const FfmShape& s) { return align_up((size_t)s.B * 2 * s.Co * sizeof(double), 256); }
+// BatchNorm partial sums [2][Co][n]: one per image (bn_rowstats) or one per workgroup of the fused forward (<= 256)
+static size_t stat_bytes(const FfmShape& s) { return align_up((size_t)(s.B > 256 ? s.B : 256) * 2 * s.Co * sizeof(double), 256); }
 static size_t low_bytes(const FfmShape& s, int Hl, int Wl) {
     return align_up((size_t)s.B * s.Co * Hl * Wl * sizeof(float), 256);
 }
@@ -1023,11 +1054,13 @@ size_t ffm_up_fwd_workspace(const FfmShape& s, int Hl, int Wl) {
 static void ffm_fwd_tail(const FfmShape& s, double* stat_part, const float* bn_w, const float* bn_b,
                          float* run_mean, float* run_var, const float* w1, const float* w2, int training,
                          float momentum, float eps, float* out, const float* z, float* save_mean,
-                         float* save_invstd, float* pooled, float* gate, hipStream_t stream) {
+                         float* save_invstd, float* pooled, float* gate, hipStream_t stream, int nparts = 0) {
+    // nparts > 0: the producer of z already left nparts (sum, sum of squares) pairs per channel in stat_part (fused forward)
     const int P = s.H * s.W;
-    if (training)
+    if (training && nparts == 0)
         hipLaunchKernelGGL(bn_rowstats_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, stat_part, s.B, s.Co, P);
-    const BnFin fin{stat_part, s.B, training, (long long)s.B * P, momentum, eps, run_mean, run_var, save_mean, save_invstd};
+    const BnFin fin{stat_part, nparts > 0 ? nparts : s.B, training, (long long)s.B * P, momentum, eps, run_mean, run_var,
+                    save_mean, save_invstd};
     hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, fin, bn_w, bn_b, pooled, s.Co, P);
     hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(SE_T), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
                        w2, gate, s.Co, s.Cm);
@@ -1069,9 +1102,14 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
     double* stat_part = reinterpret_cast<double*>(base + wt_bytes(s));
     float* ylow = reinterpret_cast<float*>(base + wt_bytes(s) + stat_bytes(s));
     void* wpack = base + wt_bytes(s) + stat_bytes(s) + low_bytes(s, Hl, Wl);
-    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
-                       s.Co, Cin);
-    if (small_grid(s.B, s.Co, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0) {
+    const bool small_low = small_grid(s.B, s.Co, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0;
+    // the persistent form of the big product (fp32; ffm_fwd_fused.hip) reads W as stored and leaves the BatchNorm partial sums
+    const bool fused_z = precision == 0 && ffm_fwd_fused_enabled() && (Cin % 4) == 0 &&
+                         ffm_fwd_fused_supported(s.B, s.Cs, s.Co, s.H, s.W, Hl, Wl);
+    if (!(small_low && fused_z))   // W_blk (Co x Cin) -> Wt (Cin x Co): the K-major A operand of gemm_kmajor
+        hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(Cin, 32), ceil_div(s.Co, 32)), dim3(32, 8), 0, stream, w_blk, wt,
+                           s.Co, Cin);
+    if (small_low) {
         // y_low = W_c . low at (Hl x Wl): a few thousand positions -> 64x64 tiles, the weight read as stored
         SgJobs jobs{};
         jobs.n = 1;
@@ -1084,6 +1122,15 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
         a.dst0 = ylow, a.dst1 = ylow, a.M0 = s.Co;
         a.P = Pl;
         if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
+    }
+    if (fused_z) {
+        // z = W_s . fsp + U(y_low) and the per-channel sums of z in one persistent launch
+        if (hipError_t e = ffm_fwd_fused_run(fsp, w_blk, Cin, ylow, s.B, s.H, s.W, Hl, Wl, z, training ? stat_part : nullptr, stream);
+            e != hipSuccess)
+            return e;
+        ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
+                     save_invstd, pooled, gate, stream, ffm_fwd_fused_nwg(s.B, P));
+        return hipGetLastError();
     }
     if (precision != 0 && gemm_bf16_supported(s.Co, s.Cs, P, s.W, Wl, true)) {
         // z = W_s . fsp + U(y_low) on the bf16 matrix pipe (operands split into bf16 pieces, gemm_bf16.hip)
@@ -1111,8 +1158,21 @@ bool ffm_bwd_fused_supported(int B, int Cs, int Cc, int Co, int P, int Pl);
 size_t ffm_bwd_fused_slab_floats(int B, int Cs, int Cc, int P, int Pl);
 hipError_t ffm_bwd_fused_run(const float* dz, const float* dzl, const float* fsp, const float* low, const float* w, int B,
                              int Cs, int Cc, int P, int Pl, float* dfsp, float* dlow, float* dw, float* slabs,
-                             hipStream_t stream);
+                             hipStream_t stream, const XwDzCoef* dz_coef);
 // CABINET_FFM_BWD_UNFUSED=1 keeps the round-3 chain of five launches (A/B timing; the tests run both forms)
+// ffm_bwd_adj.hip: U^T of three coefficient-free fields inside the reduction pass, dz_low from them (no second pass over dout, z)
+bool ffm_bwd_adj_supported(int H, int W, int Hl, int Wl);
+hipError_t ffm_bwd_reduce_adj_run(const float* g, const float* z, const float* mean, const float* invstd, const float* bn_w,
+                                  const float* bn_b, float* sums, float* t, int planes, int C, int H, int Hl, int Wl,
+                                  hipStream_t stream);
+hipError_t ffm_bwd_dzl_run(const float* t, const float* invstd, const float* bn_w, const float* a1, const float* a2,
+                           const float* mdy, const float* mdyx, float* dzl, int planes, int C, int H, int W, int Hl, int Wl,
+                           hipStream_t stream);
+// CABINET_FFM_BWD_TWO_PASS=1 keeps the second pass over dout and z (upsample_adjoint_kernel<true>; A/B timing, tests run both)
+static bool ffm_bwd_adj_enabled() {
+    const char* e = getenv("CABINET_FFM_BWD_TWO_PASS");
+    return !(e && e[0] == '1');
+}
 static bool ffm_bwd_fused_enabled() {
     const char* e = getenv("CABINET_FFM_BWD_UNFUSED");
     return !(e && e[0] == '1');
@@ -1156,10 +1216,11 @@ size_t ffm_bwd_workspace(const FfmShape& s) { return bwd_layout(s, 0, 0).total; 
 size_t ffm_up_bwd_workspace(const FfmShape& s, int Hl, int Wl) { return bwd_layout(s, Hl, Wl).total; }
 
 // dout -> dz (and the small gradients dw1, dw2, dbn_w, dbn_b): shared by both forms
-static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const float* dout, const float* z,
+static hipError_t ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const float* dout, const float* z,
                          const float* save_mean, const float* save_invstd, const float* bn_w, const float* bn_b,
                          const float* w1, const float* w2, const float* pooled, const float* gate, int training,
-                         float* dbn_w, float* dbn_b, float* dw1, float* dw2, hipStream_t stream, bool dz_pass = true) {
+                         float* dbn_w, float* dbn_b, float* dw1, float* dw2, hipStream_t stream, bool dz_pass = true,
+                         int adj_Hl = 0, int adj_Wl = 0) {   // adj_Hl > 0: the adjoint fields ride on the reduction pass
     const int P = s.H * s.W;
     float* sums = reinterpret_cast<float*>(base + L.sums);
     float* a1 = reinterpret_cast<float*>(base + L.a1);
@@ -1170,17 +1231,31 @@ static void ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, const fl
     float* dw1p = reinterpret_cast<float*>(base + L.dw1p);
     float* dw2p = reinterpret_cast<float*>(base + L.dw2p);
     float* dbnp = reinterpret_cast<float*>(base + L.dbnp);
-    hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
-                       bn_w, bn_b, sums, s.Co, P);
+    // T1..T3 (3 x B Co Hl Wl floats) borrow the head of the dz buffer: read by ffm_bwd_dzl before anything writes dz
+    if (adj_Hl > 0) {
+        if (hipError_t e = ffm_bwd_reduce_adj_run(dout, z, save_mean, save_invstd, bn_w, bn_b, sums, dz, s.B * s.Co, s.Co, s.H,
+                                                  adj_Hl, adj_Wl, stream);
+            e != hipSuccess)
+            return e;
+    } else
+        hipLaunchKernelGGL(ffm_bwd_reduce_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
+                           bn_w, bn_b, sums, s.Co, P);
     hipLaunchKernelGGL(ffm_bwd_image_kernel, dim3(s.B), dim3(SE_T),
                        (size_t)(3 * s.Co + 2 * s.Cm + SE_W * (s.Co > s.Cm ? s.Co : s.Cm)) * sizeof(float), stream, sums,
                        pooled, gate, w1, w2, s.Co, s.Cm, P, dw1p, dw2p, dbnp, a1, a2);
     hipLaunchKernelGGL(ffm_bwd_combine_kernel, dim3(ceil_div(s.Co * s.Cm, 256)), dim3(256), 0, stream, dw1p, dw2p, dbnp,
                        s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, mdy, mdyx);
-    if (!dz_pass) return;  // the fused-upsample form computes dz inside the upsample-adjoint kernel
+    if (adj_Hl > 0) {
+        if (hipError_t e = ffm_bwd_dzl_run(dz, save_invstd, bn_w, a1, a2, mdy, mdyx, reinterpret_cast<float*>(base + L.dzl),
+                                           s.B * s.Co, s.Co, s.H, s.W, adj_Hl, adj_Wl, stream);
+            e != hipSuccess)
+            return e;
+    }
+    if (!dz_pass) return hipGetLastError();  // the fused-upsample forms compute dz inside the upsample-adjoint kernel / while staging it
     const int cpr = ceil_div(P, 4096);
     hipLaunchKernelGGL(ffm_dz_kernel, dim3(s.B * s.Co * cpr), dim3(256), 0, stream, dout, z, save_mean, save_invstd,
                        bn_w, bn_b, a1, a2, mdy, mdyx, dz, s.Co, P, cpr);
+    return hipGetLastError();
 }
 
 size_t dw_part_floats(int B, int Co, int Cx, int P) {
@@ -1222,8 +1297,10 @@ hipError_t ffm_bwd_run(const FfmShape& s, const float* dout, const float* fsp, c
     char* base = static_cast<char*>(ws);
     float* dz = reinterpret_cast<float*>(base + L.dz);
     float* part = reinterpret_cast<float*>(base + L.part);
-    ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training, dbn_w, dbn_b,
-                 dw1, dw2, stream);
+    if (hipError_t e = ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training,
+                                    dbn_w, dbn_b, dw1, dw2, stream);
+        e != hipSuccess)
+        return e;
     // G2: dX[c][p] = sum_o W[o][c] dz[o][p]   (A_t = W_blk as stored: [o][c], c contiguous)
     GemmKArgs a{};
     a.at = w_blk, a.lda = Cin, a.M = Cin, a.K = s.Co;
@@ -1252,10 +1329,16 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
     // the band decomposition must cover every output row exactly once and fit the staging buffer
     const int max_rows = (int)((ADJ_BAND + 2) * ((float)s.H / (float)Hl)) + 6, XT = adj_xtaps(s.W, Wl);
     const bool fuse_dz = s.H >= Hl;  // an upsample (the model's x4); shrinking resizes keep the two-pass form
-    ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training, dbn_w, dbn_b,
-                 dw1, dw2, stream, !fuse_dz);
+    const bool lin_adj = fuse_dz && ffm_bwd_adj_enabled() && ffm_bwd_adj_supported(s.H, s.W, Hl, Wl);
+    const bool fused_xw = fuse_dz && ffm_bwd_fused_enabled() && ffm_bwd_fused_supported(s.B, s.Cs, s.Cc, s.Co, P, Pl);
+    const bool dz_in_xw = lin_adj && fused_xw;   // nothing but the fused kernel reads dz: it forms it from (dout, z) itself
+    // lin_adj: dz_low from adjoint fields taken in the reduction pass (ffm_bwd_adj.hip)
+    if (hipError_t e = ffm_bwd_head(s, L, base, dout, z, save_mean, save_invstd, bn_w, bn_b, w1, w2, pooled, gate, training,
+                                    dbn_w, dbn_b, dw1, dw2, stream, lin_adj ? !dz_in_xw : !fuse_dz, lin_adj ? Hl : 0, lin_adj ? Wl : 0);
+        e != hipSuccess)
+        return e;
     // dz_low = U^T dz  (adjoint of the bilinear upsample), then everything on the Cc side is low resolution
-    {
+    if (!lin_adj) {
         // de-interleave factor of the horizontal pass: the integer resize ratio (the model's x4), else 1 (plain layout)
         const int R = (Wl > 0 && s.W % Wl == 0 && s.W / Wl <= 32) ? s.W / Wl : 1;
         int plane = ceil_div(s.W, R);
@@ -1287,10 +1370,16 @@ hipError_t ffm_up_bwd_run(const FfmShape& s, int Hl, int Wl, const float* dout, 
                                (float)Hl / (float)s.H, (float)Wl / (float)s.W, max_rows, XT, R, plane, da);
         }
     }
-    if (fuse_dz && ffm_bwd_fused_enabled() && ffm_bwd_fused_supported(s.B, s.Cs, s.Cc, s.Co, P, Pl))
+    if (fused_xw) {
         // dfsp = W_s^T dz, dlow = W_c^T dz_low, dW = [dz fsp^T | dz_low low^T]: both products of every dz tile from ONE
         // staging of it, the low-resolution side as further segments of the same persistent launch
-        return ffm_bwd_fused_run(dz, dzl, fsp, low, w_blk, s.B, s.Cs, s.Cc, P, Pl, dfsp, dlow, dw_blk, part, stream);
+        XwDzCoef dc{};
+        dc.g = dout, dc.mean = save_mean, dc.invstd = save_invstd, dc.bn_w = bn_w, dc.bn_b = bn_b;
+        dc.coef_a1 = reinterpret_cast<float*>(base + L.a1), dc.coef_a2 = reinterpret_cast<float*>(base + L.a2);
+        dc.mean_dy = reinterpret_cast<float*>(base + L.mdy), dc.mean_dyx = reinterpret_cast<float*>(base + L.mdyx);
+        return ffm_bwd_fused_run(dz_in_xw ? z : dz, dzl, fsp, low, w_blk, s.B, s.Cs, s.Cc, P, Pl, dfsp, dlow, dw_blk, part, stream,
+                                 dz_in_xw ? &dc : nullptr);
+    }
     {   // dfsp = W_s^T dz
         GemmKArgs a{};
         a.at = w_blk, a.lda = Cin, a.M = s.Cs, a.K = s.Co;

@@ -34,7 +34,8 @@ constexpr int XW_PITCH = 36;   // LDS row pitch in floats (32 + 4: 16-byte align
 constexpr int XW_MAXSEG = 4;
 
 struct XwSeg {
-    const float* dz;   // (B, XW_CO, P)
+    const float* dz;   // (B, XW_CO, P): dz -- or, when g is set, z: dz is then formed from (g, z) while the chunk is staged
+    const float* g;    // (B, XW_CO, P) the operator's incoming gradient dout, or null
     const float* x;    // (B, x_rows, P): channels [x_c0, x_c0 + 128) are this segment's
     float* dx;         // (B, x_rows, P): gradient of the same channels
     int P, x_rows, x_c0, w_c0;
@@ -46,6 +47,9 @@ struct XwArgs {
     const float* w;    // (XW_CO, ldw) row-major weight
     int ldw;
     float* slabs;      // [(workgroup + segment)][XW_CO][XW_CX] partial dW tiles
+    // BatchNorm backward coefficients of a segment with g set (ffm.hip::ffm_dz_kernel has the formula): per channel ...
+    const float *mean, *invstd, *bn_w, *bn_b, *mean_dy, *mean_dyx;
+    const float *coef_a1, *coef_a2;   // ... and per (image, channel)
 };
 
 __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
@@ -53,6 +57,7 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
     float* dzs = smem;                                   // [2][256][36]
     float* xs = dzs + 2 * XW_CO * XW_PITCH;              // [2][128][36]
     float* red = xs + 2 * XW_CX * XW_PITCH;              // [2][4 channel blocks][2 halves][8 regs][64 lanes] / [16 rows][32 px]
+    float* coef = red + 2 * 4 * 16 * 64;                 // [256 channels][8]: mean invstd gamma beta gi mdy mdyx -
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int ci = wave & 3, kh = wave >> 2;             // dX: channel block, contraction half
     const int u_lo = blockIdx.x * a.units_per_wg, u_hi = min(u_lo + a.units_per_wg, a.total_units);
@@ -60,7 +65,8 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
 
     // staging assignment: dz chunk = 256 rows x 32 px, two threads per row (16 px each); X chunk = 128 rows, four threads per row
     const int zr = tid >> 1, zh = tid & 1, xr = tid >> 2, xq = tid & 3;
-    f32x4 rz[4], rx[2];
+    f32x4 rz[4], rx[2], rg[4];
+    float ca1 = 0.f, ca2 = 0.f;   // a1, a2 of the staged chunk's (image, channel zr)
     // Where a unit (chunk) lives: wave-uniform base pointers of its image and segment + the pixel offset, advanced
     // INCREMENTALLY from chunk to chunk.  The first version located every chunk from scratch -- a scalar-load loop over the
     // segment table and an integer division, three times per iteration (next chunk's loads, previous chunk's stores, this
@@ -71,6 +77,9 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         const float* x;   // X rows (the segment's 128 channels) of the image, at the chunk's first pixel
         float* dx;        // the same 128 channels of the output gradient
         int P, k, left;   // row pitch; segment; chunks left in this image after this one
+        const float* g;   // dout rows (meaningful when comp)
+        int cb;           // image * XW_CO: row of the per-(image, channel) coefficients
+        bool comp;        // dz = f(g, z) is formed at staging time
     };
     auto make_ref = [&](int u) {
         int k = 0;
@@ -82,11 +91,13 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         r.x = s.x + ((size_t)b * s.x_rows + s.x_c0) * s.P + p0;
         r.dx = s.dx + ((size_t)b * s.x_rows + s.x_c0) * s.P + p0;
         r.P = s.P, r.k = k, r.left = s.chunks_per_img - 1 - ci_;
+        r.comp = s.g != nullptr, r.cb = b * XW_CO;
+        r.g = (r.comp ? s.g : s.dz) + (size_t)b * XW_CO * s.P + p0;
         return r;
     };
     auto advance = [&](UnitRef& r, int u_next) {   // r describes unit u_next - 1
         if (r.left > 0) {
-            r.z += XW_PX, r.x += XW_PX, r.dx += XW_PX, r.left -= 1;
+            r.z += XW_PX, r.x += XW_PX, r.dx += XW_PX, r.g += XW_PX, r.left -= 1;
         } else {
             r = make_ref(u_next);   // next image or next segment: rare (once per >= 32 chunks)
         }
@@ -98,8 +109,27 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         for (int q = 0; q < 4; ++q) rz[q] = *reinterpret_cast<const f32x4*>(zp + 4 * q);
 #pragma unroll
         for (int q = 0; q < 2; ++q) rx[q] = *reinterpret_cast<const f32x4*>(xp + 4 * q);
+        if (r.comp) {   // wave-uniform
+            const float* gp = r.g + (size_t)zr * r.P + zh * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rg[q] = *reinterpret_cast<const f32x4*>(gp + 4 * q);
+            ca1 = a.coef_a1[r.cb + zr], ca2 = a.coef_a2[r.cb + zr];
+        }
     };
-    auto store_chunk = [&](int buf) {   // rows keep their pixel order (see the header: k-step s pairs pixels s and s + 16)
+    auto store_chunk = [&](int buf, bool comp) {   // rows keep their pixel order (see the header: k-step s pairs pixels s and s + 16)
+        if (comp) {   // dz = gi (mask (g a1 + a2) - mdy - xhat mdyx): ffm_dz_kernel's expression, operation for operation
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(coef + 8 * zr), c1 = *reinterpret_cast<const f32x4*>(coef + 8 * zr + 4);
+            const float mu = c0[0], is = c0[1], gw = c0[2], gb = c0[3], gi = c1[0], mdy = c1[1], mdyx = c1[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (rz[q][e] - mu) * is;
+                    const float y = fmaf(xh, gw, gb);
+                    const float dy = y > 0.f ? fmaf(rg[q][e], ca1, ca2) : 0.f;
+                    rz[q][e] = gi * (dy - mdy - xh * mdyx);
+                }
+        }
         float* zd = dzs + ((size_t)buf * XW_CO + zr) * XW_PITCH + zh * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(zd + 4 * q) = rz[q];
@@ -166,12 +196,21 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dxa[q] + rp[q * 64]), rs, voff, acc_row(q) * r.P * 4, 16);
     };
 
+    if (a.seg[0].g != nullptr && tid < XW_CO) {   // the per-channel coefficient table (read back at staging time: no registers)
+        const float is = a.invstd[tid], gw = a.bn_w[tid];
+        f32x4 c0, c1;
+        c0[0] = a.mean[tid], c0[1] = is, c0[2] = gw, c0[3] = a.bn_b[tid];
+        c1[0] = gw * is, c1[1] = a.mean_dy[tid], c1[2] = a.mean_dyx[tid], c1[3] = 0.f;
+        *reinterpret_cast<f32x4*>(coef + 8 * tid) = c0;
+        *reinterpret_cast<f32x4*>(coef + 8 * tid + 4) = c1;
+    }
+    __syncthreads();
     UnitRef nxt = make_ref(u_lo), cur = nxt, prv = nxt;
     int k_cur = cur.k;
     zero_dw();
     load_w(k_cur);
     load_chunk(nxt);
-    store_chunk(0);
+    store_chunk(0, nxt.comp);
     __syncthreads();
     for (int u = u_lo; u < u_hi; ++u) {
         const int buf = (u - u_lo) & 1;
@@ -240,7 +279,7 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         hand_over(buf);
         // (staging the next chunk here, at the end, or between the two products -- its 16-byte LDS writes draining under the
         // dX MFMAs -- measured the same: 183 against 185 us)
-        if (u + 1 < u_hi) store_chunk(buf ^ 1);
+        if (u + 1 < u_hi) store_chunk(buf ^ 1, nxt.comp);
         __syncthreads();
         prv = cur, cur = nxt;
     }
@@ -290,19 +329,24 @@ size_t ffm_bwd_fused_slab_floats(int B, int Cs, int Cc, int P, int Pl) {
 }
 
 // dfsp = W_s^T dz, dlow = W_c^T dzl, dW = [dz fsp^T | dzl low^T]   (w: (Co, Cs + Cc) row-major, dw likewise)
+// dz_coef set: `dz` is z, and dz = f(dout, z, coefficients) is formed inside the kernel (the full-resolution dz is never stored)
 hipError_t ffm_bwd_fused_run(const float* dz, const float* dzl, const float* fsp, const float* low, const float* w, int B,
                              int Cs, int Cc, int P, int Pl, float* dfsp, float* dlow, float* dw, float* slabs,
-                             hipStream_t stream) {
+                             hipStream_t stream, const XwDzCoef* dz_coef) {
     XwArgs a{};
     XwSumArgs sa{};
     const int ldw = Cs + Cc;
     int unit = 0, k = 0;
-    a.seg[k] = XwSeg{dz, fsp, dfsp, P, Cs, 0, 0, P / XW_PX, unit};
+    a.seg[k] = XwSeg{dz, dz_coef ? dz_coef->g : nullptr, fsp, dfsp, P, Cs, 0, 0, P / XW_PX, unit};
+    if (dz_coef) {
+        a.mean = dz_coef->mean, a.invstd = dz_coef->invstd, a.bn_w = dz_coef->bn_w, a.bn_b = dz_coef->bn_b;
+        a.mean_dy = dz_coef->mean_dy, a.mean_dyx = dz_coef->mean_dyx, a.coef_a1 = dz_coef->coef_a1, a.coef_a2 = dz_coef->coef_a2;
+    }
     sa.col_off[k] = 0;
     unit += B * (P / XW_PX);
     for (int c0 = 0; c0 < Cc; c0 += XW_CX) {
         ++k;
-        a.seg[k] = XwSeg{dzl, low, dlow, Pl, Cc, c0, Cs + c0, Pl / XW_PX, unit};
+        a.seg[k] = XwSeg{dzl, nullptr, low, dlow, Pl, Cc, c0, Cs + c0, Pl / XW_PX, unit};
         sa.col_off[k] = Cs + c0;
         unit += B * (Pl / XW_PX);
     }
@@ -316,7 +360,7 @@ hipError_t ffm_bwd_fused_run(const float* dz, const float* dzl, const float* fsp
         sa.wg_lo[s] = lo / a.units_per_wg, sa.wg_hi[s] = hi / a.units_per_wg;
     }
     sa.slabs = slabs, sa.out = dw, sa.ldo = ldw;
-    const size_t lds = ((size_t)2 * (XW_CO + XW_CX) * XW_PITCH + 2 * 4 * 16 * 64) * sizeof(float);
+    const size_t lds = ((size_t)2 * (XW_CO + XW_CX) * XW_PITCH + 2 * 4 * 16 * 64 + XW_CO * 8) * sizeof(float);
     static lds_attr_mask mask{0};
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ffm_bwd_xw_kernel), lds, mask); e != hipSuccess) return e;
     hipLaunchKernelGGL(ffm_bwd_xw_kernel, dim3(nwg), dim3(512), lds, stream, a);

@@ -274,3 +274,99 @@ def test_ffm_bwd_fused_equals_chain(B, H, W, Hl, Wl):
     for name, a, b, c in zip(("dfsp", "dlow", "dw_blk", "dbn_w", "dbn_b", "dw1", "dw2"), fused, chain, again):
         assert_close(a, b, 2e-6, name, atol=1e-9)
         assert torch.equal(a, c), name  # bit-reproducible (ordered slab sum, no atomics)
+
+
+@pytest.mark.parametrize("B,H,W,Hl,Wl,training", [(4, 64, 64, 16, 16, True), (3, 24, 128, 6, 32, True), (1, 8, 64, 2, 16, True),
+                                                  (2, 16, 64, 4, 16, False)])
+def test_ffm_fwd_fused_equals_chain(B, H, W, Hl, Wl, training):
+    """Round 4: z = W_s fsp + U(W_c low) and the BatchNorm sums from ONE persistent launch (ffm_fwd_fused.hip) against
+    round 3's gemm_kmajor + bn_rowstats pair -- out, z, saved statistics, pooled means, gate and the running buffers; runs that
+    cross image boundaries (B = 3: 144 chunks over 144 workgroups; B = 1: fewer chunks than CUs), W = 64 / 128, eval."""
+    import os
+
+    from cabinet_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(B * 100 + W)
+    Cs, Cc, Co, Cm = 128, 256, 256, 64
+    fsp = torch.randn(B, Cs, H, W, generator=gen).cuda()
+    low = torch.randn(B, Cc, Hl, Wl, generator=gen).cuda()
+    wb = (torch.randn(Co, Cs + Cc, generator=gen) * 0.07).cuda()
+    w1 = (torch.randn(Cm, Co, generator=gen) * 0.1).cuda()
+    w2 = (torch.randn(Co, Cm, generator=gen) * 0.1).cuda()
+    bw, bb = torch.rand(Co, generator=gen).cuda() + 0.5, (torch.rand(Co, generator=gen).cuda() - 0.5)
+    res = {}
+    for name, env in (("fused", None), ("chain", "1"), ("again", None)):
+        rm, rv = torch.full((Co,), 0.1).cuda(), torch.full((Co,), 0.9).cuda()
+        if env:
+            os.environ["CABINET_FFM_FWD_UNFUSED"] = env
+        try:
+            r = Fn.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, training, 0.1, 1e-5)
+        finally:
+            os.environ.pop("CABINET_FFM_FWD_UNFUSED", None)
+        res[name] = list(r) + [rm, rv]
+    torch.cuda.synchronize()
+    for nm, a, b, c in zip(("out", "z", "save_mean", "save_invstd", "pooled", "gate", "running_mean", "running_var"),
+                           res["fused"], res["chain"], res["again"]):
+        assert_close(a, b, 3e-6, nm, atol=1e-9)
+        assert torch.equal(a, c), nm  # bit-reproducible
+
+
+def test_ffm_fwd_fused_statistics_with_large_channel_means():
+    """The fused forward sums (z - pivot) per lane in fp32 and shifts back in double: channels with |mean| = 100 std must
+    keep their variance (the one-pass fp32 form E[z^2] - mean^2 would lose (mean / std)^2 ulps)."""
+    import torch.nn.functional as F
+
+    from cabinet_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(5)
+    B, Cs, Cc, Co, Cm, H, W, Hl, Wl = 2, 128, 256, 256, 64, 32, 64, 8, 16
+    fsp = torch.randn(B, Cs, H, W, generator=gen) * 0.02 + 3.0   # every input channel ~ 3 +- 0.02
+    low = torch.randn(B, Cc, Hl, Wl, generator=gen) * 0.02 - 3.0
+    wb = torch.randn(Co, Cs + Cc, generator=gen) * 0.2
+    w1, w2 = torch.randn(Cm, Co, generator=gen) * 0.1, torch.randn(Co, Cm, generator=gen) * 0.1
+    x = torch.cat([fsp, F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)], 1).double()
+    z64 = F.conv2d(x, wb.double()[:, :, None, None])
+    mean, var = z64.mean(dim=(0, 2, 3)), z64.var(dim=(0, 2, 3), unbiased=False)
+    assert float((mean.abs() / var.sqrt()).median()) > 50
+    rm, rv = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
+    out, z, sm, si, pooled, gate = Fn.ffm_up_fwd_hip(fsp.cuda(), low.cuda(), wb.cuda(), torch.ones(Co).cuda(), torch.zeros(Co).cuda(),
+                                                     rm, rv, w1.cuda(), w2.cuda(), True, 0.1, 1e-5)
+    torch.cuda.synchronize()
+    assert_close(sm, mean, 1e-6, "save_mean")
+    assert_close(si, (var + 1e-5).rsqrt(), 2e-4, "save_invstd")   # z itself carries 1e-7 * (mean / std) into the centred values
+
+
+@pytest.mark.parametrize("B,H,W,Hl,Wl,training", [(4, 64, 64, 16, 16, True), (2, 128, 128, 32, 32, True), (1, 40, 32, 10, 8, True),
+                                                  (2, 32, 256, 8, 64, True), (3, 36, 16, 9, 4, True), (2, 64, 64, 16, 16, False)])
+def test_ffm_bwd_linear_adjoint_equals_two_pass(B, H, W, Hl, Wl, training):
+    """Round 4: dz_low = U^T dz from three coefficient-free adjoint fields taken in the reduction pass (ffm_bwd_adj.hip)
+    against the second pass over dout and z it replaces (upsample_adjoint_kernel<true>) -- every gradient of the operator;
+    bands that straddle source rows (H = 128: four bands), a short last band (H = 40, 36), Wl = 4 .. 64, eval mode (no batch
+    means).  The five BatchNorm sums keep their order, so everything upstream of dz_low is bit-identical (W >= 32)."""
+    import os
+
+    from cabinet_amd import functional as Fn
+
+    gen = torch.Generator().manual_seed(B * 1000 + H + W)
+    Cs, Cc, Co, Cm = 128, 256, 256, 64
+    fsp = torch.randn(B, Cs, H, W, generator=gen).cuda()
+    low = torch.randn(B, Cc, Hl, Wl, generator=gen).cuda()
+    wb = (torch.randn(Co, Cs + Cc, generator=gen) * 0.07).cuda()
+    w1 = (torch.randn(Cm, Co, generator=gen) * 0.1).cuda()
+    w2 = (torch.randn(Co, Cm, generator=gen) * 0.1).cuda()
+    g = torch.randn(B, Co, H, W, generator=gen).cuda()
+    bw, bb = torch.rand(Co, generator=gen).cuda() + 0.5, (torch.rand(Co, generator=gen).cuda() - 0.5)
+    rm, rv = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
+    out, z, mean, invstd, pooled, gate = Fn.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, training, 0.1, 1e-5)
+    args = (g, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, training)
+    lin = Fn.ffm_up_bwd_hip(*args)
+    os.environ["CABINET_FFM_BWD_TWO_PASS"] = "1"
+    try:
+        two = Fn.ffm_up_bwd_hip(*args)
+    finally:
+        del os.environ["CABINET_FFM_BWD_TWO_PASS"]
+    again = Fn.ffm_up_bwd_hip(*args)
+    torch.cuda.synchronize()
+    for name, a, b, c in zip(("dfsp", "dlow", "dw_blk", "dbn_w", "dbn_b", "dw1", "dw2"), lin, two, again):
+        assert_close(a, b, 3e-6, name, atol=1e-9)
+        assert torch.equal(a, c), name
