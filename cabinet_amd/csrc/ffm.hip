@@ -1166,8 +1166,7 @@ hipError_t ffm_bwd_reduce_adj_run(const float* g, const float* z, const float* m
                                   const float* bn_b, float* sums, float* t, int planes, int C, int H, int Hl, int Wl,
                                   hipStream_t stream);
 hipError_t ffm_bwd_dzl_run(const float* t, const float* invstd, const float* bn_w, const float* a1, const float* a2,
-                           const float* mdy, const float* mdyx, float* dzl, int planes, int C, int H, int W, int Hl, int Wl,
-                           hipStream_t stream);
+                           const float* mdy, const float* mdyx, float* dzl, int planes, int C, int Hl, int Wl, hipStream_t stream);
 // CABINET_FFM_BWD_TWO_PASS=1 keeps the second pass over dout and z (upsample_adjoint_kernel<true>; A/B timing, tests run both)
 static bool ffm_bwd_adj_enabled() {
     const char* e = getenv("CABINET_FFM_BWD_TWO_PASS");
@@ -1247,7 +1246,7 @@ static hipError_t ffm_bwd_head(const FfmShape& s, const BwdWs& L, char* base, co
                        s.B, s.Co, s.Cm, P, training, dw1, dw2, dbn_w, dbn_b, mdy, mdyx);
     if (adj_Hl > 0) {
         if (hipError_t e = ffm_bwd_dzl_run(dz, save_invstd, bn_w, a1, a2, mdy, mdyx, reinterpret_cast<float*>(base + L.dzl),
-                                           s.B * s.Co, s.Co, s.H, s.W, adj_Hl, adj_Wl, stream);
+                                           s.B * s.Co, s.Co, adj_Hl, adj_Wl, stream);
             e != hipSuccess)
             return e;
     }

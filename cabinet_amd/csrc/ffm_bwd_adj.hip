@@ -12,7 +12,7 @@
 //     U^T dz = gi (a1 U^T(mask g) + a2 U^T(mask) - mdy U^T(1) - mdyx U^T(xhat)):
 // the three adjoint fields T1 = U^T(mask g), T2 = U^T(mask), T3 = U^T(xhat) need no coefficient and are taken in the SAME pass
 // that forms the five BatchNorm sums (ffm_bwd_reduce_adj_kernel: 268 MB in, 3 x 8 MB out), U^T(1) is a product of two 1-D
-// weight sums, and dz_low is an elementwise pass over 8 MB (ffm_bwd_dzl_kernel).  The full-resolution dz is never written:
+// weight sums (= 16), and dz_low is an elementwise pass over 8 MB (ffm_bwd_dzl_kernel).  The full-resolution dz is never written:
 // ffm_bwd_fused.hip forms it from g and z while it stages a chunk.
 // xhat, not z, goes through U^T: the combination mdyx (T3) would otherwise cancel (mean / std) ulps.
 //
@@ -23,7 +23,8 @@
 //            the horizontally reduced row goes to LDS;
 //   phase B  a thread owns (source row k, column) and adds the <= 8 output rows of the band with weight on k; a source row
 //            that straddles two bands is carried through LDS (double-buffered by band parity: one barrier per band).
-// The pixel -> thread assignment and order of the five sums are those of ffm_bwd_reduce_kernel: the sums are bit-identical.
+// The pixel -> thread assignment and order of the five sums are those of ffm_bwd_reduce_kernel (for Wl >= 8 and H a multiple of
+// 32): the sums are bit-identical.
 #include "blocks.hpp"
 #include "common.hpp"
 
@@ -139,33 +140,28 @@ __global__ __launch_bounds__(256) void ffm_bwd_reduce_adj_kernel(const float* __
     }
 }
 
-// sum over the output positions of one axis of their bilinear weight on source index k: one factor of U^T(1)
-__device__ __forceinline__ float adjoint_weight_sum(int k, int out_size, int in_size, float scale) {
-    float s = 0.f;
-    for (int o = max(0, 4 * k - 2); o <= min(out_size - 1, 4 * k + 5); ++o) {
-        int i0, i1;
-        float lam;
-        bilinear_taps(o, scale, in_size, i0, i1, lam);
-        s += (i0 == k ? 1.f - lam : 0.f) + (i1 == k ? lam : 0.f);
-    }
-    return s;
-}
-
-// dz_low = gi (a1 T1 + a2 T2 - mdy U^T(1) - mdyx T3)
+// dz_low = gi (a1 T1 + a2 T2 - mdy U^T(1) - mdyx T3),  U^T(1) = 16 everywhere: every output pixel spreads weight 1 over its
+// taps and the fold at the borders keeps it in the plane, so along one axis source index k receives
+// 1/8 + 3/8 + 5/8 + 7/8 + 7/8 + 5/8 + 3/8 + 1/8 = 4 (at k = 0: 1 + 1 + 7/8 + 5/8 + 3/8 + 1/8), exactly, in any order of summation.
+// One workgroup per quarter-KB of a plane; four positions per thread.
 __global__ __launch_bounds__(256) void ffm_bwd_dzl_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
                                                            const float* __restrict__ t3, const float* __restrict__ invstd,
                                                            const float* __restrict__ bn_w, const float* __restrict__ coef_a1,
                                                            const float* __restrict__ coef_a2,
                                                            const float* __restrict__ mean_dy,
                                                            const float* __restrict__ mean_dyx, float* __restrict__ dzl, int C,
-                                                           int H, int W, int Hl, int Wl, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int Pl = Hl * Wl, row = i / Pl, q = i - row * Pl, k = q / Wl, col = q - k * Wl, c = row % C;
-    const float u1 = adjoint_weight_sum(k, H, Hl, (float)Hl / (float)H) * adjoint_weight_sum(col, W, Wl, (float)Wl / (float)W);
-    const float gi = bn_w[c] * invstd[c];
-    const float dy = fmaf(coef_a1[row], t1[i], coef_a2[row] * t2[i]);
-    dzl[i] = gi * (dy - mean_dy[c] * u1 - mean_dyx[c] * t3[i]);
+                                                           int Pl) {
+    const int row = blockIdx.y, c = row % C;
+    const float gi = bn_w[c] * invstd[c], a1 = coef_a1[row], a2 = coef_a2[row], m16 = mean_dy[c] * 16.f, mx = mean_dyx[c];
+    const size_t base = (size_t)row * Pl;
+    for (int q = (blockIdx.x * 256 + threadIdx.x) * 4; q < Pl; q += gridDim.x * 1024) {
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(t1 + base + q), v2 = *reinterpret_cast<const f32x4*>(t2 + base + q);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(t3 + base + q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gi * (fmaf(a1, v1[e], a2 * v2[e]) - m16 - mx * v3[e]);
+        *reinterpret_cast<f32x4*>(dzl + base + q) = o;
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -195,12 +191,11 @@ hipError_t ffm_bwd_reduce_adj_run(const float* g, const float* z, const float* m
 }
 
 hipError_t ffm_bwd_dzl_run(const float* t, const float* invstd, const float* bn_w, const float* a1, const float* a2,
-                           const float* mdy, const float* mdyx, float* dzl, int planes, int C, int H, int W, int Hl, int Wl,
-                           hipStream_t stream) {
-    const size_t n = (size_t)planes * Hl * Wl;
-    if (n > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ffm_bwd_dzl_kernel, dim3(ceil_div((int)n, 256)), dim3(256), 0, stream, t, t + n, t + 2 * n, invstd, bn_w,
-                       a1, a2, mdy, mdyx, dzl, C, H, W, Hl, Wl, (int)n);
+                           const float* mdy, const float* mdyx, float* dzl, int planes, int C, int Hl, int Wl, hipStream_t stream) {
+    const int Pl = Hl * Wl;   // a multiple of 4 (Wl is)
+    const size_t n = (size_t)planes * Pl;
+    hipLaunchKernelGGL(ffm_bwd_dzl_kernel, dim3(min(ceil_div(Pl, 1024), 64), planes), dim3(256), 0, stream, t, t + n, t + 2 * n,
+                       invstd, bn_w, a1, a2, mdy, mdyx, dzl, C, Pl);
     return hipGetLastError();
 }
 

@@ -21,6 +21,8 @@
 // re-ordering at all.  The dX product reads the same rows with the pixel on the lane (consecutive words: conflict-free).
 // Work is dealt in equal contiguous runs of chunks over <= 256 workgroups (one per CU); a workgroup writes its dW tile as
 // one slab per segment it touched, and an ordered slab sum finishes dW: no atomics, bit-reproducible.
+// (Measured and not kept: walking the full-resolution segment TRANSPOSED -- step j of workgroup i = chunk 228 j + i, so that
+// the workgroups read adjacent 128-byte pieces of every row at the same time instead of pieces 2 KB apart: 221 us against 219.)
 // Exact fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout.
 #include "blocks.hpp"
 #include "common.hpp"
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
 
     // staging assignment: dz chunk = 256 rows x 32 px, two threads per row (16 px each); X chunk = 128 rows, four threads per row
     const int zr = tid >> 1, zh = tid & 1, xr = tid >> 2, xq = tid & 3;
-    f32x4 rz[4], rx[2], rg[4];
+    f32x4 rz[4], rx[2], rg[4] = {};
     float ca1 = 0.f, ca2 = 0.f;   // a1, a2 of the staged chunk's (image, channel zr)
     // Where a unit (chunk) lives: wave-uniform base pointers of its image and segment + the pixel offset, advanced
     // INCREMENTALLY from chunk to chunk.  The first version located every chunk from scratch -- a scalar-load loop over the
@@ -116,20 +118,27 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
             ca1 = a.coef_a1[r.cb + zr], ca2 = a.coef_a2[r.cb + zr];
         }
     };
-    auto store_chunk = [&](int buf, bool comp) {   // rows keep their pixel order (see the header: k-step s pairs pixels s and s + 16)
-        if (comp) {   // dz = gi (mask (g a1 + a2) - mdy - xhat mdyx): ffm_dz_kernel's expression, operation for operation
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(coef + 8 * zr), c1 = *reinterpret_cast<const f32x4*>(coef + 8 * zr + 4);
-            const float mu = c0[0], is = c0[1], gw = c0[2], gb = c0[3], gi = c1[0], mdy = c1[1], mdyx = c1[2];
+    // dz = gi (mask (g a1 + a2) - mdy - xhat mdyx): ffm_dz_kernel's expression, operation for operation, on the sixteen staged
+    // values of the NEXT chunk, a quarter at a time between the MFMAs of the dX product's last four half-blocks (the VALU is
+    // idle under a chain of dependent MFMAs; done in one piece in front of the barrier it cost 10 us per launch)
+    f32x4 cf0, cf1;
+    auto dz_coef = [&]() {
+        cf0 = *reinterpret_cast<const f32x4*>(coef + 8 * zr), cf1 = *reinterpret_cast<const f32x4*>(coef + 8 * zr + 4);
+    };
+    auto dz_quarter = [&](int q, bool on) {   // branch-free (a select on the wave-uniform `on`): the VALU work has to sit in the
+        const float mu = cf0[0], is = cf0[1], gw = cf0[2], gb = cf0[3], gi = cf1[0], mdy = cf1[1], mdyx = cf1[2];   // MFMAs' block
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = (rz[q][e] - mu) * is;
-                    const float y = fmaf(xh, gw, gb);
-                    const float dy = y > 0.f ? fmaf(rg[q][e], ca1, ca2) : 0.f;
-                    rz[q][e] = gi * (dy - mdy - xh * mdyx);
-                }
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (rz[q][e] - mu) * is;
+            const float y = fmaf(xh, gw, gb);
+            const float dy = y > 0.f ? fmaf(rg[q][e], ca1, ca2) : 0.f;
+            const float v = gi * (dy - mdy - xh * mdyx);
+            rz[q][e] = on ? v : rz[q][e];
         }
+        // keeps the arithmetic HERE: left alone, instruction sinking moves it down to its use, the LDS store behind the MFMAs
+        asm volatile("" : "+v"(rz[q]));
+    };
+    auto store_chunk = [&](int buf) {   // rows keep their pixel order (see the header: k-step s pairs pixels s and s + 16)
         float* zd = dzs + ((size_t)buf * XW_CO + zr) * XW_PITCH + zh * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(zd + 4 * q) = rz[q];
@@ -210,7 +219,12 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
     zero_dw();
     load_w(k_cur);
     load_chunk(nxt);
-    store_chunk(0, nxt.comp);
+    if (nxt.comp) {
+        dz_coef();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dz_quarter(q, true);
+    }
+    store_chunk(0);
     __syncthreads();
     for (int u = u_lo; u < u_hi; ++u) {
         const int buf = (u - u_lo) & 1;
@@ -268,18 +282,28 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (t == 3) read8(zrow + 8, af);
         }
+        const bool comp_next = u + 1 < u_hi && nxt.comp;   // wave-uniform
+        dz_coef();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (e < 7) read_col(e + 1, bf[(e + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 8; ++s) dxa = mfma32(wf[8 * e + s], bf[e & 1][s], dxa);
+            if (e >= 4) {
+                dz_quarter(e - 4, comp_next);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {   // program order: one MFMA, five VALU, one MFMA, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         hand_over(buf);
         // (staging the next chunk here, at the end, or between the two products -- its 16-byte LDS writes draining under the
         // dX MFMAs -- measured the same: 183 against 185 us)
-        if (u + 1 < u_hi) store_chunk(buf ^ 1, nxt.comp);
+        if (u + 1 < u_hi) store_chunk(buf ^ 1);
         __syncthreads();
         prv = cur, cur = nxt;
     }
