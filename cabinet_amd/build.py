@@ -54,7 +54,12 @@ def is_fresh():
     if not (os.path.exists(LIB_PATH) and os.path.exists(stamp)):
         return False
     with open(stamp) as f:
-        return f.read().strip() == source_digest()
+        return f.read().strip() == _stamp()
+
+
+def _stamp():
+    """What the built library is checked against: the sources AND the extra flags (a -D experiment build must not pass for the product)."""
+    return (source_digest() + " " + os.environ.get("CABINET_EXTRA_HIPCC_FLAGS", "").strip()).strip()
 
 
 def build(force=False, save_temps=False, verbose=True):
@@ -90,7 +95,7 @@ def build(force=False, save_temps=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     with open(LIB_PATH + ".stamp", "w") as f:
-        f.write(source_digest())
+        f.write(_stamp())
     if verbose:
         print(f"[cabinet_amd.build] built {LIB_PATH}")
     return LIB_PATH

@@ -54,6 +54,16 @@ struct XwArgs {
     const float *coef_a1, *coef_a2;   // ... and per (image, channel)
 };
 
+// -DXW_TRACE (tools/xw_trace.py): cycle stamps of waves 0 and 4 of one workgroup at the phase boundaries of every chunk
+#ifdef XW_TRACE
+__device__ unsigned long long xw_trace_buf[2 * 32 * 16];
+#define XW_T(i)                                                                                                            \
+    if (blockIdx.x == 100 && (tid & 255) == 0 && u - u_lo < 32)                                                             \
+    xw_trace_buf[((tid >> 8) * 32 + (u - u_lo)) * 16 + (i)] = __builtin_readcyclecounter()
+#else
+#define XW_T(i)
+#endif
+
 __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dzs = smem;                                   // [2][256][36]
@@ -116,6 +126,25 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) rg[q] = *reinterpret_cast<const f32x4*>(gp + 4 * q);
             ca1 = a.coef_a1[r.cb + zr], ca2 = a.coef_a2[r.cb + zr];
+        }
+    };
+    // The same loads dealt over the first five half-blocks of the dW product.  Issued in one piece at the top of the chunk, the
+    // 8 x 14 load instructions of a workgroup (two lanes per row: 32 cache lines per instruction) kept the texture-address path
+    // busy for ~3000 cycles during which every wave sat at its next load and no MFMA was issued (tools/xw_trace.py: 2000-5000
+    // of a chunk's 23000 cycles in "advance + load").
+    auto load_part = [&](const UnitRef& r, int t) {
+        if (t < 2) {
+            const float* zp = r.z + (size_t)zr * r.P + zh * 16 + 8 * t;
+            rz[2 * t] = *reinterpret_cast<const f32x4*>(zp), rz[2 * t + 1] = *reinterpret_cast<const f32x4*>(zp + 4);
+        } else if (t < 4) {
+            if (r.comp) {
+                const float* gp = r.g + (size_t)zr * r.P + zh * 16 + 8 * (t - 2);
+                rg[2 * (t - 2)] = *reinterpret_cast<const f32x4*>(gp), rg[2 * (t - 2) + 1] = *reinterpret_cast<const f32x4*>(gp + 4);
+            }
+        } else if (t == 4) {
+            const float* xp = r.x + (size_t)xr * r.P + xq * 8;
+            rx[0] = *reinterpret_cast<const f32x4*>(xp), rx[1] = *reinterpret_cast<const f32x4*>(xp + 4);
+            if (r.comp) ca1 = a.coef_a1[r.cb + zr], ca2 = a.coef_a2[r.cb + zr];
         }
     };
     // dz = gi (mask (g a1 + a2) - mdy - xhat mdyx): ffm_dz_kernel's expression, operation for operation, on the sixteen staged
@@ -195,13 +224,13 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
             for (int q = 0; q < 16; ++q) rp[q * 64] = dxa[q];
         }
     };
-    auto store_dx = [&](const UnitRef& r, int rbuf, bool valid) {
+    auto store_dx = [&](const UnitRef& r, int rbuf, bool valid, int q_lo, int q_hi) {   // rows q_lo .. q_hi - 1 of the tile
         if (!valid || kh != 0) return;
         const float* rp = red + ((size_t)(rbuf * 4 + ci) * 16) * 64 + lane;
         const buf_rsrc rs = make_rsrc(r.dx, 0x7fffffffu);
         const int voff = ((32 * ci + 4 * h) * r.P + li) * 4;
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
+        for (int q = q_lo; q < q_hi; ++q)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dxa[q] + rp[q * 64]), rs, voff, acc_row(q) * r.P * 4, 16);
     };
 
@@ -228,19 +257,17 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
     __syncthreads();
     for (int u = u_lo; u < u_hi; ++u) {
         const int buf = (u - u_lo) & 1;
-        store_dx(prv, buf ^ 1, u > u_lo);   // the previous chunk's tile: both halves' hand-overs landed before the barrier
-        if (u + 1 < u_hi) {   // (behind the finalisation: its temporaries and the 24 staging registers are never live together)
-            advance(nxt, u + 1);
-            load_chunk(nxt);
-        }
+        XW_T(0);
+        const bool has_next = u + 1 < u_hi;
+        if (has_next) advance(nxt, u + 1);
+        XW_T(1);
+        XW_T(2);
         if (cur.k != k_cur) {   // wave-uniform: a new segment starts with this chunk
             flush_dw(k_cur);
             zero_dw();
             load_w(cur.k);
             k_cur = cur.k;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
         // Sixteen half-blocks of 8 MFMAs per chunk: half-blocks 0-7 = dW column block j = t / 2, k-steps 8 (t & 1) .. + 7
         // (operands: 8 consecutive floats of the wave's dz row and of X row 32 j + li), half-blocks 8-15 = eighths of the dX
         // half-contraction (operand: one float per k-step from the dz rows, pixel on the lane).  The operands of half-block
@@ -267,6 +294,7 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
         // dz row (8 registers) is resident: the second half is read once the MFMAs of t = 3 are issued (one exposed LDS round
         // trip per chunk) -- with both halves resident the kernel needed 8 registers more than the 256 a wave has at two per
         // SIMD, and a scratch reload in the loop makes the compiler wait for vmcnt(0), i.e. for the chunk loads just issued.
+        XW_T(3);
         read8(zrow, af);
         read8(xrow, bf[0]);
 #pragma unroll
@@ -281,7 +309,14 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
             for (int s = 0; s < 8; ++s) dw[j] = mfma32(af[s], bf[t & 1][s], dw[j]);
             __builtin_amdgcn_sched_barrier(0);
             if (t == 3) read8(zrow + 8, af);
+            // between the half-blocks: two rows of the PREVIOUS chunk's dX tile leave (its two halves' hand-overs landed before the
+            // barrier; dxa is not touched by the dW product) and a share of the NEXT chunk's loads is issued
+            store_dx(prv, buf ^ 1, u > u_lo, 2 * t, 2 * t + 2);
+            if (has_next) load_part(nxt, t);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
+        XW_T(4);
         const bool comp_next = u + 1 < u_hi && nxt.comp;   // wave-uniform
         dz_coef();
 #pragma unroll
@@ -300,14 +335,18 @@ __global__ __launch_bounds__(512) void ffm_bwd_xw_kernel(XwArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        XW_T(5);
         hand_over(buf);
+        XW_T(6);
         // (staging the next chunk here, at the end, or between the two products -- its 16-byte LDS writes draining under the
         // dX MFMAs -- measured the same: 183 against 185 us)
         if (u + 1 < u_hi) store_chunk(buf ^ 1);
+        XW_T(7);
         __syncthreads();
+        XW_T(8);
         prv = cur, cur = nxt;
     }
-    store_dx(prv, (u_hi - 1 - u_lo) & 1, true);
+    store_dx(prv, (u_hi - 1 - u_lo) & 1, true, 0, 16);
     flush_dw(k_cur);
 }
 
@@ -393,3 +432,9 @@ hipError_t ffm_bwd_fused_run(const float* dz, const float* dzl, const float* fsp
 }
 
 }  // namespace cabinet
+
+#ifdef XW_TRACE
+extern "C" int cabinet_debug_xw_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cabinet::xw_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+#endif
