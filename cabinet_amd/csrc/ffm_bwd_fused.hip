@@ -23,6 +23,8 @@
 // one slab per segment it touched, and an ordered slab sum finishes dW: no atomics, bit-reproducible.
 // (Measured and not kept: walking the full-resolution segment TRANSPOSED -- step j of workgroup i = chunk 228 j + i, so that
 // the workgroups read adjacent 128-byte pieces of every row at the same time instead of pieces 2 KB apart: 221 us against 219.)
+// (Also measured and not kept: eight lanes per staged row instead of two, i.e. whole 128-byte lines per load instruction and a
+// quarter of the line touches: 294 us for the operator against 288.)
 // Exact fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout.
 #include "blocks.hpp"
 #include "common.hpp"

@@ -39,6 +39,16 @@ struct FzArgs {
     int total_units, units_per_wg, nwg;
 };
 
+// -DFZ_TRACE (tools/xw_trace.py fwd): cycle stamps of waves 0 and 4 of one workgroup at the phase boundaries of every chunk
+#ifdef FZ_TRACE
+__device__ unsigned long long fz_trace_buf[2 * 32 * 16];
+#define FZ_T(i)                                                                                                            \
+    if (blockIdx.x == 100 && (tid & 255) == 0 && u - u_lo < 32)                                                             \
+    fz_trace_buf[((tid >> 8) * 32 + (u - u_lo)) * 16 + (i)] = __builtin_readcyclecounter()
+#else
+#define FZ_T(i)
+#endif
+
 __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* fs = smem;                                  // [2][128][64] staged fsp chunks
@@ -83,10 +93,67 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
             if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four loads in flight, not 32 (registers)
         }
     }
-    float s1[16], s2[16];   // per lane: sums of (z - pivot) and (z - pivot)^2 over its pixel columns, rows acc_row(r) + 4 h
+    // The MFMA takes the PIXEL as its row and the channel as its column (A = the staged fsp, B = W): a lane then holds ONE channel
+    // (32 wave + li) and, per block, the pixels 8 g + 4 h + {0,1,2,3}, g < 4 -- four runs of four consecutive pixels: the
+    // statistics are two scalars per lane and z leaves in 16-byte stores.  (With the channel on the row a lane held 16 channels
+    // x 1 pixel: 32 accumulating registers and 16 dword stores per block -- 256 store instructions per chunk and workgroup at
+    // ~64 cycles each in the address path = as long as the chunk's MFMAs; tools/xw_trace.py fwd.)
+    float s1 = 0.f, s2 = 0.f, pivot = 0.f;   // sums of (z - pivot), (z - pivot)^2 over this lane's pixels; pivot = its first value
+    bool pivot_open = true;                  // wave-uniform
+    // ---- the epilogue of a finished block (32 pixels x 32 channels per wave), one run of four pixels (quad g) per call --------
+    // val = acc + bilinear(y_low) from the wave's two staged source rows; centred statistics; 16-byte store.  The four pixels of
+    // a quad start at a multiple of 4 = the footprint of source column m: taps m - 1, m, m + 1 (clamped: the fold at the border
+    // is align_corners=False's clamp) with the x4 weights 3/8 5/8 | 1/8 7/8 | 7/8 1/8 | 5/8 3/8.
+    struct Pending {
+        float ly;            // vertical weight of the chunk's row
+        int col0;            // first pixel column of the block (ox0 + 32 j)
+        int voff;            // byte offset of (channel 32 wave + li, pixel 32 j + 4 h) from the chunk's z
+        const float* z;      // z of the chunk's image at the chunk's first pixel (block-uniform)
+    };
+    auto make_pending = [&](int b_, int p0_, int oy_, int ox0_, int j_) {
+        Pending q;
+        int y0_, y1_;
+        bilinear_taps(oy_, a.rh, a.Hl, y0_, y1_, q.ly);
+        q.col0 = ox0_ + 32 * j_;
+        q.voff = ((32 * wave + li) * a.P + 32 * j_ + 4 * h) * 4;
+        q.z = a.z + (size_t)b_ * FZ_CO * a.P + p0_;
+        return q;
+    };
+    const float* ylc = yl + li * VW;   // this lane's channel in the two staged rows (second row: + 32 VW)
+    float ev[6];
+    auto epi_read = [&](const Pending& q, int g) {
+        const int m = (q.col0 + 8 * g + 4 * h) >> 2, xm = max(m - 1, 0), xp = min(m + 1, a.Wl - 1);
+        ev[0] = ylc[xm], ev[1] = ylc[m], ev[2] = ylc[xp];
+        ev[3] = ylc[32 * VW + xm], ev[4] = ylc[32 * VW + m], ev[5] = ylc[32 * VW + xp];
+    };
+    auto epi_compute = [&](const Pending& q, const f32x16& acc_, int g) {
+        const float lyc = 1.f - q.ly;
+        const float va = lyc * ev[0] + q.ly * ev[3], vb = lyc * ev[1] + q.ly * ev[4], vc = lyc * ev[2] + q.ly * ev[5];
+        f32x4 val;
+        val[0] = acc_[4 * g + 0] + (0.375f * va + 0.625f * vb);
+        val[1] = acc_[4 * g + 1] + (0.125f * va + 0.875f * vb);
+        val[2] = acc_[4 * g + 2] + (0.875f * vb + 0.125f * vc);
+        val[3] = acc_[4 * g + 3] + (0.625f * vb + 0.375f * vc);
+        pivot = pivot_open ? val[0] : pivot;
+        pivot_open = false;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s1[r] = 0.f, s2[r] = 0.f;
-    float* pivot = yl_all + (size_t)8 * 2 * 32 * VW + wave * 32;   // [2 halves][16 rows] per wave
+        for (int e = 0; e < 4; ++e) {
+            const float d = val[e] - pivot;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+        // block-uniform descriptor (a wave-dependent base makes every store a readfirstlane waterfall loop); the channel row is
+        // part of the lane offset
+        const buf_rsrc zr = make_rsrc(q.z, 0x7fffffffu);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), zr, q.voff + 32 * g, 0, 0);
+    };
+    auto epi_full = [&](const Pending& q, const f32x16& acc_) {   // not overlapped: row changes, end of the run
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            epi_read(q, g);
+            epi_compute(q, acc_, g);
+        }
+    };
 
     // position of unit u: image b, first pixel p0 = (row oy, column ox0)
     int b = u_lo / cpi, p0 = (u_lo - b * cpi) * FZ_PX;
@@ -95,54 +162,63 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
     load_chunk(fbase);
     store_chunk(0);
     __syncthreads();
+    // Software pipeline over the blocks (chunk u, column block j): the MFMAs of a block run with the epilogue of the PREVIOUS
+    // block between them (two accumulators, alternating).  Done one after the other, MFMA phase and epilogue took 4200 and 6000
+    // cycles per block (tools/xw_trace.py fwd): the matrix pipe idle for more than half of the kernel.
+    f32x16 acc2[2];
+    Pending pend{};
+    bool have_pending = false;   // wave-uniform
     for (int u = u_lo; u < u_hi; ++u) {
         const int buf = (u - u_lo) & 1;
+        FZ_T(0);
         // next unit's position (wave-uniform, incremental)
         int nb = b, np0 = p0 + FZ_PX, noy = oy, nox0 = ox0 + FZ_PX;
         if (nox0 == a.W) nox0 = 0, noy += 1;
         if (np0 == a.P) np0 = 0, nb += 1, noy = 0, nox0 = 0;
         if (u + 1 < u_hi) load_chunk(a.fsp + (size_t)nb * FZ_CS * a.P + np0);
+        FZ_T(1);
         // the two y_low rows under this output row for the wave's 32 channels (wave-private: no barrier); they change every
-        // fourth output row, so a run of a few rows reloads them once or twice.  All loads of a batch are in flight together
-        // (a loop of dependent load -> store iterations cost one L2 round trip each: 8 us per two chunks, measured)
+        // fourth output row, so a run of a few rows reloads them once or twice: 2 x 32 x Wl floats as 16-byte pieces, all (<= 8)
+        // loads in flight together.  The pending epilogue still reads the OLD rows: it is finished first (not overlapped).
         int y0, y1;
         float ly;
         bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
         if (y0 != yl_y0 || y1 != yl_y1 || b != yl_b) {
+            if (have_pending) epi_full(pend, acc2[1]);   // the pending block is always a j = 1 block here
+            have_pending = false;
             const float* src = a.ylow + ((size_t)b * FZ_CO + 32 * wave) * a.Hl * a.Wl;
-            const float inv_wl = 1.f / (float)a.Wl;
-            const int n = 32 * a.Wl;
+            const int ppr = a.Wl >> 2, np = 32 * ppr;   // pieces per row; per source row over the 32 channels (<= 256)
+            const float inv_ppr = 1.f / (float)ppr;
+            f32x4 t0[4], t1[4];
+            int off[4];
 #pragma unroll
-            for (int bt = 0; bt < 4; ++bt) {
-                float t0[4], t1[4];
-                int off[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = lane + 64 * (4 * bt + k);
-                    const int ml = idiv_small(min(i, n - 1), inv_wl), xs = min(i, n - 1) - ml * a.Wl;
-                    const float* sp = src + (size_t)ml * a.Hl * a.Wl + xs;
-                    t0[k] = sp[y0 * a.Wl], t1[k] = sp[y1 * a.Wl];
-                    off[k] = i < n ? ml * VW + xs : -1;
+            for (int k = 0; k < 4; ++k) {
+                const int pc = lane + 64 * k, pcl = min(pc, np - 1);
+                const int ml = idiv_small(pcl, inv_ppr), piece = pcl - ml * ppr;
+                const float* sp = src + (size_t)ml * a.Hl * a.Wl + 4 * piece;
+                off[k] = pc < np ? ml * VW + 4 * piece : -1;
+                if (64 * k < np) {   // wave-uniform
+                    t0[k] = *reinterpret_cast<const f32x4*>(sp + y0 * a.Wl);
+                    t1[k] = *reinterpret_cast<const f32x4*>(sp + y1 * a.Wl);
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (off[k] >= 0) yl[off[k]] = t0[k], yl[32 * VW + off[k]] = t1[k];
-                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (64 * k < np && off[k] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) yl[off[k] + e] = t0[k][e], yl[32 * VW + off[k] + e] = t1[k][e];
+                }
             yl_y0 = y0, yl_y1 = y1, yl_b = b;
         }
-        // block-uniform descriptor (a wave-dependent base makes every store a readfirstlane waterfall loop); the wave's rows are
-        // part of the lane offset
-        const buf_rsrc zr = make_rsrc(a.z + (size_t)b * FZ_CO * a.P + p0, 0x7fffffffu);
-        const float* vr = yl + 4 * h * VW;
-        const float lyc = 1.f - ly;
-        // the two 32-pixel column blocks of the chunk one after the other (one 16-register accumulator at a time)
+        FZ_T(2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x16 acc;
+            f32x16& acc = acc2[j];
+            const f32x16& accp = acc2[j ^ 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // eight half-blocks of 8 k-steps; the B operand of half-block t + 1 is requested before the 8 MFMAs of t are issued
+            // eight half-blocks of 8 k-steps; the B operand of half-block t + 1 (and the LDS operands of the pending epilogue's rows
+            // 2 t, 2 t + 1) are requested before the 8 MFMAs of t are issued
             const float* col = fs + ((size_t)buf * FZ_CS + h) * FZ_PX + 32 * j + li;
             float bq[2][8];
             auto read_half = [&](int t, float* d) {
@@ -150,59 +226,56 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
                 for (int s = 0; s < 8; ++s) d[s] = col[(size_t)(2 * (8 * t + s)) * FZ_PX];
             };
             read_half(0, bq[0]);
+            if (have_pending) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t < 7) read_half(t + 1, bq[(t + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < 8; ++t) {
+                    if (t < 7) read_half(t + 1, bq[(t + 1) & 1]);
+                    if ((t & 1) == 0) epi_read(pend, t >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) acc = mfma32(wf[8 * t + s], bq[t & 1][s], acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // epilogue: + bilinear(y_low), centred statistics, write-through stores (rows of 128 contiguous bytes per lane half)
-            int x0, x1;
-            float lx;
-            bilinear_taps(ox0 + 32 * j + li, a.rw, a.Wl, x0, x1, lx);
-            const int voff = ((32 * wave + 4 * h) * a.P + 32 * j + li) * 4;
-            if (u == u_lo && j == 0) {   // the pivots: the first value of each of the wave's rows (lane 0 of each half)
+                    for (int s = 0; s < 8; ++s) acc = mfma32(bq[t & 1][s], wf[8 * t + s], acc);
+                    if ((t & 1) == 0) {
+                        epi_compute(pend, accp, t >> 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float* v = vr + acc_row(r) * VW;
-                    const float v0 = lyc * v[x0] + ly * v[32 * VW + x0], v1 = lyc * v[x1] + ly * v[32 * VW + x1];
-                    if (li == 0) pivot[16 * h + r] = acc[r] + ((1.f - lx) * v0 + lx * v1);
+                        for (int s = 0; s < 8; ++s) {   // program order: one MFMA, four VALU, one MFMA, ...
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t < 7) read_half(t + 1, bq[(t + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = mfma32(bq[t & 1][s], wf[8 * t + s], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* v = vr + acc_row(r) * VW;
-                const float v0 = lyc * v[x0] + ly * v[32 * VW + x0], v1 = lyc * v[x1] + ly * v[32 * VW + x1];
-                const float val = acc[r] + ((1.f - lx) * v0 + lx * v1);
-                const float d = val - pivot[16 * h + r];
-                s1[r] += d;
-                s2[r] = fmaf(d, d, s2[r]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), zr, voff, acc_row(r) * a.P * 4, 16);
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 16 LDS reads in flight, not 64 (registers)
-            }
+            FZ_T(3 + 2 * j);
+            pend = make_pending(b, p0, oy, ox0, j);
+            have_pending = true;
+            FZ_T(4 + 2 * j);
         }
         if (u + 1 < u_hi) store_chunk(buf ^ 1);
+        FZ_T(7);
         __syncthreads();
+        FZ_T(8);
         b = nb, p0 = np0, oy = noy, ox0 = nox0;
     }
-    if (a.stat_part) {   // one cross-lane reduction per workgroup: the 32 lanes of a half hold the same 16 rows
-        const double n = 64.0 * (double)(u_hi - u_lo);   // values per channel in this workgroup's run
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double d1 = (double)s1[r], d2 = (double)s2[r];
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) {
-                d1 += __shfl_xor(d1, o, 64);
-                d2 += __shfl_xor(d2, o, 64);
-            }
-            if (li == 0) {
-                const double pv = (double)pivot[16 * h + r];
-                const int c = 32 * wave + acc_row(r) + 4 * h;
-                a.stat_part[(size_t)c * a.nwg + blockIdx.x] = d1 + n * pv;
-                a.stat_part[((size_t)FZ_CO + c) * a.nwg + blockIdx.x] = d2 + 2.0 * pv * d1 + n * pv * pv;
-            }
+    if (have_pending) epi_full(pend, acc2[1]);
+    if (a.stat_part) {   // the two halves of the wave hold the same channel: shift back, add (in double), one pair per workgroup
+        const double n = 32.0 * (double)(u_hi - u_lo);   // values per lane over the run: 16 per block
+        const double pv = (double)pivot, d1 = (double)s1, d2 = (double)s2;
+        double t1 = d1 + n * pv, t2 = d2 + 2.0 * pv * d1 + n * pv * pv;
+        t1 += __shfl_xor(t1, 32, 64);
+        t2 += __shfl_xor(t2, 32, 64);
+        if (h == 0) {
+            const int c = 32 * wave + li;
+            a.stat_part[(size_t)c * a.nwg + blockIdx.x] = t1;
+            a.stat_part[((size_t)FZ_CO + c) * a.nwg + blockIdx.x] = t2;
         }
     }
 }
@@ -210,7 +283,7 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
 // ---- host side -------------------------------------------------------------------------------------------------------------
 bool ffm_fwd_fused_supported(int B, int Cs, int Co, int H, int W, int Hl, int Wl) {
     const long long P = (long long)H * W;
-    return Co == FZ_CO && Cs == FZ_CS && B > 0 && (W % FZ_PX) == 0 && Wl >= 1 && Wl <= FZ_WL && Hl >= 1 &&
+    return Co == FZ_CO && Cs == FZ_CS && B > 0 && (W % FZ_PX) == 0 && Wl >= 4 && Wl <= FZ_WL && (Wl & 3) == 0 && W == 4 * Wl && Hl >= 1 &&
            (size_t)FZ_CO * P * sizeof(float) < 0x7fffffffull;   // one image's z rows inside a buffer resource
 }
 int ffm_fwd_fused_nwg(int B, int P) {
@@ -227,7 +300,7 @@ hipError_t ffm_fwd_fused_run(const float* fsp, const float* w, int ldw, const fl
     a.total_units = B * (a.P / FZ_PX);
     a.units_per_wg = ceil_div(a.total_units, 256);
     a.nwg = ceil_div(a.total_units, a.units_per_wg);
-    const size_t lds = ((size_t)2 * FZ_CS * FZ_PX + (size_t)8 * 2 * 32 * FZ_VW + 8 * 32) * sizeof(float);
+    const size_t lds = ((size_t)2 * FZ_CS * FZ_PX + (size_t)8 * 2 * 32 * FZ_VW) * sizeof(float);
     static lds_attr_mask mask{0};
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ffm_fwd_z_kernel), 160 * 1024, mask); e != hipSuccess) return e;
     hipLaunchKernelGGL(ffm_fwd_z_kernel, dim3(a.nwg), dim3(512), lds, stream, a);
@@ -235,3 +308,9 @@ hipError_t ffm_fwd_fused_run(const float* fsp, const float* w, int ldw, const fl
 }
 
 }  // namespace cabinet
+
+#ifdef FZ_TRACE
+extern "C" int cabinet_debug_fz_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cabinet::fz_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+#endif

@@ -23,16 +23,23 @@ bw, bb = torch.rand(Co, generator=gen).cuda() + 0.5, torch.rand(Co, generator=ge
 rm, rv = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
 out, z, mean, invstd, pooled, gate = Fn.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)
 args = (g, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)
+fwd = len(sys.argv) > 1 and sys.argv[1] == "fwd"   # the forward kernel (ffm_fwd_fused.hip, -DFZ_TRACE) instead
 for _ in range(3):
-    Fn.ffm_up_bwd_hip(*args)
+    if fwd:
+        Fn.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5)
+    else:
+        Fn.ffm_up_bwd_hip(*args)
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 2 * 32 * 16
 buf = (ctypes.c_ulonglong * n)()
-lib.cabinet_debug_xw_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-rc = lib.cabinet_debug_xw_trace(buf, n)
+fn = lib.cabinet_debug_fz_trace if fwd else lib.cabinet_debug_xw_trace
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = fn(buf, n)
 assert rc == 0, rc
 names = ["store_dx", "advance+load", "(seg)", "dW 64 MFMA", "dX 64 MFMA", "hand_over", "store_chunk", "barrier", "->next top"]
+if fwd:
+    names = ["load issue", "y_low rows", "MFMA j=0", "epilogue 0", "MFMA j=1", "epilogue 1", "store_chunk", "barrier", "->next top"]
 for wv in range(2):
     print(f"wave {4 * wv}:  chunk  " + "  ".join(f"{x:>12s}" for x in names[:8]) + "   total")
     for c in range(18):
