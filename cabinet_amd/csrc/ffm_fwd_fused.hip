@@ -155,11 +155,50 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
         }
     };
 
+    // staging of two y_low rows (32 channels x Wl floats each) as 16-byte pieces: all (<= 8) loads in flight together, kept in
+    // registers until the chunk that needs them starts.  (Dword loads in four dependent batches at the point of use:
+    // 16000-27000 cycles per reload in tools/xw_trace.py, a fifth of the kernel; 16-byte loads at the point of use: 8000-9500.)
+    f32x4 yt0[4], yt1[4];
+    auto yl_issue = [&](int b_, int y0_, int y1_) {
+        const float* src = a.ylow + ((size_t)b_ * FZ_CO + 32 * wave) * a.Hl * a.Wl;
+        const int ppr = a.Wl >> 2, np = 32 * ppr;   // pieces per row; per source row over the 32 channels (<= 256)
+        const float inv_ppr = 1.f / (float)ppr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pcl = min(lane + 64 * k, np - 1);
+            const int ml = idiv_small(pcl, inv_ppr), piece = pcl - ml * ppr;
+            const float* sp = src + (size_t)ml * a.Hl * a.Wl + 4 * piece;
+            if (64 * k < np) {   // wave-uniform
+                yt0[k] = *reinterpret_cast<const f32x4*>(sp + y0_ * a.Wl);
+                yt1[k] = *reinterpret_cast<const f32x4*>(sp + y1_ * a.Wl);
+            }
+        }
+    };
+    auto yl_commit = [&]() {
+        const int ppr = a.Wl >> 2, np = 32 * ppr;
+        const float inv_ppr = 1.f / (float)ppr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pc = lane + 64 * k;
+            if (pc < np) {
+                const int ml = idiv_small(pc, inv_ppr), off = ml * VW + 4 * (pc - ml * ppr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yl[off + e] = yt0[k][e], yl[32 * VW + off + e] = yt1[k][e];
+            }
+        }
+    };
+
     // position of unit u: image b, first pixel p0 = (row oy, column ox0)
     int b = u_lo / cpi, p0 = (u_lo - b * cpi) * FZ_PX;
     int oy = p0 / a.W, ox0 = p0 - oy * a.W, yl_y0 = -1, yl_y1 = -1, yl_b = -1;
     const float* fbase = a.fsp + (size_t)b * FZ_CS * a.P + p0;
     load_chunk(fbase);
+    {
+        int y0, y1;
+        float ly;
+        bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
+        yl_issue(b, y0, y1);   // committed by the first iteration
+    }
     store_chunk(0);
     __syncthreads();
     // Software pipeline over the blocks (chunk u, column block j): the MFMAs of a block run with the epilogue of the PREVIOUS
@@ -175,40 +214,28 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
         int nb = b, np0 = p0 + FZ_PX, noy = oy, nox0 = ox0 + FZ_PX;
         if (nox0 == a.W) nox0 = 0, noy += 1;
         if (np0 == a.P) np0 = 0, nb += 1, noy = 0, nox0 = 0;
-        if (u + 1 < u_hi) load_chunk(a.fsp + (size_t)nb * FZ_CS * a.P + np0);
         FZ_T(1);
         // the two y_low rows under this output row for the wave's 32 channels (wave-private: no barrier); they change every
-        // fourth output row, so a run of a few rows reloads them once or twice: 2 x 32 x Wl floats as 16-byte pieces, all (<= 8)
-        // loads in flight together.  The pending epilogue still reads the OLD rows: it is finished first (not overlapped).
+        // fourth output row, so a run of a few rows reloads them once or twice.  The pending epilogue still reads the OLD rows:
+        // it is finished first (not overlapped); the new rows were requested one chunk ahead (yl_issue below) and only have to
+        // be written to LDS here.
         int y0, y1;
         float ly;
         bilinear_taps(oy, a.rh, a.Hl, y0, y1, ly);
         if (y0 != yl_y0 || y1 != yl_y1 || b != yl_b) {
             if (have_pending) epi_full(pend, acc2[1]);   // the pending block is always a j = 1 block here
             have_pending = false;
-            const float* src = a.ylow + ((size_t)b * FZ_CO + 32 * wave) * a.Hl * a.Wl;
-            const int ppr = a.Wl >> 2, np = 32 * ppr;   // pieces per row; per source row over the 32 channels (<= 256)
-            const float inv_ppr = 1.f / (float)ppr;
-            f32x4 t0[4], t1[4];
-            int off[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int pc = lane + 64 * k, pcl = min(pc, np - 1);
-                const int ml = idiv_small(pcl, inv_ppr), piece = pcl - ml * ppr;
-                const float* sp = src + (size_t)ml * a.Hl * a.Wl + 4 * piece;
-                off[k] = pc < np ? ml * VW + 4 * piece : -1;
-                if (64 * k < np) {   // wave-uniform
-                    t0[k] = *reinterpret_cast<const f32x4*>(sp + y0 * a.Wl);
-                    t1[k] = *reinterpret_cast<const f32x4*>(sp + y1 * a.Wl);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (64 * k < np && off[k] >= 0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) yl[off[k] + e] = t0[k][e], yl[32 * VW + off[k] + e] = t1[k][e];
-                }
+            yl_commit();
             yl_y0 = y0, yl_y1 = y1, yl_b = b;
+        }
+        // (the next chunk's loads go out BEHIND the commit: in front of it, the commit's wait for the staged rows -- vmcnt counts
+        // in order -- became a wait for these loads too: 6000-12000 cycles per reload)
+        if (u + 1 < u_hi) {   // does the next chunk need other rows?  Request them now: a chunk's worth of MFMAs hides the trip
+            load_chunk(a.fsp + (size_t)nb * FZ_CS * a.P + np0);
+            int ny0, ny1;
+            float nly;
+            bilinear_taps(noy, a.rh, a.Hl, ny0, ny1, nly);
+            if (ny0 != yl_y0 || ny1 != yl_y1 || nb != yl_b) yl_issue(nb, ny0, ny1);
         }
         FZ_T(2);
 #pragma unroll
