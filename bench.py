@@ -240,7 +240,7 @@ def kernel_cases(batch, height, width=None, classes=8, extra=False):
     upb = lambda: Fh.ffm_up_bwd_hip(dout, fsp, low, wb, bw, bb, w1, w2, z, mean, invstd, pooled, gate, True)  # noqa: E731
     fl_b = 4.0 * B * Co * (P * Cs + Pl * Cc)
     by_b = 4.0 * B * (P * (2 * Co + 3 * Co + Co + Cs + Co + Co + Cs) + Pl * (Co + Co + Cc + Co + Cc))
-    yield ("ffm_up_bwd (K4': reduce, U^T dz with dz in flight, dfsp + dlow + dW from one staged dz tile, slab sum)", upb, fl_b, by_b, "hbm")
+    yield ("ffm_up_bwd (K4': reduce + three adjoint fields, dz_low, dfsp + dlow + dW with dz formed while staged, slab sum)", upb, fl_b, by_b, "hbm")
     del fsp, dout, o, z, low
     torch.cuda.empty_cache()
 
@@ -348,12 +348,15 @@ _NOTES = {
     "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
                     ": it replaces recomputing S and dP for dq (4.3 GFLOP)",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
-    "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel), not HBM",
+    "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel, one log-sum-exp "
+                        "shift per source interval), not HBM",
     "ohem_up_pair_bwd": "what the step runs: both heads per launch; x pass VALU bound (fma + sub + exp + 2 fma per pixel and "
                         "class), y pass HBM bound (T written once, read once)",
-    "ffm_up_bwd": "bound by its two 8.6 GFLOP products on the 1/16-rate fp32 matrix pipe (109 us at peak) between two HBM passes "
-                  "(reduce; upsample adjoint computing dz in flight)",
-    "ffm_up_fwd": "z product (fp32 MFMA, write-through output stores) + three HBM passes over z that BatchNorm's batch statistics force",
+    "ffm_up_bwd": "bound by its two 8.6 GFLOP products on the 1/16-rate fp32 matrix pipe (109 us at peak) behind ONE HBM pass "
+                  "(the reduction, which also takes the resize adjoint of three coefficient-free fields); dz is never stored, so "
+                  "the measured traffic is below the algorithmic bytes of SURVEY 8(d)'s pass structure",
+    "ffm_up_fwd": "persistent z product (fp32 MFMA) with the BatchNorm sums in its epilogue + two HBM passes over z (pool, gate) "
+                  "that BatchNorm's batch statistics force",
     "ohem_up_bwd": "exp and VALU bound (softmax recomputed per pixel), not HBM",
     "bn_dwconv_fwd": "the depthwise stencil is VALU bound; the BatchNorm statistics pass is HBM bound",
     "bn_dwconv_bwd": "the depthwise stencil backward is VALU bound; the BatchNorm dx pass is HBM bound",

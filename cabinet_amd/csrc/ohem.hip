@@ -192,16 +192,29 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
         // lerp is one fma on a difference formed once per source interval, exp2 needs no scaling multiply, and the label's
         // logit is gathered from LDS (rows are Wl floats apart and lanes walk consecutive columns: conflict-free whatever the
         // labels) instead of a compare + select per class.
-        float xc[NH][CMAX], dm[NH][CMAX], dp[NH][CMAX];
+        // Round 4: the log-sum-exp of all eight pixels is shifted by ONE bound per interval instead of a maximum per pixel:
+        // every upsampled logit is a convex combination of the interval's taps, so M = max over classes and taps bounds them
+        // all (3 C maxima per interval instead of 8 C), and with xc - M staged once the per-pixel-and-class work is
+        // fma + exp2 + add (it was fma + max + sub + exp2 + add).  M exceeds a pixel's own maximum by at most the spread of
+        // neighbouring source columns: exp2 of a few tens below zero, nowhere near underflow.
+        float xc[NH][CMAX], dm[NH][CMAX], dp[NH][CMAX], big[NH];
         const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
 #pragma unroll
-        for (int hh = 0; hh < NH; ++hh)
+        for (int hh = 0; hh < NH; ++hh) {
+            float m3 = -INFINITY;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
                 if (EXACT || c < C) {
                     const float* vc = v + hh * CW + c * Wl;
-                    xc[hh][c] = vc[g], dm[hh][c] = vc[g] - vc[gm], dp[hh][c] = vc[gp] - vc[g];
+                    const float a = vc[gm], bq = vc[g], cq = vc[gp];
+                    xc[hh][c] = bq, dm[hh][c] = bq - a, dp[hh][c] = cq - bq;
+                    m3 = fmaxf(m3, fmaxf(a, fmaxf(bq, cq)));
                 }
+            big[hh] = m3;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (EXACT || c < C) xc[hh][c] -= m3;
+        }
         float out[NH][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -221,18 +234,11 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
                 if (valid) {
                     const float* vl = v + hh * CW + lrow;
                     const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);
-                    float x[CMAX], mx = -INFINITY;
-#pragma unroll
-                    for (int c = 0; c < CMAX; ++c)
-                        if (EXACT || c < C) {
-                            x[c] = fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]);
-                            mx = fmaxf(mx, x[c]);
-                        }
                     float se = 0.f;
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c)
-                        if (EXACT || c < C) se += fast_exp2(x[c] - mx);
-                    loss = ((mx - xl) + fast_log2(se)) * LN2_F;
+                        if (EXACT || c < C) se += fast_exp2(fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]));
+                    loss = ((big[hh] - xl) + fast_log2(se)) * LN2_F;
                     if (loss > thresh) {
                         my_above[hh] += 1;
                         my_sum[hh] += loss;
