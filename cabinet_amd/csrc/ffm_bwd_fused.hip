@@ -19,6 +19,13 @@
 // lanes 32-63: the 16 values a lane needs for the 16 k-steps of a chunk are then 16 CONSECUTIVE floats of its row in plain
 // pixel order = four 16-byte LDS reads (row pitch 36 floats: conflict-free for ds_read_b128), and the staged rows need no
 // re-ordering at all.  The dX product reads the same rows with the pixel on the lane (consecutive words: conflict-free).
+// The full-resolution dz is not read but FORMED here: the segment's "dz" pointer is z, the incoming gradient g = dout rides
+// along, and dz = gi (mask (g a1 + a2) - mdy - xhat mdyx) (ffm.hip::ffm_dz_kernel's expression, operation for operation) is
+// evaluated on the staged registers between the MFMAs of the dX product, per-channel coefficients from an LDS table -- the
+// low-resolution operand dz_low = U^T dz comes from ffm_bwd_adj.hip by linearity, so nothing else needs dz and its 134 MB
+// are neither written nor read back.  The next chunk's loads and the previous chunk's dX stores are dealt over the half-blocks
+// of the dW product: issued in one piece at the top of a chunk they kept every wave at its next load for 2000-5000 of the
+// chunk's 23000 cycles with no MFMA in flight (tools/xw_trace.py: cycle stamps at the phase boundaries, -DXW_TRACE).
 // Work is dealt in equal contiguous runs of chunks over <= 256 workgroups (one per CU); a workgroup writes its dW tile as
 // one slab per segment it touched, and an ordered slab sum finishes dW: no atomics, bit-reproducible.
 // (Measured and not kept: walking the full-resolution segment TRANSPOSED -- step j of workgroup i = chunk 228 j + i, so that

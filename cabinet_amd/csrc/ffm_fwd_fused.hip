@@ -8,18 +8,26 @@
 // 134 MB store phase does not overlap the matrix phase: 94 us at 0.55 MFMA busy) and then read z back for the statistics
 // (bn_rowstats, 22 us; an in-epilogue reduction per tile cost 60 us more, DESIGN_HISTORY.md).  Here, as in ffm_bwd_fused.hip:
 //   * <= 256 workgroups (one per CU) each walk a contiguous run of 64-pixel chunks; wave w owns output channels 32 w .. + 31
-//     and keeps its A operand W_s[o][c] (64 values per lane) in registers for the whole run; a chunk of fsp (128 x 64) is
-//     staged in LDS once and read with the pixel on the lane (consecutive words: conflict-free), two column blocks per wave;
-//   * the upsample term needs, per output row, two y_low rows for the wave's 32 channels: kept in a wave-private LDS image
-//     (reloaded when the row pair changes: every fourth output row), the four taps are combined in the epilogue;
-//   * the statistics are accumulated PER LANE over the whole run and reduced across lanes ONCE at the end (a persistent
-//     kernel pays the cross-lane reduction per workgroup, not per tile).  A lane sums at most a few dozen values per channel,
-//     so it does so in fp32 -- but of z MINUS A PIVOT (the first value the workgroup sees of that channel, kept in LDS):
-//     var = E[z^2] - mean^2 loses (mean / std)^2 ulps in fp32 (test_ffm_bn_statistics_with_large_channel_means: mean =
-//     100 std), the centred sums do not; 32 double accumulators per lane did not fit the register file beside W and the
-//     tile.  The lane sums are widened to double, reduced, shifted back (sum z = S1 + n p, sum z^2 = S2 + 2 p S1 + n p^2) and
-//     one pair per workgroup and channel goes to stat_part[2][C][nwg], summed in a fixed order by ffm_pool's finalize;
-//   * z leaves with write-through stores (common.hpp::store_wt: no dirty L2 line in the way of the fsp stream).
+//     and keeps W_s[o][c] (64 values per lane) in registers for the whole run; a chunk of fsp (128 x 64) is staged in LDS once
+//     and read with the pixel on the lane (consecutive words: conflict-free), two 32-pixel column blocks per wave;
+//   * the PIXEL is the MFMA's row and the channel its column (A = staged fsp, B = W): a lane holds ONE channel and four runs
+//     of four consecutive pixels per block, so z leaves in 16-byte stores and the statistics are two scalars per lane;
+//   * software pipeline: the epilogue of block n (bilinear(y_low) added, statistics, stores) sits between the MFMAs of block
+//     n + 1 (two accumulators, alternating);
+//   * the upsample term needs, per output row, two y_low rows for the wave's 32 channels: kept in a wave-private LDS image,
+//     requested one chunk ahead when the row pair changes (every fourth output row); a quad of pixels is the footprint of
+//     one source column, so its six taps are read once and combined with the x4 constants;
+//   * statistics: a lane sums (z - pivot) and (z - pivot)^2 in fp32 over its <= few hundred values, pivot = its first value:
+//     var = E[z^2] - mean^2 loses (mean / std)^2 ulps in fp32 (test_ffm_fwd_fused_statistics_with_large_channel_means: mean =
+//     130 std), the centred sums do not.  At the end they are widened to double, shifted back (sum z = S1 + n p, sum z^2 =
+//     S2 + 2 p S1 + n p^2), the two halves of the wave added, and one pair per workgroup and channel goes to
+//     stat_part[2][C][nwg], summed in a fixed order by ffm_pool's finalize.
+// What tools/xw_trace.py (cycle stamps at the phase boundaries, -DFZ_TRACE) showed on the way: y_low rows fetched with dword
+// loads in dependent batches cost 16000-27000 cycles per reload; with the channel on the MFMA row a block's epilogue (16 dword
+// stores, 80 LDS reads, 32 accumulating registers) took 6000 cycles against 4200 for its 64 MFMAs, all of it exposed; a wait
+// for staged rows placed behind the next chunk's loads waits for those too (vmcnt counts in order).  What is left: two waves
+// per SIMD share the matrix pipe at ~0.77 busy (chunk boundary: LDS write -> barrier -> first operand reads with no MFMA in
+// flight), at ~1.9 GHz under this load rather than the 2.4 GHz the 157 TFLOP/s peak assumes.
 // Exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
 #include "blocks.hpp"
 #include "common.hpp"
