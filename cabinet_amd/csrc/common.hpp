@@ -6,6 +6,7 @@
 #include <stddef.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_32x32x2_f32: exact-fp32 matrix FMA, D(32x32) += A(32x2) * B(2x32).

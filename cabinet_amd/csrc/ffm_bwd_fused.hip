@@ -367,22 +367,27 @@ struct XwSumArgs {
     int col_off[XW_MAXSEG], wg_lo[XW_MAXSEG], wg_hi[XW_MAXSEG];
 };
 __global__ __launch_bounds__(256) void ffm_bwd_xw_sum_kernel(XwSumArgs a) {
-    // one element per thread, eight slabs in flight, ascending order in eight interleaved partial sums (a fixed association).
-    // (Four elements per thread with 16-byte loads left 96 workgroups for 34 MB: 33 us against 13.5 -- reverted.)
-    const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;   // i over XW_CO * XW_CX
-    if (k >= a.nseg || i >= XW_CO * XW_CX) return;
+    // 64 elements per workgroup; the slab range of the segment in four quarters, one wave each: eight slabs in flight per
+    // thread, ascending order in eight interleaved partial sums, then the four quarters in order through LDS -- a fixed
+    // association, whatever the placement.  (One element per thread over the whole range was one chain of 228 loads, eight in
+    // flight: 14 us for 34 MB; four elements per thread with 16-byte loads left 96 workgroups: 33 us.)
+    __shared__ float part[4][64];
+    const int k = blockIdx.y, e = threadIdx.x & 63, qt = threadIdx.x >> 6, i = blockIdx.x * 64 + e;   // i over XW_CO * XW_CX
+    if (k >= a.nseg) return;
     const size_t stride = (size_t)XW_CO * XW_CX;
+    const int n = a.wg_hi[k] - a.wg_lo[k] + 1, per = (n + 3) >> 2, lo = qt * per, hi = min(n, lo + per);
     const float* p = a.slabs + (size_t)(a.wg_lo[k] + k) * stride + i;
-    const int n = a.wg_hi[k] - a.wg_lo[k] + 1;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
-    int w = 0;
-    for (; w + 7 < n; w += 8) {
+    int w = lo;
+    for (; w + 7 < hi; w += 8) {
         s0 += p[(size_t)w * stride], s1 += p[(size_t)(w + 1) * stride], s2 += p[(size_t)(w + 2) * stride];
         s3 += p[(size_t)(w + 3) * stride], s4 += p[(size_t)(w + 4) * stride], s5 += p[(size_t)(w + 5) * stride];
         s6 += p[(size_t)(w + 6) * stride], s7 += p[(size_t)(w + 7) * stride];
     }
-    for (; w < n; ++w) s0 += p[(size_t)w * stride];
-    a.out[(size_t)(i / XW_CX) * a.ldo + a.col_off[k] + (i % XW_CX)] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    for (; w < hi; ++w) s0 += p[(size_t)w * stride];
+    part[qt][e] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    __syncthreads();
+    if (qt == 0) a.out[(size_t)(i / XW_CX) * a.ldo + a.col_off[k] + (i % XW_CX)] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -436,7 +441,7 @@ hipError_t ffm_bwd_fused_run(const float* dz, const float* dzl, const float* fsp
     static lds_attr_mask mask{0};
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ffm_bwd_xw_kernel), lds, mask); e != hipSuccess) return e;
     hipLaunchKernelGGL(ffm_bwd_xw_kernel, dim3(nwg), dim3(512), lds, stream, a);
-    hipLaunchKernelGGL(ffm_bwd_xw_sum_kernel, dim3(XW_CO * XW_CX / 256, a.nseg), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL(ffm_bwd_xw_sum_kernel, dim3(XW_CO * XW_CX / 64, a.nseg), dim3(256), 0, stream, sa);
     return hipGetLastError();
 }
 
