@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
         // all (3 C maxima per interval instead of 8 C), and with xc - M staged once the per-pixel-and-class work is
         // fma + exp2 + add (it was fma + max + sub + exp2 + add).  M exceeds a pixel's own maximum by at most the spread of
         // neighbouring source columns: exp2 of a few tens below zero, nowhere near underflow.
+        // (Measured and not kept, here and in the backward's x pass: two pixels per step as packed 2-vectors -- v_pk_fma_f32 /
+        // v_pk_add_f32 halve the non-transcendental issue slots, and the time did not move: 75.7 vs 74.5 us, 72.2 vs 68.8 us.
+        // These kernels are bound by v_exp_f32 (quarter rate) and by the load -> barrier start of their short workgroups.)
         float xc[NH][CMAX], dm[NH][CMAX], dp[NH][CMAX], big[NH];
         const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
 #pragma unroll
@@ -215,32 +218,12 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
             for (int c = 0; c < CMAX; ++c)
                 if (EXACT || c < C) xc[hh][c] -= m3;
         }
-        // pixel j of the interval: x = xm + t (xc - xm) = xc - (1 - t)(xc - xm), t = (j + 4.5)/8, for j < 4;
-        //                          x = xc + t (xp - xc),                          t = (j - 3.5)/8, for j >= 4
-        auto tap_t = [](int j) { return j < 4 ? -(1.f - ((float)j + 4.5f) * 0.125f) : ((float)j - 3.5f) * 0.125f; };
-        // The sums of exponentials first, two pixels of the same half per step as 2-vectors: the fma and the accumulation are
-        // packed instructions (v_pk_fma_f32 / v_pk_add_f32: one issue slot for two pixels), only exp2 stays per value.  Every
-        // pixel is evaluated (an ignored one costs the same as a lane idling in a divergent branch) and masked afterwards.
-        float se[NH][8];
-#pragma unroll
-        for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                const f32x2 tt = {tap_t(2 * jp), tap_t(2 * jp + 1)};
-                f32x2 acc = {0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (EXACT || c < C) {
-                        const float d = jp < 2 ? dm[hh][c] : dp[hh][c];
-                        const f32x2 x = __builtin_elementwise_fma(tt, f32x2{d, d}, f32x2{xc[hh][c], xc[hh][c]});
-                        acc += f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
-                    }
-                se[hh][2 * jp] = acc[0], se[hh][2 * jp + 1] = acc[1];
-            }
         float out[NH][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float t = tap_t(j);
+            // pixel j of the interval: x = xm + t (xc - xm) = xc - (1 - t)(xc - xm), t = (j + 4.5)/8, for j < 4;
+            //                          x = xc + t (xp - xc),                          t = (j - 3.5)/8, for j >= 4
+            const float t = j < 4 ? -(1.f - ((float)j + 4.5f) * 0.125f) : ((float)j - 3.5f) * 0.125f;
             const bool valid = lb[j] != (long long)ignore_lb;
             const bool inrange = lb[j] >= 0 && lb[j] < (long long)C;
             // a label outside [0, C) that is not ignore_lb is an error (F.cross_entropy asserts on it): a separate flag,
@@ -250,12 +233,19 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
             const int lrow = inrange ? (int)lb[j] * Wl : 0;
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) {
-                const float* vl = v + hh * CW + lrow;
-                const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);
-                const float loss = valid ? ((big[hh] - xl) + fast_log2(se[hh][j])) * LN2_F : 0.f;
-                if (loss > thresh) {   // (thresh > 0: an ignored pixel's 0 never counts)
-                    my_above[hh] += 1;
-                    my_sum[hh] += loss;
+                float loss = 0.f;
+                if (valid) {
+                    const float* vl = v + hh * CW + lrow;
+                    const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);
+                    float se = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (EXACT || c < C) se += fast_exp2(fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]));
+                    loss = ((big[hh] - xl) + fast_log2(se)) * LN2_F;
+                    if (loss > thresh) {
+                        my_above[hh] += 1;
+                        my_sum[hh] += loss;
+                    }
                 }
                 out[hh][j] = loss;
             }
@@ -565,30 +555,22 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x8row_kernel(OhemBwdHeads hd,
         for (int u = 0; u < IPL; ++u) {
             const int g = g0 + u;
             const float xc = vc[g], dm = xc - vc[max(g - 1, 0)], dp = vc[min(g + 1, Wl - 1)] - xc;
-            // two pixels of the same half per step as 2-vectors: logit, shift and the two weighted sums are packed instructions
-            // (one issue slot for two pixels; this pass is VALU-issue bound), only exp2 stays per value.  Even and odd pixels
-            // accumulate separately and are added at the end: a fixed order.
-            f32x2 L2 = {0.f, 0.f}, M2 = {0.f, 0.f}, R2 = {0.f, 0.f};
+            float L = 0.f, M = 0.f, R = 0.f;
 #pragma unroll
-            for (int jp = 0; jp < 4; ++jp) {
-                const int j0 = 2 * jp;
-                const float la = jp < 2 ? ((float)j0 + 4.5f) * 0.125f : ((float)j0 - 3.5f) * 0.125f, lb = la + 0.125f;
-                const f32x2 lam = {la, lb}, one_m = {1.f - la, 1.f - lb};
-                const f32x2 tt = jp < 2 ? -one_m : lam;
-                const float d = jp < 2 ? dm : dp;
-                const f32x2 x = __builtin_elementwise_fma(tt, f32x2{d, d}, f32x2{xc, xc}) - f32x2{lr[8 * u + j0], lr[8 * u + j0 + 1]};
-                const f32x2 e = {fast_exp2(x[0]), fast_exp2(x[1])};
-                if (jp < 2) {
-                    L2 = __builtin_elementwise_fma(one_m, e, L2);
-                    M2 = __builtin_elementwise_fma(lam, e, M2);
+            for (int j = 0; j < 8; ++j) {
+                const float lam = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+                const float e = fast_exp2(fmaf(j < 4 ? -(1.f - lam) : lam, j < 4 ? dm : dp, xc) - lr[8 * u + j]);
+                if (j < 4) {
+                    L = fmaf(1.f - lam, e, L);
+                    M = fmaf(lam, e, M);
                 } else {
-                    M2 = __builtin_elementwise_fma(one_m, e, M2);
-                    R2 = __builtin_elementwise_fma(lam, e, R2);
+                    M = fmaf(1.f - lam, e, M);
+                    R = fmaf(lam, e, R);
                 }
             }
-            Lg[u] = coef * ((L2[0] + L2[1]) - ohL[c * Wl + g]);
-            Mg[u] = coef * ((M2[0] + M2[1]) - ohM[c * Wl + g]);
-            Rg[u] = coef * ((R2[0] + R2[1]) - ohR[c * Wl + g]);
+            Lg[u] = coef * (L - ohL[c * Wl + g]);
+            Mg[u] = coef * (M - ohM[c * Wl + g]);
+            Rg[u] = coef * (R - ohR[c * Wl + g]);
         }
         // T[xs] = R_{xs-1} + M_xs + L_{xs+1}; the clamped taps of the first / last column fold L_0 / R_{Wl-1} into that column
         float rprev = __shfl_up(Rg[IPL - 1], 1, 64), lnext = __shfl_down(Lg[0], 1, 64);
