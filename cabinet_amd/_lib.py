@@ -12,7 +12,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcabinet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
@@ -36,6 +36,7 @@ SIGNATURES = {
     "cabinet_ffm_up_bwd_workspace_bytes": (_SZ, [_INT] * 9),
     "cabinet_ffm_up_bwd": (_INT, [_PTR] * 13 + [_INT] * 9 + [_INT] + [_PTR] * 7 + [_PTR, _SZ, _PTR]),
     "cabinet_ohem_up_blocks": (_INT, [_INT] * 3),
+    "cabinet_ohem_stats": (_INT, [_PTR, _PTR, _INT, _INT, _PTR, _PTR]),
     "cabinet_ohem_up_fwd": (_INT, [_PTR, _PTR] + [_INT] * 6 + [_FLT, _INT] + [_PTR] * 3 + [_PTR]),
     "cabinet_ohem_up_bwd_workspace_bytes": (_SZ, [_INT] * 6),
     "cabinet_ohem_up_bwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_FLT, _INT, _FLT] + [_PTR] + [_PTR, _SZ, _PTR]),

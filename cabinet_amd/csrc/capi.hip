@@ -104,6 +104,7 @@ int ohem_blocks(int B, int H, int W);
 hipError_t ohem_up_fwd_run(int nh, const float* const* low, const long long* labels, int B, int C, int Hl, int Wl, int H, int W,
                            float thresh, int ignore_lb, float* const* loss_px, float* const* blk_sum, int* const* blk_cnt,
                            hipStream_t stream);
+hipError_t ohem_stats_run(const float* blk_sum, const int* blk_cnt, int nheads, int nblk, double* stats, hipStream_t stream);
 size_t ohem_up_bwd_workspace(int B, int C, int H, int Wl);
 bool ohem_up_supported(int C, int Wl, int W);
 hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* labels, const float* const* loss_px, int B, int C,
@@ -369,6 +370,13 @@ int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels, int B,
     return hip_status(cabinet::ohem_up_fwd_run(1, &logits_low, labels, B, C, Hl, Wl, H, W, thresh, ignore_lb, &loss_px, &blk_sum,
                                                &blk_cnt, static_cast<hipStream_t>(stream)),
                       "ohem_up_fwd launch");
+}
+
+int cabinet_ohem_stats(const float* blk_sum, const int* blk_cnt, int nheads, int nblk, double* stats, cabinet_stream_t stream) {
+    if (nheads <= 0 || nheads > 65535 || nblk <= 0) return fail(CABINET_ERR_INVALID_ARG, "ohem_stats: nheads=%d nblk=%d", nheads, nblk);
+    if (!blk_sum || !blk_cnt || !stats) return fail(CABINET_ERR_INVALID_ARG, "ohem_stats: null tensor pointer");
+    return hip_status(cabinet::ohem_stats_run(blk_sum, blk_cnt, nheads, nblk, stats, static_cast<hipStream_t>(stream)),
+                      "ohem_stats launch");
 }
 
 size_t cabinet_ohem_up_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, int W) {

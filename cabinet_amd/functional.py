@@ -408,8 +408,10 @@ def ohem_up_fwd_hip(logits_low, labels, size, thresh, ignore_lb):
     with torch.cuda.device(dev):
         rc = lib.cabinet_ohem_up_fwd(_ptr(logits_low), _ptr(labels), B, C, Hl, Wl, H, W, float(thresh), int(ignore_lb),
                                      _ptr(loss_px), _ptr(blk_sum), _ptr(blk_cnt), _stream_handle(dev))
-    _lib.check(rc, "cabinet_ohem_up_fwd")
-    stats = torch.cat([blk_cnt.sum(dim=0).double(), blk_sum.double().sum().reshape(1)])
+        _lib.check(rc, "cabinet_ohem_up_fwd")
+        stats = torch.empty(3, dtype=torch.float64, device=dev)
+        rc = lib.cabinet_ohem_stats(_ptr(blk_sum), _ptr(blk_cnt), 1, nblk, _ptr(stats), _stream_handle(dev))
+    _lib.check(rc, "cabinet_ohem_stats")
     return loss_px, stats
 
 
@@ -464,8 +466,10 @@ def ohem_up_pair_fwd_hip(low_a, low_b, labels, size, thresh, ignore_lb):
     with torch.cuda.device(dev):
         rc = lib.cabinet_ohem_up_pair_fwd(_ptr(low_a), _ptr(low_b), _ptr(labels), B, C, Hl, Wl, H, W, float(thresh),
                                           int(ignore_lb), _ptr(loss_px), _ptr(blk_sum), _ptr(blk_cnt), _stream_handle(dev))
-    _lib.check(rc, "cabinet_ohem_up_pair_fwd")
-    stats = torch.cat([blk_cnt.sum(dim=1).double(), blk_sum.double().sum(dim=1, keepdim=True)], dim=1)
+        _lib.check(rc, "cabinet_ohem_up_pair_fwd")
+        stats = torch.empty((2, 3), dtype=torch.float64, device=dev)
+        rc = lib.cabinet_ohem_stats(_ptr(blk_sum), _ptr(blk_cnt), 2, nblk, _ptr(stats), _stream_handle(dev))
+    _lib.check(rc, "cabinet_ohem_stats")
     return loss_px, stats
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CABINET_ABI_VERSION 3
+#define CABINET_ABI_VERSION 4
 
 #define CABINET_OK 0
 #define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
@@ -183,6 +183,11 @@ int cabinet_ohem_up_fwd(const float* logits_low, const long long* labels,
                         int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb,
                         float* loss_px, float* blk_sum, int* blk_cnt, cabinet_stream_t stream);
 size_t cabinet_ohem_up_bwd_workspace_bytes(int B, int C, int Hl, int Wl, int H, int W);
+/* The forward's partials reduced on the device (ABI v4): stats (nheads,3) double = per head [#valid, #(loss > thresh), sum of
+ * those losses] from blk_sum (nheads,nblk) and blk_cnt (nheads,nblk,2), nblk = cabinet_ohem_up_blocks(B,H,W).  One launch in
+ * place of the caller's own reductions (loss.py:66-75 takes these three numbers to pick its branch and form the mean); a
+ * negative #valid reports an out-of-range label (see above).  Fixed summation order: bit-reproducible.                      */
+int cabinet_ohem_stats(const float* blk_sum, const int* blk_cnt, int nheads, int nblk, double* stats, cabinet_stream_t stream);
 int cabinet_ohem_up_bwd(const float* logits_low, const long long* labels, const float* loss_px,
                         int B, int C, int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef,
                         float* dlogits_low, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
