@@ -168,6 +168,17 @@ def load_traffic(batch, height, width, classes):
 
 
 def kernel_cases(batch, height, width=None, classes=8, extra=False):
+    """The hand-written kernel groups, with the BatchNorm ``num_batches_tracked += 1`` bookkeeping deferred as the model's
+    forward defers it (``batched_bn_counters``: ONE multi-tensor add per step for the model's 59 counters): outside that
+    context the module-level closures of K5 / K6 carried three / two one-element PyTorch launches per call (6.6 / 7.6 us of
+    their 27 / 76 us) that the step never issues there."""
+    from cabinet_amd import functional as Fh
+
+    with Fh.batched_bn_counters():
+        yield from _kernel_cases(batch, height, width, classes, extra)
+
+
+def _kernel_cases(batch, height, width=None, classes=8, extra=False):
     """(Backward groups call the autograd Function's ``backward`` on the node their forward built: the same C-ABI calls as
     under autograd, issued from this thread on the current stream -- the autograd engine would run them on the forward's
     stream, outside a hipGraph capture.)

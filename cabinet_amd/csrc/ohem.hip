@@ -814,7 +814,16 @@ __global__ __launch_bounds__(256) void ohem_stats_kernel(const float* __restrict
     const int* bc = blk_cnt + (size_t)hh * nblk * 2;
     long long nv = 0, na = 0;
     double sm = 0.0;
-    for (int i = t; i < nblk; i += 256) nv += bc[2 * i], na += bc[2 * i + 1], sm += (double)bs[i];
+    int i = t;
+    for (; i + 7 * 256 < nblk; i += 8 * 256) {   // eight blocks' loads in flight, added in ascending order
+        int2 c[8];
+        float f[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = *reinterpret_cast<const int2*>(bc + 2 * (i + 256 * u)), f[u] = bs[i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nv += c[u].x, na += c[u].y, sm += (double)f[u];
+    }
+    for (; i < nblk; i += 256) nv += bc[2 * i], na += bc[2 * i + 1], sm += (double)bs[i];
     s_v[t] = nv, s_a[t] = na, s_s[t] = sm;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
