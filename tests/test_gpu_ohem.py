@@ -197,3 +197,35 @@ def test_paired_heads_with_one_head_on_the_rare_branch():
         assert abs(float(pair) - float(two)) <= 1e-6 * max(1.0, abs(float(two)))
         assert_close(xa.grad, ya.grad, 1e-6, "head a")
         assert_close(xb.grad, yb.grad, 1e-5, "head b", atol=1e-12)
+
+
+@pytest.mark.parametrize("nheads,nblk", [(1, 1), (2, 8192), (2, 4097), (3, 300)])
+def test_ohem_stats_reduces_the_partials(nheads, nblk):
+    """cabinet_ohem_stats (ABI v4): [n_valid, n_above, sum_above] per head from the forward's per-workgroup partials -- counts
+    exact (64-bit), the sum in double, a block that met an out-of-range label (count -2^30) keeps n_valid negative, and the
+    fixed summation order makes two calls bit-identical."""
+    import ctypes
+
+    from cabinet_amd import _lib
+
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(nblk)
+    blk_sum = (torch.rand(nheads, nblk, generator=gen) * 1e3).cuda()
+    blk_cnt = torch.randint(0, 1025, (nheads, nblk, 2), generator=gen, dtype=torch.int32).cuda()
+    if nblk > 1:
+        blk_cnt[0, nblk // 2, 0] = -(1 << 30)
+    outs = []
+    for _ in range(2):
+        stats = torch.empty((nheads, 3), dtype=torch.float64, device="cuda")
+        rc = lib.cabinet_ohem_stats(ctypes.c_void_p(blk_sum.data_ptr()), ctypes.c_void_p(blk_cnt.data_ptr()), nheads, nblk,
+                                    ctypes.c_void_p(stats.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "cabinet_ohem_stats")
+        outs.append(stats)
+    torch.cuda.synchronize()
+    ref_cnt = blk_cnt.long().sum(dim=1).double()
+    ref_sum = blk_sum.double().sum(dim=1)
+    assert torch.equal(outs[0][:, :2], ref_cnt)
+    assert torch.allclose(outs[0][:, 2], ref_sum, rtol=1e-13, atol=0.0)
+    assert torch.equal(outs[0], outs[1])
+    if nblk > 1:
+        assert float(outs[0][0, 0]) < 0
