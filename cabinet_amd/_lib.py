@@ -12,7 +12,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcabinet_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
@@ -71,6 +71,12 @@ SIGNATURES = {
     "cabinet_pwconv_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR]),
     "cabinet_pwconv_bwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_pwconv_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
+    "cabinet_conv3x3_supported": (_INT, [_INT] * 3),
+    "cabinet_conv3x3_tile_blocks": (_INT, [_INT] * 3),
+    "cabinet_conv3x3_fwd_workspace_bytes": (_SZ, [_INT] * 6),
+    "cabinet_conv3x3_fwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
+    "cabinet_conv3x3_bwd_workspace_bytes": (_SZ, [_INT] * 6),
+    "cabinet_conv3x3_bwd": (_INT, [_PTR] * 4 + [_INT] * 6 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_dwconv_supported": (_INT, [_INT] * 2),
     "cabinet_dwconv_fwd": (_INT, [_PTR] * 2 + [_INT] * 6 + [_PTR] + [_PTR]),
     "cabinet_dwconv_bwd_workspace_bytes": (_SZ, [_INT] * 6),

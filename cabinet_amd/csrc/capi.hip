@@ -110,6 +110,19 @@ bool ohem_up_supported(int C, int Wl, int W);
 hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* labels, const float* const* loss_px, int B, int C,
                            int Hl, int Wl, int H, int W, float thresh, int ignore_lb, float coef, float* dlow, void* ws,
                            hipStream_t stream);
+// conv3x3_wino.hip
+struct WinoShape {
+    int B, C0, C1, K, H, W;
+};
+bool conv3x3_supported(int C0, int C1, int K);
+bool conv3x3_shape_ok(const WinoShape& s);
+int conv3x3_tile_blocks(int B, int H, int W);
+size_t conv3x3_fwd_workspace(const WinoShape& s);
+size_t conv3x3_bwd_workspace(const WinoShape& s);
+hipError_t conv3x3_fwd_run(const WinoShape& s, const float* x0, const float* x1, const float* w, float* y, float* stat_part, void* ws,
+                           hipStream_t stream);
+hipError_t conv3x3_bwd_run(const WinoShape& s, const float* dy, const float* x0, const float* x1, const float* w, float* dx0,
+                           float* dx1, float* dw, void* ws, hipStream_t stream);
 }  // namespace cabinet
 
 static thread_local char g_err[512] = "";
@@ -864,6 +877,61 @@ int cabinet_pwconv_bwd(const float* dy, const float* x, const float* w, int B, i
         return fail(CABINET_ERR_WORKSPACE, "pwconv_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     return hip_status(cabinet::pwconv_bwd_run(dy, x, w, B, Ci, Co, P, dx, dw, workspace, static_cast<hipStream_t>(stream)),
                       "pwconv_bwd launch");
+}
+
+// ------------------------------------------------------ dense 3x3 convolution (Winograd F(2x2,3x3), fp32 MFMA)
+static int check_conv3x3(const cabinet::WinoShape& s, const char* who) {
+    if (s.B <= 0 || s.C0 <= 0 || s.C1 < 0 || s.K <= 0 || s.H <= 0 || s.W <= 0)
+        return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if (!cabinet::conv3x3_shape_ok(s))
+        return fail(CABINET_ERR_UNSUPPORTED,
+                    "%s: C0=%d C1=%d Co=%d H=%d W=%d (C0, C1 multiples of 16; Co, C0+C1 multiples of 64; C0 %% 64 == 0 when C1 > 0; "
+                    "one image's tensors < 2 GB)", who, s.C0, s.C1, s.K, s.H, s.W);
+    return CABINET_OK;
+}
+
+int cabinet_conv3x3_supported(int C0, int C1, int Co) { return cabinet::conv3x3_supported(C0, C1, Co) ? 1 : 0; }
+
+int cabinet_conv3x3_tile_blocks(int B, int H, int W) {
+    return B > 0 && H > 0 && W > 0 ? cabinet::conv3x3_tile_blocks(B, H, W) : 0;
+}
+
+size_t cabinet_conv3x3_fwd_workspace_bytes(int B, int C0, int C1, int Co, int H, int W) {
+    const cabinet::WinoShape s{B, C0, C1, Co, H, W};
+    return B > 0 && H > 0 && W > 0 && cabinet::conv3x3_shape_ok(s) ? cabinet::conv3x3_fwd_workspace(s) : 0;
+}
+
+int cabinet_conv3x3_fwd(const float* x0, const float* x1, const float* w, int B, int C0, int C1, int Co, int H, int W, float* y,
+                        float* bn_part, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    const cabinet::WinoShape s{B, C0, C1, Co, H, W};
+    if (int rc = check_conv3x3(s, "conv3x3_fwd")) return rc;
+    if (!x0 || !w || !y || (C1 > 0 && !x1)) return fail(CABINET_ERR_INVALID_ARG, "conv3x3_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("conv3x3_fwd", x0, x1, w, y, bn_part);
+    const size_t need = cabinet::conv3x3_fwd_workspace(s);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "conv3x3_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::conv3x3_fwd_run(s, x0, C1 > 0 ? x1 : nullptr, w, y, bn_part, workspace, static_cast<hipStream_t>(stream)),
+                      "conv3x3_fwd launch");
+}
+
+size_t cabinet_conv3x3_bwd_workspace_bytes(int B, int C0, int C1, int Co, int H, int W) {
+    const cabinet::WinoShape s{B, C0, C1, Co, H, W};
+    return B > 0 && H > 0 && W > 0 && cabinet::conv3x3_shape_ok(s) ? cabinet::conv3x3_bwd_workspace(s) : 0;
+}
+
+int cabinet_conv3x3_bwd(const float* dy, const float* x0, const float* x1, const float* w, int B, int C0, int C1, int Co, int H,
+                        int W, float* dx0, float* dx1, float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
+    const cabinet::WinoShape s{B, C0, C1, Co, H, W};
+    if (int rc = check_conv3x3(s, "conv3x3_bwd")) return rc;
+    if (!dy || !w || (dw && (!x0 || (C1 > 0 && !x1))) || (dx0 && C1 > 0 && !dx1))
+        return fail(CABINET_ERR_INVALID_ARG, "conv3x3_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("conv3x3_bwd", dy, x0, x1, w, dx0, dx1, dw);
+    const size_t need = cabinet::conv3x3_bwd_workspace(s);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "conv3x3_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::conv3x3_bwd_run(s, dy, x0, C1 > 0 ? x1 : nullptr, w, dx0, C1 > 0 ? dx1 : nullptr, dw, workspace,
+                                               static_cast<hipStream_t>(stream)),
+                      "conv3x3_bwd launch");
 }
 
 }  // extern "C"

@@ -1,0 +1,629 @@
+// K11 (round 5) -- dense 3x3 convolution (stride 1, padding 1, no bias) as Winograd F(2x2, 3x3) on the exact-fp32 MFMA.
+//
+// Reference spans (src/models/cabinet.py): :59 `conva[0]` (Ci -> 256), :68 + :88-89 `b1(torch.cat([x, feat], 1))`
+// (Ci + 256 -> 256; SURVEY.md section 8 row f2: "the 3x3 of north_star's phrase"), :160 `conv_out.conv.conv` (256 -> 256, row
+// f4), and the autograd backward of each.  Until round 4 these ran on MIOpen (Winograd assembly for forward / data gradient,
+// NHWC implicit GEMM + layout transposes for conv_out and the weight gradients): 2.4 + 4.0 ms of a 27.7 ms step.
+//
+// Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 2x2 output tile and (k, c) pair: 16 multiplications instead of 36, i.e. 16
+// independent GEMMs  M_xi (K x tiles) = U_xi (K x C) . V_xi (C x tiles), xi = 0..15, at 1 / 2.25 of the direct FLOPs.  The
+// matrix pipe is the 1/16-rate fp32 one (gfx950 has no xf32 and bf16 cannot hold the 1e-3 contract through BatchNorm's
+// batch statistics), so the 2.25x is worth more here than anywhere: a direct implicit GEMM at the 0.62 of peak this repo's
+// best fp32 kernels reach would LOSE to MIOpen's Winograd (97 vs 114 TFLOP/s effective).
+//
+// One launch does the input transform, the 16 products and the output transform; V (16/4 = 4x the input) and M never
+// touch HBM:
+//   * a workgroup (512 threads) owns 64 output channels x 32 tiles (2 tile rows x 16 tile columns = 4 x 32 output pixels of
+//     one image) for ALL 16 xi; wave w owns xi = 2w, 2w+1: 2 xi x 2 (32-channel blocks) = 4 accumulator tiles = 64 registers;
+//   * per chunk of 16 input channels every thread loads ONE 4x4 input patch (tile = lane & 31, channel = 2 wave + (lane >> 5)),
+//     transforms it in registers (32 additions) and writes its 16 values to LDS as V[xi][channel][tile] (64 consecutive floats
+//     per wave and xi: conflict-free); the B operand of wave w's MFMAs is then one ds_read_b32 per k-step from its two xi
+//     planes (64 consecutive floats again);
+//   * the A operand (the transformed filters U) is written by wino_filter_kernel in MFMA operand order: one 16-byte load per
+//     lane = four k-steps, straight from L2 into registers (a 64-channel slice of U is 16 x 64 x C x 4 B = 3.9 MB at C = 960:
+//     the XCD-chunked grid gives each XCD ONE slice, so it stays in that XCD's 4 MB L2);
+//   * two-pointer input: the chunk loop walks C0 channels of x0, then C1 channels of x1 -- `torch.cat([x, feat], 1)` (8 x 1216 x
+//     32 x 32 x 4 B = 40 MB written and read back at config 3) never exists;
+//   * epilogue: the 16 accumulator planes meet in LDS (128 KB), a thread applies A^T . A to its (channel, tile) pairs and writes
+//     2 x 2 outputs as two 8-byte stores (16 lanes = one 128-byte row segment); optional per-channel (mean, M2) partials of the
+//     block for the BatchNorm that follows (Chan-merged later, as bn_act.hip does).
+// The data gradient is the same kernel on filters transformed with the spatial flip and the channel roles swapped
+// (dx = conv(dy, rot180(w)^T)); the weight gradient is its own kernel below (contraction over tiles).
+// Exact fp32 MFMA (v_mfma_f32_32x32x2_f32); Winograd's own rounding (+-1, 1/2 coefficients) stays at the 1e-6 level.
+#include "common.hpp"
+
+namespace cabinet {
+
+constexpr int WN_KB = 64;   // output channels per workgroup
+constexpr int WN_TB = 32;   // tiles per workgroup: 2 tile rows x 16 tile columns
+constexpr int WN_CC = 16;   // input channels per chunk
+constexpr int WN_VBUF = 16 * WN_CC * WN_TB;   // floats of one staged V chunk (32 KB)
+
+struct WinoArgs {
+    const float* x0;   // (B, C0, H, W)
+    const float* x1;   // (B, C1, H, W) or null
+    const float* u;    // transformed filters, operand order: [16 xi][K/32][C/8][64 lanes][4]
+    float* y0;         // output channels [0, K0): (B, K0, H, W)
+    float* y1;         // output channels [K0, K): (B, K - K0, H, W) (null when K0 == K)
+    float* stat_part;  // optional [2][K][ntb]: (mean, M2) of the block's valid outputs per channel; null: none
+    int C0, C1, K, K0;
+    int B, H, W;
+    int nby, nbx, ntb, nkb;   // tile blocks per image (rows, columns), tile blocks in all, 64-channel blocks
+    int accumulate;           // 1: y += result (the second data gradient into a shared input)
+};
+
+// ---- filter transform: U = G g G^T, written in MFMA operand order -----------------------------------------------------------
+// `rows` output channels (the MFMA row), `q` contracted channels.  dgrad == 0: g = w[row][q] (w: (rows, q, 3, 3));
+// dgrad == 1: g = rot180(w[q][row]) (w: (q, rows, 3, 3)) -- the data gradient's filters.
+// thread <-> (row block of 32, group of 8 contracted channels, lane): row = 32 rb + (lane & 31), channels 8 g + 2 s + (lane >> 5)
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int rows, int q, int dgrad,
+                                                           float* __restrict__ u) {
+    const int gid = blockIdx.x * 256 + threadIdx.x, lane = gid & 63, unit = gid >> 6;
+    const int ng = q >> 3, nrb = rows >> 5;
+    if (unit >= nrb * ng) return;
+    const int rb = unit / ng, g = unit - rb * ng, row = 32 * rb + (lane & 31), hh = lane >> 5;
+    f32x4 out[16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 8 * g + 2 * s + hh;
+        float f[9];
+        if (dgrad) {
+            const float* p = w + ((size_t)c * rows + row) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) f[e] = p[8 - e];
+        } else {
+            const float* p = w + ((size_t)row * q + c) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) f[e] = p[e];
+        }
+        float gg[4][3];   // G g
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gg[0][j] = f[j];
+            gg[1][j] = 0.5f * ((f[j] + f[6 + j]) + f[3 + j]);
+            gg[2][j] = 0.5f * ((f[j] + f[6 + j]) - f[3 + j]);
+            gg[3][j] = f[6 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[4 * i + 0][s] = gg[i][0];
+            out[4 * i + 1][s] = 0.5f * ((gg[i][0] + gg[i][2]) + gg[i][1]);
+            out[4 * i + 2][s] = 0.5f * ((gg[i][0] + gg[i][2]) - gg[i][1]);
+            out[4 * i + 3][s] = gg[i][2];
+        }
+    }
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+        *reinterpret_cast<f32x4*>(u + ((((size_t)xi * nrb + rb) * ng + g) * 64 + lane) * 4) = out[xi];
+}
+
+// ---- input transform of one 4x4 patch: V = B^T d B ---------------------------------------------------------------------------
+__device__ __forceinline__ void wino_bt_d_b(const float (&d)[16], float (&v)[16]) {
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0 + j] = d[0 + j] - d[8 + j];
+        t[4 + j] = d[4 + j] + d[8 + j];
+        t[8 + j] = d[8 + j] - d[4 + j];
+        t[12 + j] = d[4 + j] - d[12 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[4 * i + 0] = t[4 * i + 0] - t[4 * i + 2];
+        v[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+        v[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1];
+        v[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+    }
+}
+
+__device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+
+__global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int tau = xcd_chunked_tile(blockIdx.x, a.ntb * a.nkb);
+    const int kblk = tau / a.ntb, tb = tau - kblk * a.ntb;
+    const int per_img = a.nby * a.nbx, b = tb / per_img, rem = tb - b * per_img, by = rem / a.nbx, bx = rem - by * a.nbx;
+    const int HW = a.H * a.W, C = a.C0 + a.C1, nch = C / WN_CC, nch0 = a.C0 / WN_CC;
+
+    // ---- this thread's patch: tile li of the block, channel 2 wave + h of the chunk --------------------------------------
+    const int ty = 2 * by + (li >> 4), tx = 16 * bx + (li & 15);
+    int roff[4], coff[4];
+    bool rv[4], cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 2 * ty - 1 + i, c = 2 * tx - 1 + i;
+        rv[i] = (unsigned)r < (unsigned)a.H, cv[i] = (unsigned)c < (unsigned)a.W;
+        roff[i] = (min(max(r, 0), a.H - 1) * a.W + (2 * wave + h) * HW) * 4;
+        coff[i] = min(max(c, 0), a.W - 1) * 4;
+    }
+    const buf_rsrc rx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)((size_t)a.C0 * HW * 4));
+    const buf_rsrc rx1 = make_rsrc(a.x1 ? a.x1 + (size_t)b * a.C1 * HW : a.x0, (unsigned)((size_t)(a.x1 ? a.C1 : a.C0) * HW * 4));
+    float pd[16];
+    auto load_patch = [&](int n) {   // chunk n -> pd (zero padding applied when the values are used)
+        const bool first = n < nch0;   // wave-uniform
+        const int soff = (first ? n : n - nch0) * WN_CC * HW * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                pd[4 * i + j] = bload(first ? rx0 : rx1, roff[i] + coff[j], soff);
+    };
+    auto transform_store = [&](int buf) {
+        float d[16], v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[4 * i + j] = (rv[i] && cv[j]) ? pd[4 * i + j] : 0.f;
+        wino_bt_d_b(d, v);
+        float* dst = smem + buf * WN_VBUF + (2 * wave + h) * WN_TB + li;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) dst[xi * WN_CC * WN_TB] = v[xi];
+    };
+
+    // ---- A operand: U rows of the wave's two xi, two 32-channel blocks; one 16-byte load = four k-steps -------------------
+    const int ng = C >> 3, nrb = a.K >> 5;
+    const buf_rsrc ru = make_rsrc(a.u, (unsigned)((size_t)16 * a.K * C * 4));
+    f32x4 ua[2][2][2], ub[2][2][2];   // [xi][channel block][half chunk]
+    auto load_u = [&](f32x4 (&dst)[2][2][2], int n) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int hc = 0; hc < 2; ++hc) {
+                    const int soff = ((((2 * wave + x) * nrb + 2 * kblk + kb) * ng + 2 * n + hc) * 64) * 16;
+                    dst[x][kb][hc] = bload4(ru, lane * 16, soff);
+                }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][kb][r] = 0.f;
+
+    auto mfma_chunk = [&](const f32x4 (&uu)[2][2][2], int buf) {
+        const float* vb = smem + buf * WN_VBUF + (2 * wave) * WN_CC * WN_TB + h * WN_TB + li;
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+            float bv[2][4];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bv[x][s] = vb[x * WN_CC * WN_TB + (2 * (4 * hc + s)) * WN_TB];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) acc[x][kb] = mfma32(uu[x][kb][hc][s], bv[x][s], acc[x][kb]);
+        }
+    };
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------------
+    load_patch(0);
+    load_u(ua, 0);
+    transform_store(0);
+    if (nch > 1) load_patch(1);
+    __syncthreads();
+    // ---- main loop: chunk n's products next to chunk n+1's input transform -----------------------------------------------------
+    auto body = [&](const f32x4 (&ucur)[2][2][2], f32x4 (&unext)[2][2][2], int n) {
+        if (n + 1 < nch) load_u(unext, n + 1);
+        mfma_chunk(ucur, n & 1);
+        if (n + 1 < nch) {
+            transform_store((n + 1) & 1);
+            if (n + 2 < nch) load_patch(n + 2);
+        }
+        __syncthreads();
+    };
+    for (int n = 0; n < nch; n += 2) {
+        body(ua, ub, n);
+        if (n + 1 < nch) body(ub, ua, n + 1);
+    }
+
+    // ---- epilogue: the 16 planes meet in LDS, output transform Y = A^T M A ---------------------------------------------------
+    // (the loop's last barrier has passed: V is dead)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                smem[((2 * wave + x) * WN_KB + 32 * kb + acc_row(r) + 4 * h) * WN_TB + li] = acc[x][kb][r];
+    __syncthreads();
+    const int k0 = kblk * WN_KB;
+    float* ybase;
+    int krow0, kimg;   // first channel of the block inside its output tensor, channels of that tensor
+    if (k0 < a.K0) ybase = a.y0, krow0 = k0, kimg = a.K0;
+    else ybase = a.y1, krow0 = k0 - a.K0, kimg = a.K - a.K0;
+    const int t = tid & 31, oty = 2 * by + (t >> 4), otx = 16 * bx + (t & 15);
+    const int oy = 2 * oty, ox = 2 * otx;
+    const bool even_w = (a.W & 1) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kk = (tid >> 5) + 16 * i;   // channel of the block
+        float m[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) m[xi] = smem[(xi * WN_KB + kk) * WN_TB + t];
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = (m[j] + m[4 + j]) + m[8 + j];
+            s1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+        }
+        float o[2][2];
+        o[0][0] = (s0[0] + s0[1]) + s0[2], o[0][1] = (s0[1] - s0[2]) - s0[3];
+        o[1][0] = (s1[0] + s1[1]) + s1[2], o[1][1] = (s1[1] - s1[2]) - s1[3];
+        float* yp = ybase + ((size_t)b * kimg + krow0 + kk) * HW;
+        const bool vx0 = ox < a.W, vx1 = ox + 1 < a.W;
+        float cnt = 0.f, sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool vy = oy + r < a.H;
+            float* p = yp + (size_t)(oy + r) * a.W + ox;
+            if (vy && vx1 && even_w) {
+                f32x2 val = {o[r][0], o[r][1]};
+                if (a.accumulate) {
+                    const f32x2 old = *reinterpret_cast<const f32x2*>(p);
+                    val[0] += old[0], val[1] += old[1], o[r][0] = val[0], o[r][1] = val[1];
+                }
+                *reinterpret_cast<f32x2*>(p) = val;
+            } else if (vy) {
+                if (vx0) {
+                    if (a.accumulate) o[r][0] += p[0];
+                    p[0] = o[r][0];
+                }
+                if (vx1) {
+                    if (a.accumulate) o[r][1] += p[1];
+                    p[1] = o[r][1];
+                }
+            }
+            if (vy && vx0) cnt += 1.f, sum += o[r][0];
+            if (vy && vx1) cnt += 1.f, sum += o[r][1];
+        }
+        if (a.stat_part) {   // (mean, M2) of the block's valid outputs of channel kk: two half-wave reductions, fixed order
+            const float n_blk = half_sum(cnt), mean = half_sum(sum) / fmaxf(n_blk, 1.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool vy = oy + r < a.H;
+                if (vy && vx0) m2 += (o[r][0] - mean) * (o[r][0] - mean);
+                if (vy && vx1) m2 += (o[r][1] - mean) * (o[r][1] - mean);
+            }
+            m2 = half_sum(m2);
+            if (t == 0) {
+                a.stat_part[(size_t)(k0 + kk) * a.ntb + tb] = mean;
+                a.stat_part[((size_t)a.K + k0 + kk) * a.ntb + tb] = m2;
+            }
+        }
+    }
+}
+
+// ---- weight gradient: dU_xi (K x C) = sum over tiles of dM_xi (K x tiles) . V_xi^T (tiles x C), dw = G^T dU G ---------------------
+// dM = A dY A^T (the 2x2 output-gradient tile spread to 4x4), V = B^T d B as in forward: F(3x3, 2x2), the exact adjoint of the
+// forward's bilinear form, 16 instead of 36 multiplications per (k, c, tile).  The contraction runs over tiles, so BOTH operands are
+// transformed on the fly and meet in LDS:
+//   * a workgroup owns 64 output channels x 64 input channels for all 16 xi over a contiguous range of tile chunks (8 tiles of one
+//     tile row per chunk); wave w owns xi = 2w, 2w+1: 2 x 2 x 2 accumulator tiles = 128 registers;
+//   * per chunk a thread (tile = tid & 7, channel = tid >> 3) loads one 2x2 dy tile and one 4x4 x patch, transforms both and writes
+//     2 x 16 values: planes [xi][tile][channel], pitch 72 (8 tiles x 8 channels per wave: two-way conflicts at most);
+//   * every range writes its G^T dU G (9 values per (k, c), via LDS in two halves) to a slab; wino_wgrad_sum_kernel adds the slabs in
+//     a fixed order: no atomics, bit-reproducible.
+constexpr int WG_KB = 64, WG_CB = 64, WG_TT = 8, WG_PITCH = 72;
+constexpr int WG_PLANE = WG_TT * WG_PITCH;   // floats of one xi plane of one operand
+constexpr int WG_OPBUF = 16 * WG_PLANE;      // one operand of one chunk: 36,864 B
+constexpr int WG_BUF = 2 * WG_OPBUF;         // dM + V of one chunk
+
+struct WinoWgArgs {
+    const float* dy;   // (B, K, H, W)
+    const float* x0;   // (B, C0, H, W)
+    const float* x1;   // (B, C1, H, W) or null
+    float* slab;       // [nsplit][K][C0 + C1][9]
+    int C0, C1, K, B, H, W;
+    int TH, ncx, nchunks, nsplit, nkb, ncb;   // tile rows, chunks per tile row, chunks in all, ranges, 64-channel blocks of K and C
+};
+
+__device__ __forceinline__ f32x2 bload2(buf_rsrc r, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0));
+}
+
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][dM | V][16 xi][8 tiles][72]; epilogue: [16][64][32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int tt = tid & 7, ch = tid >> 3;
+    const int unit = xcd_chunked_tile(blockIdx.x, a.nsplit * a.nkb * a.ncb);
+    const int per_split = a.nkb * a.ncb, split = unit / per_split, rem = unit - split * per_split;
+    const int kblk = rem / a.ncb, cblk = rem - kblk * a.ncb;
+    const int q_lo = (int)((long long)split * a.nchunks / a.nsplit), q_hi = (int)((long long)(split + 1) * a.nchunks / a.nsplit);
+    const int HW = a.H * a.W, C = a.C0 + a.C1;
+    // the 64 input channels of the block lie in x0 or in x1 (C0 is a multiple of 64 when there are two inputs)
+    const bool in0 = cblk * WG_CB < a.C0;
+    const float* xsrc = in0 ? a.x0 : a.x1;
+    const int Cx = in0 ? a.C0 : a.C1, cfirst = in0 ? cblk * WG_CB : cblk * WG_CB - a.C0;
+    const bool even_w = (a.W & 1) == 0;
+
+    // position of chunk q: image b, tile row ty, chunk column cx (wave-uniform, advanced incrementally)
+    struct Pos {
+        int b, ty, cx;
+    };
+    auto pos_of = [&](int q) {
+        Pos p;
+        const int per_img = a.TH * a.ncx;
+        p.b = q / per_img;
+        const int r = q - p.b * per_img;
+        p.ty = r / a.ncx, p.cx = r - p.ty * a.ncx;
+        return p;
+    };
+    auto advance = [&](Pos& p) {
+        if (++p.cx == a.ncx) {
+            p.cx = 0;
+            if (++p.ty == a.TH) p.ty = 0, ++p.b;
+        }
+    };
+
+    float px[16];
+    f32x2 pg[2];
+    auto load_chunk = [&](const Pos& p) {
+        const int tx = 8 * p.cx + tt;
+        // x patch: rows 2 ty - 1 + i (scalar), columns 2 tx - 1 + j (per lane); clamped addresses, zeros applied when used
+        const buf_rsrc rx = make_rsrc(xsrc + (size_t)p.b * Cx * HW, (unsigned)((size_t)Cx * HW * 4));
+        int cof[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cof[j] = (min(max(2 * tx - 1 + j, 0), a.W - 1) + (cfirst + ch) * HW) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int so = min(max(2 * p.ty - 1 + i, 0), a.H - 1) * a.W * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) px[4 * i + j] = bload(rx, cof[j], so);
+        }
+        // dy tile: rows 2 ty, 2 ty + 1, columns 2 tx, 2 tx + 1
+        const buf_rsrc rg = make_rsrc(a.dy + (size_t)p.b * a.K * HW, (unsigned)((size_t)a.K * HW * 4));
+        const int gx = min(2 * tx, a.W - 1), go = ((kblk * WG_KB + ch) * HW + gx) * 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int so = min(2 * p.ty + r, a.H - 1) * a.W * 4;
+            if (even_w) pg[r] = bload2(rg, go, so);
+            else pg[r][0] = bload(rg, go, so), pg[r][1] = bload(rg, ((kblk * WG_KB + ch) * HW + min(2 * tx + 1, a.W - 1)) * 4, so);
+        }
+    };
+    auto transform_store = [&](const Pos& p, int buf) {
+        const int tx = 8 * p.cx + tt;
+        float d[16], v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool rvi = (unsigned)(2 * p.ty - 1 + i) < (unsigned)a.H;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[4 * i + j] = (rvi && (unsigned)(2 * tx - 1 + j) < (unsigned)a.W) ? px[4 * i + j] : 0.f;
+        }
+        wino_bt_d_b(d, v);
+        float* dv = smem + buf * WG_BUF + WG_OPBUF + tt * WG_PITCH + ch;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) dv[xi * WG_PLANE] = v[xi];
+        float g[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool rvr = 2 * p.ty + r < a.H;
+            g[r][0] = (rvr && 2 * tx < a.W) ? pg[r][0] : 0.f;
+            g[r][1] = (rvr && 2 * tx + 1 < a.W) ? pg[r][1] : 0.f;
+        }
+        // dM = A g A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+        float rr[4][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) rr[0][e] = g[0][e], rr[1][e] = g[0][e] + g[1][e], rr[2][e] = g[0][e] - g[1][e], rr[3][e] = -g[1][e];
+        float* dm = smem + buf * WG_BUF + tt * WG_PITCH + ch;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dm[(4 * i + 0) * WG_PLANE] = rr[i][0];
+            dm[(4 * i + 1) * WG_PLANE] = rr[i][0] + rr[i][1];
+            dm[(4 * i + 2) * WG_PLANE] = rr[i][0] - rr[i][1];
+            dm[(4 * i + 3) * WG_PLANE] = -rr[i][1];
+        }
+    };
+
+    f32x16 acc[2][2][2];   // [xi][k block][c block]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][kb][cb][r] = 0.f;
+    auto mfma_chunk = [&](int buf) {
+        const float* ab = smem + buf * WG_BUF + (2 * wave) * WG_PLANE + h * WG_PITCH + li;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float av[2][2], bv[2][2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    av[x][e] = ab[x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
+                    bv[x][e] = ab[WG_OPBUF + x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
+                }
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) acc[x][kb][cb] = mfma32(av[x][kb], bv[x][cb], acc[x][kb][cb]);
+        }
+    };
+
+    if (q_lo < q_hi) {
+        Pos p_cur = pos_of(q_lo), p_ld = p_cur;
+        load_chunk(p_ld);
+        transform_store(p_cur, 0);
+        advance(p_ld);
+        if (q_lo + 1 < q_hi) load_chunk(p_ld);
+        __syncthreads();
+        for (int q = q_lo; q < q_hi; ++q) {
+            const int buf = (q - q_lo) & 1;
+            mfma_chunk(buf);
+            if (q + 1 < q_hi) {
+                advance(p_cur);          // = position of chunk q + 1, whose values are in px / pg
+                transform_store(p_cur, buf ^ 1);
+                advance(p_ld);
+                if (q + 2 < q_hi) load_chunk(p_ld);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: dw contribution G^T dU G of this range, two halves of 32 input channels through LDS --------------------------
+    float* slab = a.slab + ((size_t)split * a.K + kblk * WG_KB) * C * 9;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (cb) __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[((2 * wave + x) * WG_KB + 32 * kb + acc_row(r) + 4 * h) * 32 + li] = acc[x][kb][cb][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = (tid >> 5) + 16 * i, cc = tid & 31;
+            float m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = smem[(xi * WG_KB + kk) * 32 + cc];
+            // G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
+            float t[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = m[j] + 0.5f * (m[4 + j] + m[8 + j]);
+                t[1][j] = 0.5f * (m[4 + j] - m[8 + j]);
+                t[2][j] = m[12 + j] + 0.5f * (m[4 + j] + m[8 + j]);
+            }
+            float* o = slab + ((size_t)kk * C + cblk * WG_CB + 32 * cb + cc) * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                o[3 * r + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+                o[3 * r + 1] = 0.5f * (t[r][1] - t[r][2]);
+                o[3 * r + 2] = t[r][3] + 0.5f * (t[r][1] + t[r][2]);
+            }
+        }
+    }
+}
+
+// dw[i] = sum of the nsplit slabs in ascending order (fixed order: deterministic)
+__global__ __launch_bounds__(256) void wino_wgrad_sum_kernel(const float* __restrict__ slab, int n4, int nsplit, float* __restrict__ dw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(slab)[i];
+    for (int k = 1; k < nsplit; ++k) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(size_t)k * n4 + i];
+        s[0] += v[0], s[1] += v[1], s[2] += v[2], s[3] += v[3];
+    }
+    reinterpret_cast<f32x4*>(dw)[i] = s;
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------
+struct WinoShape {
+    int B, C0, C1, K, H, W;
+};
+static inline int wn_th(int H) { return (H + 1) / 2; }
+bool conv3x3_supported(int C0, int C1, int K) {
+    return C0 > 0 && C1 >= 0 && K > 0 && (C0 % WN_CC) == 0 && (C1 % WN_CC) == 0 && (K % WN_KB) == 0 &&
+           // the data gradient runs the same kernel with the roles swapped: its output blocks must not straddle x0 | x1
+           (K % WN_CC) == 0 && ((C0 + C1) % WN_KB) == 0 && (C1 == 0 || (C0 % WN_KB) == 0);
+}
+bool conv3x3_shape_ok(const WinoShape& s) {
+    const long long img_in = (long long)(s.C0 > s.C1 ? s.C0 : s.C1) * s.H * s.W * 4, img_out = (long long)s.K * s.H * s.W * 4;
+    return conv3x3_supported(s.C0, s.C1, s.K) && s.B > 0 && s.H > 0 && s.W > 0 && img_in < 0x7fffffffLL && img_out < 0x7fffffffLL &&
+           (long long)16 * s.K * (s.C0 + s.C1) * 4 < 0x7fffffffLL;
+}
+int conv3x3_tile_blocks(int B, int H, int W) { return B * ((wn_th(H) + 1) / 2) * ((wn_th(W) + 15) / 16); }
+size_t conv3x3_filter_bytes(int C, int K) { return align_up((size_t)16 * K * C * sizeof(float), 256); }
+
+static hipError_t wino_filter_run(const float* w, int rows, int q, int dgrad, float* u, hipStream_t stream) {
+    const int threads = (rows / 32) * (q / 8) * 64;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, stream, w, rows, q, dgrad, u);
+    return hipGetLastError();
+}
+
+static hipError_t wino_conv_run(const float* x0, const float* x1, const float* u, int B, int C0, int C1, int K, int K0, int H,
+                                int W, float* y0, float* y1, float* stat_part, int accumulate, hipStream_t stream) {
+    WinoArgs a{};
+    a.x0 = x0, a.x1 = x1, a.u = u, a.y0 = y0, a.y1 = y1, a.stat_part = stat_part;
+    a.C0 = C0, a.C1 = C1, a.K = K, a.K0 = K0, a.B = B, a.H = H, a.W = W;
+    a.nby = (wn_th(H) + 1) / 2, a.nbx = (wn_th(W) + 15) / 16, a.ntb = B * a.nby * a.nbx, a.nkb = K / WN_KB;
+    a.accumulate = accumulate;
+    const size_t lds = (size_t)16 * WN_KB * WN_TB * sizeof(float);   // 128 KB (the epilogue's planes; the V ring needs 64 KB)
+    static lds_attr_mask mask{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel), 160 * 1024, mask); e != hipSuccess) return e;
+    hipLaunchKernelGGL(wino_conv_kernel, dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+// forward: ws = transformed filters
+size_t conv3x3_fwd_workspace(const WinoShape& s) { return conv3x3_filter_bytes(s.C0 + s.C1, s.K); }
+hipError_t conv3x3_fwd_run(const WinoShape& s, const float* x0, const float* x1, const float* w, float* y, float* stat_part, void* ws,
+                           hipStream_t stream) {
+    float* u = static_cast<float*>(ws);
+    if (hipError_t e = wino_filter_run(w, s.K, s.C0 + s.C1, 0, u, stream); e != hipSuccess) return e;
+    return wino_conv_run(x0, x1, u, s.B, s.C0, s.C1, s.K, s.K, s.H, s.W, y, nullptr, stat_part, 0, stream);
+}
+
+// data gradient: dx0 (B,C0,H,W), dx1 (B,C1,H,W) from dy (B,K,H,W)
+size_t conv3x3_dgrad_workspace(const WinoShape& s) { return conv3x3_filter_bytes(s.C0 + s.C1, s.K); }
+hipError_t conv3x3_dgrad_run(const WinoShape& s, const float* dy, const float* w, float* dx0, float* dx1, int accumulate0, void* ws,
+                             hipStream_t stream) {
+    float* u = static_cast<float*>(ws);
+    const int C = s.C0 + s.C1;
+    if (hipError_t e = wino_filter_run(w, C, s.K, 1, u, stream); e != hipSuccess) return e;
+    // accumulate applies to dx0 only (the input two convolutions share); dx1 blocks are plain stores: handled by two launches
+    // only when both are asked for and differ -- the common case (accumulate0 == 0) is one launch
+    if (!accumulate0 || s.C1 == 0) return wino_conv_run(dy, nullptr, u, s.B, s.K, 0, C, s.C0, s.H, s.W, dx0, dx1, nullptr, accumulate0, stream);
+    return hipErrorInvalidValue;   // accumulate into dx0 with a second output: not offered
+}
+
+
+// weight gradient: ranges of the chunk list so that the grid fills whole rounds of 256 workgroups
+static int wino_wgrad_nsplit(const WinoShape& s, int nchunks) {
+    const int units = (s.K / WG_KB) * ((s.C0 + s.C1) / WG_CB);
+    int rounds = ceil_div(units, 256), ns = (256 * rounds) / units;
+    if (ns < 1) ns = 1;
+    return ns > nchunks ? nchunks : ns;
+}
+static int wino_wgrad_nchunks(const WinoShape& s) { return s.B * wn_th(s.H) * ((wn_th(s.W) + WG_TT - 1) / WG_TT); }
+static size_t wino_wgrad_slab_bytes(const WinoShape& s) {
+    return align_up((size_t)wino_wgrad_nsplit(s, wino_wgrad_nchunks(s)) * s.K * (s.C0 + s.C1) * 9 * sizeof(float), 256);
+}
+static hipError_t wino_wgrad_run(const WinoShape& s, const float* dy, const float* x0, const float* x1, float* dw, float* slab,
+                                 hipStream_t stream) {
+    WinoWgArgs a{};
+    a.dy = dy, a.x0 = x0, a.x1 = x1, a.slab = slab;
+    a.C0 = s.C0, a.C1 = s.C1, a.K = s.K, a.B = s.B, a.H = s.H, a.W = s.W;
+    a.TH = wn_th(s.H), a.ncx = (wn_th(s.W) + WG_TT - 1) / WG_TT, a.nchunks = wino_wgrad_nchunks(s);
+    a.nsplit = wino_wgrad_nsplit(s, a.nchunks), a.nkb = s.K / WG_KB, a.ncb = (s.C0 + s.C1) / WG_CB;
+    const size_t lds = (size_t)2 * WG_BUF * sizeof(float);   // 147,456 B (the epilogue's 128 KB of planes alias it)
+    static lds_attr_mask mask{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_wgrad_kernel), 160 * 1024, mask); e != hipSuccess) return e;
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.nsplit * a.nkb * a.ncb), dim3(512), lds, stream, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    const int n4 = s.K * (s.C0 + s.C1) * 9 / 4;   // K % 64 == 0: divisible
+    hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, stream, slab, n4, a.nsplit, dw);
+    return hipGetLastError();
+}
+
+// backward: ws = transformed (flipped, transposed) filters | weight-gradient slabs
+size_t conv3x3_bwd_workspace(const WinoShape& s) { return conv3x3_filter_bytes(s.C0 + s.C1, s.K) + wino_wgrad_slab_bytes(s); }
+hipError_t conv3x3_bwd_run(const WinoShape& s, const float* dy, const float* x0, const float* x1, const float* w, float* dx0,
+                           float* dx1, float* dw, void* ws, hipStream_t stream) {
+    if (dx0)
+        if (hipError_t e = conv3x3_dgrad_run(s, dy, w, dx0, dx1, 0, ws, stream); e != hipSuccess) return e;
+    if (dw) {
+        float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + conv3x3_filter_bytes(s.C0 + s.C1, s.K));
+        return wino_wgrad_run(s, dy, x0, x1, dw, slab, stream);
+    }
+    return hipSuccess;
+}
+
+}  // namespace cabinet

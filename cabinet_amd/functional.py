@@ -758,6 +758,71 @@ def conv1x1(x, weight):
     return _Conv1x1.apply(x, weight)
 
 
+# --------------------------------------------------------------------------- dense 3x3 convolution (K11, Winograd on the fp32 MFMA)
+
+
+def conv3x3_supported(C0, C1, Co):
+    """True when K11 takes ``nn.Conv2d(C0 + C1, Co, 3, padding=1, bias=False)`` over inputs of C0 (+ C1) channels."""
+    return bool(_lib.load().cabinet_conv3x3_supported(int(C0), int(C1), int(Co)))
+
+
+def conv3x3_fwd_hip(x0, x1, weight, bn_part=None):
+    lib = _lib.load()
+    B, C0, H, W = x0.shape
+    C1 = x1.shape[1] if x1 is not None else 0
+    Co = weight.shape[0]
+    y = torch.empty((B, Co, H, W), dtype=torch.float32, device=x0.device)
+    ws, nbytes = _workspace(lib.cabinet_conv3x3_fwd_workspace_bytes(B, C0, C1, Co, H, W), x0.device)
+    with torch.cuda.device(x0.device):
+        rc = lib.cabinet_conv3x3_fwd(_ptr(x0), _ptr(x1), _ptr(weight), B, C0, C1, Co, H, W, _ptr(y), _ptr(bn_part), _ptr(ws), nbytes,
+                                     _stream_handle(x0.device))
+    _lib.check(rc, "cabinet_conv3x3_fwd")
+    return y
+
+
+def conv3x3_bwd_hip(g, x0, x1, weight, need_dx=True, need_dw=True):
+    lib = _lib.load()
+    B, C0, H, W = x0.shape
+    C1 = x1.shape[1] if x1 is not None else 0
+    Co = weight.shape[0]
+    dx0 = torch.empty_like(x0) if need_dx else None
+    dx1 = torch.empty_like(x1) if need_dx and x1 is not None else None
+    dw = torch.empty_like(weight) if need_dw else None
+    ws, nbytes = _workspace(lib.cabinet_conv3x3_bwd_workspace_bytes(B, C0, C1, Co, H, W), x0.device)
+    with torch.cuda.device(x0.device):
+        rc = lib.cabinet_conv3x3_bwd(_ptr(g), _ptr(x0), _ptr(x1), _ptr(weight), B, C0, C1, Co, H, W, _ptr(dx0), _ptr(dx1), _ptr(dw),
+                                     _ptr(ws), nbytes, _stream_handle(x0.device))
+    _lib.check(rc, "cabinet_conv3x3_bwd")
+    return dx0, dx1, dw
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x0, x1, weight):
+        x0, weight = _f32c(x0), _f32c(weight)
+        x1 = _f32c(x1) if x1 is not None else None
+        y = conv3x3_fwd_hip(x0, x1, weight)
+        fn_ctx.save_for_backward(x0, x1, weight)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        x0, x1, weight = fn_ctx.saved_tensors
+        need = fn_ctx.needs_input_grad
+        dx0, dx1, dw = conv3x3_bwd_hip(_f32c(g), x0, x1, weight, need_dx=need[0] or (x1 is not None and need[1]), need_dw=need[2])
+        return dx0, dx1, dw
+
+
+def conv3x3(x, weight, x1=None):
+    """``F.conv2d(cat([x, x1], 1), weight, padding=1)`` (``x1`` optional) for a bias-free 3x3 stride-1 convolution of device
+    tensors, without the concat: reference cabinet.py:59, :68 + :88-89, :160."""
+    if not x.is_cuda:
+        raise RuntimeError("conv3x3: device tensors only")
+    return _Conv3x3.apply(x, x1, weight)
+
+
 # --------------------------------------------------------------------------- BatchNorm2d + activation (K7)
 
 _ACT_CODES = {None: 0, "none": 0, "relu": 1, "hardswish": 2}

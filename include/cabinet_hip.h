@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define CABINET_ABI_VERSION 4
+#define CABINET_ABI_VERSION 5
 
 #define CABINET_OK 0
 #define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
@@ -396,6 +396,31 @@ int cabinet_pwconv_fwd(const float* x, const float* w, int B, int Ci, int Co, in
 size_t cabinet_pwconv_bwd_workspace_bytes(int B, int Ci, int Co, int P);
 int cabinet_pwconv_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P,
                        float* dx, float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Dense 3x3 convolution, stride 1, padding 1, no bias (nn.Conv2d(Ci, Co, 3, padding=1, bias=False)) as Winograd
+ * F(2x2,3x3) on the exact-fp32 MFMA; input transform, the 16 products and the output transform in ONE launch.
+ * Replaces src/models/cabinet.py:59 (`conva[0]`), :68 + :88-89 (`b1(torch.cat([x, feat], dim=1))`: the two inputs are read
+ * through two pointers, the concat is never materialised) and :160 (`conv_out.conv.conv`), plus their autograd backward.
+ *   x0 (B,C0,H,W), x1 (B,C1,H,W) (C1 = 0, x1 = NULL: a plain convolution);  w (Co, C0+C1, 3, 3);  y (B,Co,H,W)
+ *   bn_part (fwd, nullable): [2][Co][cabinet_conv3x3_tile_blocks(B,H,W)] floats -- per output channel and tile block
+ *     (4 x 32 output pixels) the mean and the sum of squared deviations of the block's valid outputs, for the training-mode
+ *     BatchNorm2d that follows (cabinet.py:60, :90): cabinet_bn_act_fwd_stats consumes them instead of a pass over y.
+ *   bwd: dx0 (B,C0,H,W) and dx1 (B,C1,H,W) = data gradient (either pair skipped when dx0 == NULL), dw (Co,C0+C1,3,3) =
+ *     weight gradient (skipped when NULL); both Winograd too (the weight gradient contracts over tiles: F(3x3,2x2));
+ *     ordered slab sums, no atomics: deterministic.
+ * Supported (cabinet_conv3x3_supported): C0, C1 multiples of 16, Co and C0+C1 multiples of 64, C0 a multiple of 64 when C1 > 0;
+ * any B, H, W (odd sizes masked) with one image's tensors below 2 GB.
+ * ------------------------------------------------------------------------- */
+int cabinet_conv3x3_supported(int C0, int C1, int Co);
+int cabinet_conv3x3_tile_blocks(int B, int H, int W);
+size_t cabinet_conv3x3_fwd_workspace_bytes(int B, int C0, int C1, int Co, int H, int W);
+int cabinet_conv3x3_fwd(const float* x0, const float* x1, const float* w, int B, int C0, int C1, int Co, int H, int W,
+                        float* y, float* bn_part, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+size_t cabinet_conv3x3_bwd_workspace_bytes(int B, int C0, int C1, int Co, int H, int W);
+int cabinet_conv3x3_bwd(const float* dy, const float* x0, const float* x1, const float* w, int B, int C0, int C1, int Co,
+                        int H, int W, float* dx0, float* dx1, float* dw,
+                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
 #ifdef __cplusplus
 }
