@@ -255,6 +255,76 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
     del fsp, dout, o, z, low
     torch.cuda.empty_cache()
 
+    if extra:  # K7 .. K10: backbone / spatial-branch operators of rounds 1-2, outside SURVEY.md section 8 (--all-kernels)
+        yield from _backbone_cases(B, H, W, g, dev)
+
+    # ---- f3: OHEM-CE fused with the final x8 upsample
+    ncls = classes
+    lowl = torch.randn(B, ncls, h, w, generator=g).to(dev)
+    lab = torch.randint(0, ncls, (B, H, W), generator=g).to(dev)
+    px = float(B * H * W)
+    if extra:  # one head per launch (OhemCELoss.forward_upsampled); the step runs the paired form below
+        yield ("ohem_up_fwd (f3: upsample + CE + OHEM partials)", lambda: Fh.ohem_up_fwd_hip(lowl, lab, (H, W), 0.7, 255),
+               px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
+        loss_px = Fh.ohem_up_fwd_hip(lowl, lab, (H, W), 0.7, 255)[0]
+        yield ("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)",
+               lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (H, W), 0.7, 255, 1e-6), px * ncls * 16,
+               px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * H * w, "hbm")
+    lowl2 = torch.randn(B, ncls, h, w, generator=g).to(dev)
+    yield ("ohem_up_pair_fwd (f3: BOTH loss heads per launch, label tile shared)",
+           lambda: Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255),
+           2 * px * ncls * 12, px * (8 + 2 * 4) + 8.0 * lowl.numel(), "hbm")
+    loss_px2 = Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255)[0]
+    yield ("ohem_up_pair_bwd (f3: both heads; x pass = whole source rows per wave, resize adjoint in registers; y pass)",
+           lambda: Fh.ohem_up_pair_bwd_hip(lowl, lowl2, lab, loss_px2, (H, W), 0.7, 255, 1e-6),
+           2 * px * ncls * 16, px * (8 + 2 * 4) + 8.0 * lowl.numel() + 16.0 * B * ncls * H * w, "hbm")
+    del lowl2, loss_px2
+
+    # ---- K5 / K6: the rest of the Context Aggregation Block at (B, 256, size/32, size/32)
+    from cabinet_amd.models.cab import ContextAggregationBlock
+
+    cab = ContextAggregationBlock(256, 128).to(dev).train()
+    xc = torch.randn(B, 256, hl, wl, generator=g).to(dev).requires_grad_(True)
+    gc = torch.randn(B, 256, hl, wl, generator=g).to(dev)
+    elems = float(xc.numel())
+    yl = cab.local_attn(xc)
+    yield ("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", lambda: cab.local_attn(xc.detach()), elems * 3 * 22, 8.0 * elems, "hbm")
+    yield ("cab_local_bwd (K5: chain recomputed in LDS)", lambda: Fh._CabLocal.backward(yl.grad_fn, gc), elems * 3 * 60, 12.0 * elems, "hbm")
+    q3 = Fh.cab_qkv(xc, cab.global_attn)
+    gq = [torch.randn_like(t) for t in q3]
+    fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
+    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 4 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
+    yield ("cab_qkv_bwd (K6: adjoint chain, 6 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
+    del cab, xc, gc, yl, q3, gq
+    torch.cuda.empty_cache()
+
+    # ---- K11: the decoder's three plain 3x3 convolutions as fused Winograd F(2x2,3x3) kernels:
+    # ab.conva (960 -> 256), the fusion head ab.b1 over cat([x, feat]) read through two pointers (960 + 256 -> 256), both at
+    # size/32, and conv_out.conv (256 -> 256) at size/8.  `flops` are the EXECUTED matrix FLOPs -- 16 multiplications per
+    # (k, c, 2x2 tile) = the direct convolution's 2*9*... / 2.25 -- so that `frac` is a share of the fp32 MFMA peak; the
+    # direct-equivalent rate is 2.25x the reported TFLOP/s.  Bytes: inputs + outputs + weights once.
+    for tag, C0, C1, hh, ww in (("conva", 960, 0, hl, wl), ("b1", 960, 256, hl, wl), ("out", 256, 0, h, w)):
+        Co = 256
+        x0 = torch.randn(B, C0, hh, ww, generator=g).to(dev)
+        x1 = torch.randn(B, C1, hh, ww, generator=g).to(dev) if C1 else None
+        wt = (torch.randn(Co, C0 + C1, 3, 3, generator=g) * 0.02).to(dev)
+        dy = torch.randn(B, Co, hh, ww, generator=g).to(dev)
+        fl = 2.0 * B * hh * ww * (C0 + C1) * Co * 9 / 2.25
+        io = 4.0 * (B * hh * ww * (C0 + C1 + Co) + wt.numel())
+        yield (f"conv3x3_{tag}_fwd (K11: filter transform + fused Winograd forward, {C0}{'+' + str(C1) if C1 else ''} -> {Co})",
+               lambda: Fh.conv3x3_fwd_hip(x0, x1, wt), fl, io, "mfma")
+        yield (f"conv3x3_{tag}_bwd (K11: data gradient + weight gradient, both Winograd, ordered slab sum)",
+               lambda: Fh.conv3x3_bwd_hip(dy, x0, x1, wt), 2.0 * fl, 2.0 * io, "mfma")
+        del x0, x1, wt, dy
+        torch.cuda.empty_cache()
+
+
+
+def _backbone_cases(B, H, W, g, dev):
+    """K7 .. K10 (rounds 1-2): operators of the backbone and the spatial branch, outside SURVEY.md section 8; measured only with
+    ``--all-kernels`` (the default run's time belongs to the section-8 groups)."""
+    from cabinet_amd import functional as Fh
+
     # ---- K7: BatchNorm + activation at the largest plane of the model (sb.conv1 / features.2: 64 x size/2 x size/2);
     # algorithmic bytes = the passes a training-mode BatchNorm cannot avoid: fwd read x twice + write y,
     # bwd read dy and x twice + write dx
@@ -311,45 +381,6 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
     del xp, yp, gp
     torch.cuda.empty_cache()
 
-    # ---- f3: OHEM-CE fused with the final x8 upsample
-    ncls = classes
-    lowl = torch.randn(B, ncls, h, w, generator=g).to(dev)
-    lab = torch.randint(0, ncls, (B, H, W), generator=g).to(dev)
-    px = float(B * H * W)
-    if extra:  # one head per launch (OhemCELoss.forward_upsampled); the step runs the paired form below
-        yield ("ohem_up_fwd (f3: upsample + CE + OHEM partials)", lambda: Fh.ohem_up_fwd_hip(lowl, lab, (H, W), 0.7, 255),
-               px * ncls * 12, px * 12 + 4.0 * lowl.numel(), "hbm")
-        loss_px = Fh.ohem_up_fwd_hip(lowl, lab, (H, W), 0.7, 255)[0]
-        yield ("ohem_up_bwd (f3: U^T[sel * (softmax - onehot)], separable)",
-               lambda: Fh.ohem_up_bwd_hip(lowl, lab, loss_px, (H, W), 0.7, 255, 1e-6), px * ncls * 16,
-               px * 12 + 4.0 * lowl.numel() + 8.0 * B * ncls * H * w, "hbm")
-    lowl2 = torch.randn(B, ncls, h, w, generator=g).to(dev)
-    yield ("ohem_up_pair_fwd (f3: BOTH loss heads per launch, label tile shared)",
-           lambda: Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255),
-           2 * px * ncls * 12, px * (8 + 2 * 4) + 8.0 * lowl.numel(), "hbm")
-    loss_px2 = Fh.ohem_up_pair_fwd_hip(lowl, lowl2, lab, (H, W), 0.7, 255)[0]
-    yield ("ohem_up_pair_bwd (f3: both heads; x pass = whole source rows per wave, resize adjoint in registers; y pass)",
-           lambda: Fh.ohem_up_pair_bwd_hip(lowl, lowl2, lab, loss_px2, (H, W), 0.7, 255, 1e-6),
-           2 * px * ncls * 16, px * (8 + 2 * 4) + 8.0 * lowl.numel() + 16.0 * B * ncls * H * w, "hbm")
-    del lowl2, loss_px2
-
-    # ---- K5 / K6: the rest of the Context Aggregation Block at (B, 256, size/32, size/32)
-    from cabinet_amd.models.cab import ContextAggregationBlock
-
-    cab = ContextAggregationBlock(256, 128).to(dev).train()
-    xc = torch.randn(B, 256, hl, wl, generator=g).to(dev).requires_grad_(True)
-    gc = torch.randn(B, 256, hl, wl, generator=g).to(dev)
-    elems = float(xc.numel())
-    yl = cab.local_attn(xc)
-    yield ("cab_local_fwd (K5: 3x DW3x3+BN+ReLU, gate, one kernel)", lambda: cab.local_attn(xc.detach()), elems * 3 * 22, 8.0 * elems, "hbm")
-    yield ("cab_local_bwd (K5: chain recomputed in LDS)", lambda: Fh._CabLocal.backward(yl.grad_fn, gc), elems * 3 * 60, 12.0 * elems, "hbm")
-    q3 = Fh.cab_qkv(xc, cab.global_attn)
-    gq = [torch.randn_like(t) for t in q3]
-    fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
-    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 4 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
-    yield ("cab_qkv_bwd (K6: adjoint chain, 6 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
-
-
 
 _NOTES = {
     "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
@@ -358,6 +389,12 @@ _NOTES = {
     "cab_qkv_bwd": "6 dependent launches on 8192 positions: latency / small-tile MFMA bound",
     "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
                     ": it replaces recomputing S and dP for dq (4.3 GFLOP)",
+    "conv3x3_conva_fwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
+    "conv3x3_conva_bwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
+    "conv3x3_b1_fwd": "executed FLOPs (Winograd: direct / 2.25); the concat of its two inputs is never materialised",
+    "conv3x3_b1_bwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
+    "conv3x3_out_fwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
+    "conv3x3_out_bwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
     "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel, one log-sum-exp "
                         "shift per source interval), not HBM",

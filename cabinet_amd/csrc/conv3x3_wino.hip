@@ -122,7 +122,8 @@ __device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_byt
 
 __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar, or every load offset built from it becomes a waterfall loop
     const int tau = xcd_chunked_tile(blockIdx.x, a.ntb * a.nkb);
     const int kblk = tau / a.ntb, tb = tau - kblk * a.ntb;
     const int per_img = a.nby * a.nbx, b = tb / per_img, rem = tb - b * per_img, by = rem / a.nbx, bx = rem - by * a.nbx;
@@ -187,44 +188,94 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][kb][r] = 0.f;
 
-    auto mfma_chunk = [&](const f32x4 (&uu)[2][2][2], int buf) {
+    // ---- the chunk loop as ONE basic block per chunk, software-pipelined --------------------------------------------------------
+    // A chunk is 32 MFMAs per wave (2 xi x 2 channel blocks x 8 k-steps) = 2048 cycles of the SIMD's matrix pipe; everything else a
+    // wave does for a chunk -- 8 filter loads, 16 patch loads, the input transform of the NEXT chunk (16 selects + 32 additions),
+    // 8 LDS stores, 8 LDS operand reads -- is ~100 instructions that must sit BETWEEN its MFMAs, or the two waves of a SIMD (in
+    // lockstep through the barrier) leave the matrix pipe idle while they both transform: the first version, with the transform in
+    // its own conditional block behind the 32 MFMAs, ran at 0.51 MFMA busy (profiles/r05_conv3x3_first_counters.json).  So the tail
+    // is handled by clamping the chunk index (the last chunk transforms a chunk nobody reads) instead of branching, and four fenced
+    // quarters of 8 MFMAs carry:
+    //   Q0  the filter loads of chunk n+1, the LDS operand reads of this chunk's second half, the 16 border selects of patch n+1
+    //   Q1  the 32 additions of B^T d B, then the 16 loads of patch n+2 (their registers are free once the selects have run)
+    //   Q2  the 16 LDS stores of V[n+1]            -- barrier: V[n+1] is complete --
+    //   Q3  the LDS operand reads of chunk n+1's first half (so no MFMA waits for LDS after the barrier)
+    // All reads of V[n] are issued by the end of Q0 of chunk n, i.e. in front of barrier n; V[n+2] is written behind barrier n+1:
+    // two buffers suffice.
+    float bva[2][4], bvb[2][4];   // B operands (V) of half 0 / half 1 of the current chunk: [xi][k-step]
+    float dsel[16], vout[16];
+    auto read_v = [&](float (&dst)[2][4], int buf, int hc) {
         const float* vb = smem + buf * WN_VBUF + (2 * wave) * WN_CC * WN_TB + h * WN_TB + li;
 #pragma unroll
-        for (int hc = 0; hc < 2; ++hc) {
-            float bv[2][4];
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dst[x][s] = vb[x * WN_CC * WN_TB + (2 * (4 * hc + s)) * WN_TB];
+    };
+    auto mfma_quarter = [&](const f32x4 (&uu)[2][2][2], const float (&bv)[2][4], int hc, int s0) {
+#pragma unroll
+        for (int s = s0; s < s0 + 2; ++s)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) bv[x][s] = vb[x * WN_CC * WN_TB + (2 * (4 * hc + s)) * WN_TB];
+                for (int kb = 0; kb < 2; ++kb) acc[x][kb] = mfma32(uu[x][kb][hc][s], bv[x][s], acc[x][kb]);
+    };
+    // group-barrier recipes: `per` instructions of class `mask` behind each of `n` MFMAs (0x002 VALU, 0x020 VMEM read, 0x100 DS read,
+    // 0x200 DS write)
+#define WN_PIN(n, mask, per)                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+        __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                    \
+    }
+    auto body = [&](const f32x4 (&ucur)[2][2][2], f32x4 (&unext)[2][2][2], int n, int buf) {
+        const int n1 = min(n + 1, nch - 1), n2 = min(n + 2, nch - 1);
+        // ---- Q0
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(unext, n1);
+        read_v(bvb, buf, 1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+            for (int j = 0; j < 4; ++j) dsel[4 * i + j] = (rv[i] && cv[j]) ? pd[4 * i + j] : 0.f;
+        mfma_quarter(ucur, bva, 0, 0);
+        WN_PIN(4, 0x020, 2)    // 8 filter loads
+        WN_PIN(4, 0x100, 2)    // LDS operand reads (ds_read2: 4 instructions; the recipe tolerates fewer)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q1
+        wino_bt_d_b(dsel, vout);
+        load_patch(n2);
+        mfma_quarter(ucur, bva, 0, 2);
+        WN_PIN(8, 0x002, 4)    // 32 additions
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q2
+        {
+            float* dst = smem + (buf ^ 1) * WN_VBUF + (2 * wave + h) * WN_TB + li;
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) acc[x][kb] = mfma32(uu[x][kb][hc][s], bv[x][s], acc[x][kb]);
+            for (int xi = 0; xi < 16; ++xi) dst[xi * WN_CC * WN_TB] = vout[xi];
         }
+        mfma_quarter(ucur, bvb, 1, 0);
+        WN_PIN(8, 0x200, 1)    // 8 LDS stores (ds_write2)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- Q3
+        read_v(bva, buf ^ 1, 0);
+        mfma_quarter(ucur, bvb, 1, 2);
+        WN_PIN(4, 0x100, 1)
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------
     load_patch(0);
     load_u(ua, 0);
     transform_store(0);
-    if (nch > 1) load_patch(1);
+    load_patch(min(1, nch - 1));
     __syncthreads();
-    // ---- main loop: chunk n's products next to chunk n+1's input transform -----------------------------------------------------
-    auto body = [&](const f32x4 (&ucur)[2][2][2], f32x4 (&unext)[2][2][2], int n) {
-        if (n + 1 < nch) load_u(unext, n + 1);
-        mfma_chunk(ucur, n & 1);
-        if (n + 1 < nch) {
-            transform_store((n + 1) & 1);
-            if (n + 2 < nch) load_patch(n + 2);
-        }
-        __syncthreads();
-    };
+    read_v(bva, 0, 0);
     for (int n = 0; n < nch; n += 2) {
-        body(ua, ub, n);
-        if (n + 1 < nch) body(ub, ua, n + 1);
+        body(ua, ub, n, 0);
+        if (n + 1 < nch) body(ub, ua, n + 1, 1);
     }
+    __syncthreads();   // every wave is past its last LDS operand read: the epilogue's planes may overwrite the V buffers
+#undef WN_PIN
 
     // ---- epilogue: the 16 planes meet in LDS, output transform Y = A^T M A ---------------------------------------------------
     // (the loop's last barrier has passed: V is dead)
@@ -311,11 +362,11 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
 //   * a workgroup owns 64 output channels x 64 input channels for all 16 xi over a contiguous range of tile chunks (8 tiles of one
 //     tile row per chunk); wave w owns xi = 2w, 2w+1: 2 x 2 x 2 accumulator tiles = 128 registers;
 //   * per chunk a thread (tile = tid & 7, channel = tid >> 3) loads one 2x2 dy tile and one 4x4 x patch, transforms both and writes
-//     2 x 16 values: planes [xi][tile][channel], pitch 72 (8 tiles x 8 channels per wave: two-way conflicts at most);
+//     2 x 16 values: planes [xi][tile][channel], pitch 68 (a wave's 8 tiles x 8 channels land in 4 tile + channel: conflict-free; 72 was two-way);
 //   * every range writes its G^T dU G (9 values per (k, c), via LDS in two halves) to a slab; wino_wgrad_sum_kernel adds the slabs in
 //     a fixed order: no atomics, bit-reproducible.
-constexpr int WG_KB = 64, WG_CB = 64, WG_TT = 8, WG_PITCH = 72;
-constexpr int WG_PLANE = WG_TT * WG_PITCH;   // floats of one xi plane of one operand
+constexpr int WG_KB = 64, WG_CB = 64, WG_TT = 8, WG_PITCH = 68;
+constexpr int WG_PLANE = 576;                 // floats of one xi plane of one operand: 8 x 68 padded to 9 x 64 (ds_write2st64 pairs)
 constexpr int WG_OPBUF = 16 * WG_PLANE;      // one operand of one chunk: 36,864 B
 constexpr int WG_BUF = 2 * WG_OPBUF;         // dM + V of one chunk
 
@@ -332,9 +383,11 @@ __device__ __forceinline__ f32x2 bload2(buf_rsrc r, int voff_bytes, int soff_byt
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0));
 }
 
+template <bool EVEN_W>
 __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][dM | V][16 xi][8 tiles][72]; epilogue: [16][64][32]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][dM | V][16 xi][8 tiles][68]; epilogue: [16][64][32]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar, or every load offset built from it becomes a waterfall loop
     const int tt = tid & 7, ch = tid >> 3;
     const int unit = xcd_chunked_tile(blockIdx.x, a.nsplit * a.nkb * a.ncb);
     const int per_split = a.nkb * a.ncb, split = unit / per_split, rem = unit - split * per_split;
@@ -345,9 +398,9 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     const bool in0 = cblk * WG_CB < a.C0;
     const float* xsrc = in0 ? a.x0 : a.x1;
     const int Cx = in0 ? a.C0 : a.C1, cfirst = in0 ? cblk * WG_CB : cblk * WG_CB - a.C0;
-    const bool even_w = (a.W & 1) == 0;
 
-    // position of chunk q: image b, tile row ty, chunk column cx (wave-uniform, advanced incrementally)
+    // position of chunk q: image b, tile row ty, chunk column cx (wave-uniform; advanced with selects, not branches: the chunk
+    // loop below is one basic block per chunk)
     struct Pos {
         int b, ty, cx;
     };
@@ -359,11 +412,14 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
         p.ty = r / a.ncx, p.cx = r - p.ty * a.ncx;
         return p;
     };
-    auto advance = [&](Pos& p) {
-        if (++p.cx == a.ncx) {
-            p.cx = 0;
-            if (++p.ty == a.TH) p.ty = 0, ++p.b;
-        }
+    auto advance = [&](Pos& p, bool go) {   // go == false: stay (the clamped tail re-loads the last chunk)
+        const int cx1 = p.cx + 1;
+        const bool wx = cx1 == a.ncx;
+        const int ty1 = p.ty + (wx ? 1 : 0);
+        const bool wy = ty1 == a.TH;
+        p.cx = go ? (wx ? 0 : cx1) : p.cx;
+        p.ty = go ? (wy ? 0 : ty1) : p.ty;
+        p.b = go ? p.b + (wy ? 1 : 0) : p.b;
     };
 
     float px[16];
@@ -387,34 +443,40 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int so = min(2 * p.ty + r, a.H - 1) * a.W * 4;
-            if (even_w) pg[r] = bload2(rg, go, so);
+            if constexpr (EVEN_W) pg[r] = bload2(rg, go, so);
             else pg[r][0] = bload(rg, go, so), pg[r][1] = bload(rg, ((kblk * WG_KB + ch) * HW + min(2 * tx + 1, a.W - 1)) * 4, so);
         }
     };
-    auto transform_store = [&](const Pos& p, int buf) {
+    float dsel[16], gsel[4];   // selected patch / after stage 1 of B^T d B: t = B^T d (in place)
+    auto select_chunk = [&](const Pos& p) {   // zero padding / masked tiles applied to the loaded values
         const int tx = 8 * p.cx + tt;
-        float d[16], v[16];
+        // the tile row is wave-uniform; seen as such, every `row valid ? x : 0` becomes a scalar BRANCH around the selects and cuts
+        // the chunk's basic block into pieces the pinned schedule cannot cross: made opaque, it is a lane mask like the column's
+        int ty = p.ty;
+        asm volatile("" : "+v"(ty));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool rvi = (unsigned)(2 * p.ty - 1 + i) < (unsigned)a.H;
+            const bool rvi = (unsigned)(2 * ty - 1 + i) < (unsigned)a.H;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[4 * i + j] = (rvi && (unsigned)(2 * tx - 1 + j) < (unsigned)a.W) ? px[4 * i + j] : 0.f;
+            for (int j = 0; j < 4; ++j)   // `&`, not `&&`: a select, not control flow
+                dsel[4 * i + j] = (rvi & ((unsigned)(2 * tx - 1 + j) < (unsigned)a.W)) ? px[4 * i + j] : 0.f;
         }
-        wino_bt_d_b(d, v);
-        float* dv = smem + buf * WG_BUF + WG_OPBUF + tt * WG_PITCH + ch;
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) dv[xi * WG_PLANE] = v[xi];
-        float g[2][2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const bool rvr = 2 * p.ty + r < a.H;
-            g[r][0] = (rvr && 2 * tx < a.W) ? pg[r][0] : 0.f;
-            g[r][1] = (rvr && 2 * tx + 1 < a.W) ? pg[r][1] : 0.f;
+            const bool rvr = 2 * ty + r < a.H;
+            gsel[2 * r + 0] = (rvr & (2 * tx < a.W)) ? pg[r][0] : 0.f;
+            gsel[2 * r + 1] = (rvr & (2 * tx + 1 < a.W)) ? pg[r][1] : 0.f;
         }
-        // dM = A g A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+    };
+    // The transforms are cut in two so that no transformed value lives across a quarter of the pipeline (with vout / mout kept from
+    // the additions to the stores the kernel needed 146 registers more than the 256 a wave has at two per SIMD):
+    //   stage A: dM = A g A^T, A = [[1,0],[1,1],[1,-1],[0,-1]], stored at once; t = B^T d in place of d
+    //   stage B: V = t B, stored row by row
+    auto stage_a = [&](int buf) {
         float rr[4][2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) rr[0][e] = g[0][e], rr[1][e] = g[0][e] + g[1][e], rr[2][e] = g[0][e] - g[1][e], rr[3][e] = -g[1][e];
+        for (int e = 0; e < 2; ++e)
+            rr[0][e] = gsel[e], rr[1][e] = gsel[e] + gsel[2 + e], rr[2][e] = gsel[e] - gsel[2 + e], rr[3][e] = -gsel[2 + e];
         float* dm = smem + buf * WG_BUF + tt * WG_PITCH + ch;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -422,6 +484,21 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
             dm[(4 * i + 1) * WG_PLANE] = rr[i][0] + rr[i][1];
             dm[(4 * i + 2) * WG_PLANE] = rr[i][0] - rr[i][1];
             dm[(4 * i + 3) * WG_PLANE] = -rr[i][1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d0 = dsel[j], d1 = dsel[4 + j], d2 = dsel[8 + j], d3 = dsel[12 + j];
+            dsel[j] = d0 - d2, dsel[4 + j] = d1 + d2, dsel[8 + j] = d2 - d1, dsel[12 + j] = d1 - d3;
+        }
+    };
+    auto stage_b = [&](int buf) {
+        float* dv = smem + buf * WG_BUF + WG_OPBUF + tt * WG_PITCH + ch;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dv[(4 * i + 0) * WG_PLANE] = dsel[4 * i + 0] - dsel[4 * i + 2];
+            dv[(4 * i + 1) * WG_PLANE] = dsel[4 * i + 1] + dsel[4 * i + 2];
+            dv[(4 * i + 2) * WG_PLANE] = dsel[4 * i + 2] - dsel[4 * i + 1];
+            dv[(4 * i + 3) * WG_PLANE] = dsel[4 * i + 1] - dsel[4 * i + 3];
         }
     };
 
@@ -434,46 +511,87 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][kb][cb][r] = 0.f;
-    auto mfma_chunk = [&](int buf) {
+    // operands of ONE k-step (two tiles): av[xi][k block], bv[xi][c block]
+    struct Ops {
+        float av[2][2], bv[2][2];
+    };
+    auto read_ops = [&](Ops& o, int buf, int s) {
         const float* ab = smem + buf * WG_BUF + (2 * wave) * WG_PLANE + h * WG_PITCH + li;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            float av[2][2], bv[2][2];
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    av[x][e] = ab[x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
-                    bv[x][e] = ab[WG_OPBUF + x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
-                }
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) acc[x][kb][cb] = mfma32(av[x][kb], bv[x][cb], acc[x][kb][cb]);
-        }
-    };
-
-    if (q_lo < q_hi) {
-        Pos p_cur = pos_of(q_lo), p_ld = p_cur;
-        load_chunk(p_ld);
-        transform_store(p_cur, 0);
-        advance(p_ld);
-        if (q_lo + 1 < q_hi) load_chunk(p_ld);
-        __syncthreads();
-        for (int q = q_lo; q < q_hi; ++q) {
-            const int buf = (q - q_lo) & 1;
-            mfma_chunk(buf);
-            if (q + 1 < q_hi) {
-                advance(p_cur);          // = position of chunk q + 1, whose values are in px / pg
-                transform_store(p_cur, buf ^ 1);
-                advance(p_ld);
-                if (q + 2 < q_hi) load_chunk(p_ld);
+            for (int e = 0; e < 2; ++e) {
+                o.av[x][e] = ab[x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
+                o.bv[x][e] = ab[WG_OPBUF + x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
             }
-            __syncthreads();
-        }
+    };
+    auto mfma_step = [&](const Ops& o) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc[x][kb][cb] = mfma32(o.av[x][kb], o.bv[x][cb], acc[x][kb][cb]);
+    };
+#define WG_PIN(n, mask, per)                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+        __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                    \
     }
+
+    // Software pipeline, one basic block per chunk (see wino_conv_kernel): a chunk is four k-steps of 8 MFMAs; between them sit
+    //   Q0  operand reads of k-step 1
+    //   Q1  operand reads of k-step 2, the border selects of chunk q+1's loaded values, stage A of the transforms (dM stored)
+    //   Q2  operand reads of k-step 3, stage B (V stored), the loads of chunk q+2      -- barrier --
+    //   Q3  operand reads of k-step 0 of chunk q+1
+    // (every range holds at least one chunk: nsplit <= nchunks)
+    Pos p_cur = pos_of(q_lo), p_ld = p_cur;
+    load_chunk(p_ld);
+    select_chunk(p_cur);
+    stage_a(0);
+    stage_b(0);
+    advance(p_ld, q_lo + 1 < q_hi);
+    load_chunk(p_ld);
+    __syncthreads();
+    Ops o0, o1;
+    read_ops(o0, 0, 0);
+    auto body = [&](int q, int buf) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q0
+        advance(p_cur, q + 1 < q_hi);   // position of chunk q + 1, whose values are in px / pg
+        read_ops(o1, buf, 1);
+        mfma_step(o0);
+        WG_PIN(4, 0x100, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q1
+        read_ops(o0, buf, 2);
+        select_chunk(p_cur);
+        stage_a(buf ^ 1);
+        mfma_step(o1);
+        WG_PIN(4, 0x100, 1)
+        WG_PIN(4, 0x002, 12)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- Q2
+        read_ops(o1, buf, 3);
+        stage_b(buf ^ 1);
+        advance(p_ld, q + 2 < q_hi);
+        load_chunk(p_ld);
+        mfma_step(o0);
+        WG_PIN(8, 0x002, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- Q3
+        read_ops(o0, buf ^ 1, 0);
+        mfma_step(o1);
+        WG_PIN(4, 0x100, 1)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int q = q_lo; q < q_hi; q += 2) {
+        body(q, 0);
+        if (q + 1 < q_hi) body(q + 1, 1);
+    }
+    __syncthreads();   // every wave is past its last operand read: the epilogue's planes may overwrite the ring
+#undef WG_PIN
     // ---- epilogue: dw contribution G^T dU G of this range, two halves of 32 input channels through LDS --------------------------
     float* slab = a.slab + ((size_t)split * a.K + kblk * WG_KB) * C * 9;
 #pragma unroll
@@ -605,8 +723,14 @@ static hipError_t wino_wgrad_run(const WinoShape& s, const float* dy, const floa
     a.nsplit = wino_wgrad_nsplit(s, a.nchunks), a.nkb = s.K / WG_KB, a.ncb = (s.C0 + s.C1) / WG_CB;
     const size_t lds = (size_t)2 * WG_BUF * sizeof(float);   // 147,456 B (the epilogue's 128 KB of planes alias it)
     static lds_attr_mask mask{0};
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_wgrad_kernel), 160 * 1024, mask); e != hipSuccess) return e;
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(a.nsplit * a.nkb * a.ncb), dim3(512), lds, stream, a);
+    static lds_attr_mask mask_odd{0};
+    if ((s.W & 1) == 0) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_wgrad_kernel<true>), 160 * 1024, mask); e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_wgrad_kernel<true>, dim3(a.nsplit * a.nkb * a.ncb), dim3(512), lds, stream, a);
+    } else {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_wgrad_kernel<false>), 160 * 1024, mask_odd); e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_wgrad_kernel<false>, dim3(a.nsplit * a.nkb * a.ncb), dim3(512), lds, stream, a);
+    }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     const int n4 = s.K * (s.C0 + s.C1) * 9 / 4;   // K % 64 == 0: divisible
     hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3(ceil_div(n4, 256)), dim3(256), 0, stream, slab, n4, a.nsplit, dw);

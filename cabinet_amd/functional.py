@@ -761,6 +761,10 @@ def conv1x1(x, weight):
 # --------------------------------------------------------------------------- dense 3x3 convolution (K11, Winograd on the fp32 MFMA)
 
 
+# CABINET_CONV3X3=0: the model's plain 3x3 convolutions go back to the stock (MIOpen) operator -- same-box A/B timing only
+CONV3X3_ENABLED = _os.environ.get("CABINET_CONV3X3", "1") != "0"
+
+
 def conv3x3_supported(C0, C1, Co):
     """True when K11 takes ``nn.Conv2d(C0 + C1, Co, 3, padding=1, bias=False)`` over inputs of C0 (+ C1) channels."""
     return bool(_lib.load().cabinet_conv3x3_supported(int(C0), int(C1), int(Co)))

@@ -6,9 +6,12 @@ sub-module names and ``state_dict`` keys.  On HIP tensors ``FeatureFusionModule.
 (reference cabinet.py:142-153) runs as the fused gfx950 pipeline behind
 :func:`cabinet_amd.functional.ffm_fused` and the CAB attention core as one fused
 kernel (see ``cab.py``); ``ConvBNReLU`` runs its BatchNorm + ReLU through the fused streaming op
-(and the spatial branch's 7x7/2 stem through its own MFMA kernel).  The dense 3x3 and wide 1x1
-convolutions of backbone, spatial branch and heads stay on stock PyTorch-ROCm (MIOpen), as
-BASELINE.json's north_star prescribes.
+(and the spatial branch's 7x7/2 stem through its own MFMA kernel).  The three dense 3x3 stride-1 convolutions of the
+decoder -- ``ab.conva``, the fusion head's ``ab.b1`` over ``cat([x, feat])`` and ``conv_out.conv`` (reference
+cabinet.py:59, :68 + :88-89, :160) -- run as K11's fused Winograd kernels
+(:func:`cabinet_amd.functional.conv3x3`; ``CABINET_CONV3X3=0`` restores MIOpen for A/B timing); the strided and
+wide 1x1 convolutions of backbone and spatial branch stay on stock PyTorch-ROCm (MIOpen), as BASELINE.json's
+north_star prescribes.
 """
 
 from __future__ import annotations
@@ -21,8 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import (batched_bn_counters, bn_act, ffm_fused, ffm_fused_upsampled, stem_conv,
-                          stem_conv_supported)
+from .. import functional as _functional
+from ..functional import (batched_bn_counters, bn_act, conv3x3, conv3x3_supported, ffm_fused, ffm_fused_upsampled,
+                          stem_conv, stem_conv_supported)
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -32,6 +36,21 @@ logger = logging.getLogger(__name__)
 
 def _resize(x, size):
     return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+def _is_plain_3x3(conv: nn.Conv2d) -> bool:
+    """3x3, stride 1, padding 1, dilation 1, one group, no bias: what K11 (conv3x3_wino.hip) computes."""
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
+            conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros")
+
+
+def _conv3x3_or_stock(conv: nn.Conv2d, x: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``conv(cat([x, x1], 1))`` (``x1`` optional): on device tensors K11's fused Winograd kernels when the layer is a plain 3x3
+    with channel counts inside their coverage (the concat is then never materialised), else the stock convolution."""
+    c1 = 0 if x1 is None else x1.shape[1]
+    if x.is_cuda and _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels):
+        return conv3x3(x, conv.weight, x1)
+    return conv(x if x1 is None else torch.cat([x, x1], dim=1))
 
 
 class ConvBNReLU(nn.Module):
@@ -49,7 +68,7 @@ class ConvBNReLU(nn.Module):
         if x.is_cuda and x.shape[1] == 3 and stem_conv_supported(self.conv):
             x = stem_conv(x, self.conv)  # K9: the 7x7/2 image stem without NHWC round trips
         else:
-            x = self.conv(x)
+            x = _conv3x3_or_stock(self.conv, x)  # K11 for conv_out's 256 -> 256 3x3 (cabinet.py:160)
         if x.is_cuda:  # K7: BatchNorm + ReLU in one streaming pass pair instead of two library launches
             return bn_act(x, self.bn, "relu")
         return self.relu(self.bn(x))
@@ -77,9 +96,10 @@ class AttentionBranch(nn.Module):
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if x.is_cuda:
-            feat = self.a2block(bn_act(self.conva[0](x), self.conva[1], "relu"))
+            feat = self.a2block(bn_act(_conv3x3_or_stock(self.conva[0], x), self.conva[1], "relu"))
             low_res_out = self.convb(feat)
-            return low_res_out, self.b4(bn_act(self.b1(torch.cat([x, feat], dim=1)), self.b2, "relu"))
+            # K11 reads x and feat through two pointers: the (B, inplanes + 256, H', W') concat is never written
+            return low_res_out, self.b4(bn_act(_conv3x3_or_stock(self.b1, x, feat), self.b2, "relu"))
         feat = self.a2block(self.conva(x))
         low_res_out = self.convb(feat)
         high_res_out = self.b4(self.b3(self.b2(self.b1(torch.cat([x, feat], dim=1)))))
