@@ -452,9 +452,11 @@ def main():
     from cabinet_amd.ddp import BucketedGradReducer, init_distributed
     from cabinet_amd.train import GraphedDDPStep, GraphedTrainStep, TrainStep, build_model, make_criteria, synthetic_batch
 
-    # device_count() does not initialise the HIP runtime: with several ranks, init_distributed() pins the process to its
-    # GPU's NUMA node BEFORE the first GPU call so that the runtime's threads inherit the mask
-    if torch.cuda.device_count() == 0:
+    # With several ranks, init_distributed() pins the process to its GPU's NUMA node BEFORE the first GPU call so that the
+    # runtime's threads inherit the mask: nothing may touch torch.cuda before it (torch.cuda.device_count() falls back to
+    # hipGetDeviceCount -- which starts the runtime's threads -- when amdsmi is not importable), so "is there a GPU"
+    # is answered from the kernel driver's device node
+    if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     if args.kernels_only:
         for r in kernel_rooflines(args.batch, args.height, args.width, args.classes, args.kernel_iters, args.all_kernels):

@@ -71,6 +71,7 @@ SIGNATURES = {
     "cabinet_pwconv_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR]),
     "cabinet_pwconv_bwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_pwconv_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
+    "cabinet_bn_act_fwd_part": (_INT, [_PTR] * 7 + [_INT] * 6 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR]),
     "cabinet_conv3x3_supported": (_INT, [_INT] * 3),
     "cabinet_conv3x3_tile_blocks": (_INT, [_INT] * 3),
     "cabinet_conv3x3_fwd_workspace_bytes": (_SZ, [_INT] * 6),

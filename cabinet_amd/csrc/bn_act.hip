@@ -93,8 +93,10 @@ __global__ __launch_bounds__(BA_T) void bn_act_stats_kernel(const float* __restr
 }
 
 // one workgroup per channel: merge the chunk statistics (Chan et al.), update the running buffers
+// conv_h > 0: the partials come from the epilogue of the 3x3 convolution that produced x (conv3x3_wino.hip: one (mean, M2) pair per
+// channel and tile block of 4 x 32 output pixels, blocks ordered image, block row, block column) instead of bn_act_stats_kernel
 __global__ __launch_bounds__(BA_T) void bn_act_finalize_kernel(const float* __restrict__ part, int B, int C, int P,
-                                                                int chunks, int training, float momentum, float eps,
+                                                                int chunks, int conv_h, int conv_w, int training, float momentum, float eps,
                                                                 float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var,
                                                                 float* __restrict__ save_mean,
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(BA_T) void bn_act_finalize_kernel(const float* __re
         }
         return;
     }
-    const int nt = B * chunks;
+    const int nbx = conv_h > 0 ? (conv_w + 31) / 32 : 1, nbi = conv_h > 0 ? ((conv_h + 3) / 4) * nbx : chunks;
+    const int nt = B * nbi;
     const float* pm = part + (size_t)c * nt;
     const float* p2 = part + ((size_t)C + c) * nt;
     auto block_sum_d = [&](double v) {
@@ -121,7 +124,11 @@ __global__ __launch_bounds__(BA_T) void bn_act_finalize_kernel(const float* __re
         __syncthreads();
         return t;
     };
-    auto count_of = [&](int t) { return (double)(min((t % chunks + 1) * BA_CHUNK, P) - (t % chunks) * BA_CHUNK); };
+    auto count_of = [&](int t) {
+        const int r = t % nbi;
+        if (conv_h > 0) return (double)(min(4, conv_h - 4 * (r / nbx)) * min(32, conv_w - 32 * (r % nbx)));
+        return (double)(min((r + 1) * BA_CHUNK, P) - r * BA_CHUNK);
+    };
     const double N = (double)B * (double)P;
     double s = 0.0;
     for (int t = threadIdx.x; t < nt; t += BA_T) s += count_of(t) * (double)pm[t];
@@ -310,8 +317,20 @@ hipError_t bn_stats_run(const float* x, float* running_mean, float* running_var,
     float* part = static_cast<float*>(ws);
     if (training)
         hipLaunchKernelGGL(bn_act_stats_kernel, dim3(grid), dim3(BA_T), 0, stream, x, part, B, C, P, chunks);
-    hipLaunchKernelGGL(bn_act_finalize_kernel, dim3(C), dim3(BA_T), 0, stream, part, B, C, P, chunks, training, momentum,
+    hipLaunchKernelGGL(bn_act_finalize_kernel, dim3(C), dim3(BA_T), 0, stream, part, B, C, P, chunks, 0, 0, training, momentum,
                        eps, running_mean, running_var, save_mean, save_invstd);
+    return hipGetLastError();
+}
+
+// the same forward with the statistics pass replaced by partials a producer already holds (K11's epilogue): finalize + apply only
+hipError_t bn_act_fwd_part_run(const float* x, const float* conv_part, int H, int W, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, const float* residual, int B, int C, int act, int training,
+                               float momentum, float eps, float* y, float* save_mean, float* save_invstd, hipStream_t stream) {
+    const int P = H * W, chunks = ba_chunks(P), grid = B * C * chunks;
+    hipLaunchKernelGGL(bn_act_finalize_kernel, dim3(C), dim3(BA_T), 0, stream, conv_part, B, C, P, chunks, H, W, training, momentum,
+                       eps, running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_act_apply_kernel, dim3(grid), dim3(BA_T), 0, stream, x, save_mean, save_invstd, weight, bias,
+                       residual, C, P, chunks, act, y);
     return hipGetLastError();
 }
 

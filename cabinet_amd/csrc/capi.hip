@@ -67,6 +67,9 @@ hipError_t bn_act_fwd_run(const float* x, const float* weight, const float* bias
 hipError_t bn_act_bwd_run(const float* dy, const float* x, const float* weight, const float* bias,
                           const float* save_mean, const float* save_invstd, int B, int C, int P, int act, int training,
                           float* dx, float* dweight, float* dbias, void* ws, hipStream_t stream);
+hipError_t bn_act_fwd_part_run(const float* x, const float* conv_part, int H, int W, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, const float* residual, int B, int C, int act, int training,
+                               float momentum, float eps, float* y, float* save_mean, float* save_invstd, hipStream_t stream);
 size_t gate_act_workspace(int rows, int P);
 hipError_t gate_act_fwd_run(const float* x, const float* gate, int rows, int P, int act, float* y, hipStream_t stream);
 hipError_t gate_act_bwd_run(const float* dy, const float* x, const float* gate, int rows, int P, int act, float* dx,
@@ -260,6 +263,7 @@ int cabinet_ffm_fwd(const float* fsp, const float* fcp, const float* w_blk, cons
     if (!fsp || !fcp || !w_blk || !bn_weight || !bn_bias || !running_mean || !running_var || !w1 || !w2 ||
         !out || !z || !save_mean || !save_invstd || !pooled || !gate)
         return fail(CABINET_ERR_INVALID_ARG, "ffm_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ffm_fwd", fsp, fcp, w_blk, out, z);
     const size_t need = cabinet_ffm_fwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "ffm_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -286,6 +290,7 @@ int cabinet_ffm_bwd(const float* dout, const float* fsp, const float* fcp, const
         !save_invstd || !pooled || !gate || !dfsp || !dfcp || !dw_blk || !dbn_weight || !dbn_bias || !dw1 ||
         !dw2)
         return fail(CABINET_ERR_INVALID_ARG, "ffm_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ffm_bwd", dout, fsp, fcp, w_blk, z, dfsp, dfcp, dw_blk);
     const size_t need = cabinet_ffm_bwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "ffm_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -320,6 +325,7 @@ int cabinet_ffm_up_fwd(const float* fsp, const float* low, const float* w_blk, c
     if (!fsp || !low || !w_blk || !bn_weight || !bn_bias || !running_mean || !running_var || !w1 || !w2 || !out ||
         !z || !save_mean || !save_invstd || !pooled || !gate)
         return fail(CABINET_ERR_INVALID_ARG, "ffm_up_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ffm_up_fwd", fsp, low, w_blk, out, z);
     const size_t need = cabinet_ffm_up_fwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W, Hl, Wl);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "ffm_up_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -346,6 +352,7 @@ int cabinet_ffm_up_bwd(const float* dout, const float* fsp, const float* low, co
     if (!dout || !fsp || !low || !w_blk || !bn_weight || !bn_bias || !w1 || !w2 || !z || !save_mean ||
         !save_invstd || !pooled || !gate || !dfsp || !dlow || !dw_blk || !dbn_weight || !dbn_bias || !dw1 || !dw2)
         return fail(CABINET_ERR_INVALID_ARG, "ffm_up_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("ffm_up_bwd", dout, fsp, low, w_blk, z, dfsp, dlow, dw_blk);
     const size_t need = cabinet_ffm_up_bwd_workspace_bytes(B, Cs, Cc, Co, Cm, H, W, Hl, Wl);
     if (need && (!workspace || workspace_bytes < need))
         return fail(CABINET_ERR_WORKSPACE, "ffm_up_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -579,6 +586,7 @@ int cabinet_cab_qkv_fwd(const float* x, const float* wq, const float* wk, const 
         !bnk_bias || !bnk_running_mean || !bnk_running_var || !wpk || !wpv || !q || !k || !v || !zqk || !vv || !kk ||
         !pooled_k || !pooled_v || !save_mean || !save_invstd)
         return fail(CABINET_ERR_INVALID_ARG, "cab_qkv_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("cab_qkv_fwd", x, q, k, v, zqk, vv, kk);
     const size_t need = cabinet::qkv_fwd_workspace(s);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "cab_qkv_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -610,6 +618,7 @@ int cabinet_cab_qkv_bwd(const float* dq, const float* dk, const float* dv, const
         !wpv || !zqk || !vv || !kk || !pooled_k || !pooled_v || !save_mean || !save_invstd || !dx || !dwqk || !dwv ||
         !dbnq_weight || !dbnq_bias || !dbnk_weight || !dbnk_bias || !dwpk || !dwpv)
         return fail(CABINET_ERR_INVALID_ARG, "cab_qkv_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("cab_qkv_bwd", dq, dk, dv, x, zqk, vv, kk, dx);
     const size_t need = cabinet::qkv_bwd_workspace(s);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "cab_qkv_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -641,6 +650,7 @@ int cabinet_conv1x1_fwd(const float* x, const float* w, int B, int Ci, int Co, i
                         size_t workspace_bytes, cabinet_stream_t stream) {
     if (int rc = check_conv1x1(B, Ci, Co, P, "conv1x1_fwd")) return rc;
     if (!x || !w || !y) return fail(CABINET_ERR_INVALID_ARG, "conv1x1_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("conv1x1_fwd", x, w, y);
     const size_t need = cabinet::conv1x1_fwd_workspace(Ci, Co);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "conv1x1_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -656,6 +666,7 @@ int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, 
                         float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
     if (int rc = check_conv1x1(B, Ci, Co, P, "conv1x1_bwd")) return rc;
     if (!dy || !x || !w) return fail(CABINET_ERR_INVALID_ARG, "conv1x1_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("conv1x1_bwd", dy, x, w, dx, dw);
     const size_t need = cabinet::conv1x1_bwd_workspace(B, Ci, Co, P);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "conv1x1_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -683,6 +694,7 @@ int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias, f
     if (int rc = check_bn_act(B, C, P, act, "bn_act_fwd")) return rc;
     if (!x || !weight || !bias || !running_mean || !running_var || !y || !save_mean || !save_invstd)
         return fail(CABINET_ERR_INVALID_ARG, "bn_act_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("bn_act_fwd", x, residual, y);
     const size_t need = cabinet::bn_act_workspace(B, C, P);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "bn_act_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -692,12 +704,27 @@ int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias, f
                       "bn_act_fwd launch");
 }
 
+int cabinet_bn_act_fwd_part(const float* x, const float* conv_part, const float* weight, const float* bias, float* running_mean,
+                            float* running_var, const float* residual, int B, int C, int H, int W, int act, int training,
+                            float momentum, float eps, float* y, float* save_mean, float* save_invstd, cabinet_stream_t stream) {
+    if (H <= 0 || W <= 0) return fail(CABINET_ERR_INVALID_ARG, "bn_act_fwd_part: non-positive dimension");
+    if (int rc = check_bn_act(B, C, H * W, act, "bn_act_fwd_part")) return rc;
+    if (!x || !weight || !bias || !running_mean || !running_var || !y || !save_mean || !save_invstd || (training && !conv_part))
+        return fail(CABINET_ERR_INVALID_ARG, "bn_act_fwd_part: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("bn_act_fwd_part", x, residual, y);
+    return hip_status(cabinet::bn_act_fwd_part_run(x, conv_part, H, W, weight, bias, running_mean, running_var, residual, B, C, act,
+                                                   training, momentum, eps, y, save_mean, save_invstd,
+                                                   static_cast<hipStream_t>(stream)),
+                      "bn_act_fwd_part launch");
+}
+
 int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, const float* bias, const float* save_mean,
                        const float* save_invstd, int B, int C, int P, int act, int training, float* dx, float* dweight,
                        float* dbias, void* workspace, size_t workspace_bytes, cabinet_stream_t stream) {
     if (int rc = check_bn_act(B, C, P, act, "bn_act_bwd")) return rc;
     if (!dy || !x || !weight || !bias || !save_mean || !save_invstd || !dx || !dweight || !dbias)
         return fail(CABINET_ERR_INVALID_ARG, "bn_act_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("bn_act_bwd", dy, x, dx);
     const size_t need = cabinet::bn_act_workspace(B, C, P);
     if (!workspace || workspace_bytes < need)
         return fail(CABINET_ERR_WORKSPACE, "bn_act_bwd: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -540,9 +540,10 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     }
 
     // Software pipeline, one basic block per chunk (see wino_conv_kernel): a chunk is four k-steps of 8 MFMAs; between them sit
-    //   Q0  operand reads of k-step 1
-    //   Q1  operand reads of k-step 2, the border selects of chunk q+1's loaded values, stage A of the transforms (dM stored)
-    //   Q2  operand reads of k-step 3, stage B (V stored), the loads of chunk q+2      -- barrier --
+    //   Q0  operand reads of k-step 1, the border selects of chunk q+1's loaded values (their registers are then free)
+    //   Q1  operand reads of k-step 2, the loads of chunk q+2 (a whole chunk of MFMAs ahead of their use), stage A of the transforms
+    //       (dM stored)
+    //   Q2  operand reads of k-step 3, stage B (V stored)                              -- barrier --
     //   Q3  operand reads of k-step 0 of chunk q+1
     // (every range holds at least one chunk: nsplit <= nchunks)
     Pos p_cur = pos_of(q_lo), p_ld = p_cur;
@@ -560,22 +561,23 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
         // ---- Q0
         advance(p_cur, q + 1 < q_hi);   // position of chunk q + 1, whose values are in px / pg
         read_ops(o1, buf, 1);
+        select_chunk(p_cur);
         mfma_step(o0);
         WG_PIN(4, 0x100, 1)
+        WG_PIN(4, 0x002, 8)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q1
         read_ops(o0, buf, 2);
-        select_chunk(p_cur);
+        advance(p_ld, q + 2 < q_hi);
+        load_chunk(p_ld);
         stage_a(buf ^ 1);
         mfma_step(o1);
         WG_PIN(4, 0x100, 1)
-        WG_PIN(4, 0x002, 12)
+        WG_PIN(4, 0x002, 10)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q2
         read_ops(o1, buf, 3);
         stage_b(buf ^ 1);
-        advance(p_ld, q + 2 < q_hi);
-        load_chunk(p_ld);
         mfma_step(o0);
         WG_PIN(8, 0x002, 2)
         __builtin_amdgcn_sched_barrier(0);

@@ -128,7 +128,13 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
     extern __shared__ __attribute__((aligned(16))) float v[];  // [NH][C][Wl]
     __shared__ float s_f[NH][4];
     __shared__ int s_i[NH][3][4];
-    const int b = blockIdx.y, oy = blockIdx.x, P = H * W, nt = blockDim.x, CW = C * Wl;
+    // Grid (H, B) decoded XCD-aware (round 5): the dispatcher deals blocks round-robin over the 8 XCDs, so with
+    // oy = blockIdx.x the eight output rows that lerp the SAME two source rows ran on eight different XCDs and every private L2
+    // fetched those rows for itself (FETCH_SIZE x2 = 134 MB for 75 MB of inputs at config 3).  Each XCD now walks a contiguous
+    // chunk of the (image, output row) list: the source-row pair of a run of 8 rows is fetched into ONE L2.  `tile` = b H + oy
+    // also indexes the per-block partials, so cabinet_ohem_stats adds them in the order it always did.  Speed only.
+    const int tile = xcd_chunked_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int b = tile / H, oy = tile - b * H, P = H * W, nt = blockDim.x, CW = C * Wl;
     const size_t plane = (size_t)Hl * Wl;
     int y0, y1;
     float ly;
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
         // every upsampled logit is a convex combination of the interval's taps, so M = max over classes and taps bounds them
         // all (3 C maxima per interval instead of 8 C), and with xc - M staged once the per-pixel-and-class work is
         // fma + exp2 + add (it was fma + max + sub + exp2 + add).  M exceeds a pixel's own maximum by at most the spread of
-        // neighbouring source columns: exp2 of a few tens below zero, nowhere near underflow.
+        // neighbouring source columns: normally exp2 of a few tens below zero; when that spread passes ~100 the shifted sum
+        // underflows and the pixel is redone with its own maximum (the `se < 1e-30f` branch below).
         // (Measured and not kept, here and in the backward's x pass: two pixels per step as packed 2-vectors -- v_pk_fma_f32 /
         // v_pk_add_f32 halve the non-transcendental issue slots, and the time did not move: 75.7 vs 74.5 us, 72.2 vs 68.8 us.
         // These kernels are bound by v_exp_f32 (quarter rate) and by the load -> barrier start of their short workgroups.)
@@ -241,7 +248,23 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
 #pragma unroll
                     for (int c = 0; c < CMAX; ++c)
                         if (EXACT || c < C) se += fast_exp2(fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]));
-                    loss = ((big[hh] - xl) + fast_log2(se)) * LN2_F;
+                    float lse = fast_log2(se);
+                    if (se < 1e-30f) {
+                        // The interval bound M towers more than ~100 (log2 units: 70 nats) above every logit of THIS pixel -- a
+                        // spike in a neighbouring source column -- and the shifted sum has underflowed (se == 0 would make the
+                        // loss -inf and drop the pixel from the OHEM statistics; F.cross_entropy is exact for any finite logits).
+                        // Rare and divergent: redo the pixel with its own maximum.  
+                        float pm = -INFINITY;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (EXACT || c < C) pm = fmaxf(pm, fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]));
+                        float s2 = 0.f;
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (EXACT || c < C) s2 += fast_exp2(fmaf(t, j < 4 ? dm[hh][c] : dp[hh][c], xc[hh][c]) - pm);
+                        lse = pm + fast_log2(s2);
+                    }
+                    loss = ((big[hh] - xl) + lse) * LN2_F;
                     if (loss > thresh) {
                         my_above[hh] += 1;
                         my_sum[hh] += loss;
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(256) void ohem_up_fwd_x8_kernel(OhemFwdHeads<NH> hd
     }
     __syncthreads();
     if (threadIdx.x < NH) {
-        const int hh = threadIdx.x, blk = blockIdx.y * gridDim.x + blockIdx.x;
+        const int hh = threadIdx.x, blk = tile;
         float fs = 0.f;
         int nv = 0, na = 0, bad = 0;
         for (int w = 0; w < nw; ++w) fs += s_f[hh][w], nv += s_i[hh][0][w], na += s_i[hh][1][w], bad |= s_i[hh][2][w];

@@ -291,15 +291,20 @@ def gpu_local_cpus(local_rank, sysfs="/sys/class/drm", visible=None):
         except OSError:
             continue
     devs = [cards[k] for k in sorted(cards)]
-    if visible is None:
-        visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
-    if visible:
-        try:
-            devs = [devs[int(i)] for i in visible.split(",") if i.strip() != ""]
-        except (ValueError, IndexError):
-            return None, None  # UUID lists etc.: do not guess
+    # The visibility lists COMPOSE: ROCR_VISIBLE_DEVICES filters what the runtime sees, then HIP_VISIBLE_DEVICES (or its alias
+    # CUDA_VISIBLE_DEVICES, which HIP honours too) indexes into that.  `visible` (tests) = one explicit list.
+    lists = [visible] if visible is not None else [os.environ.get("ROCR_VISIBLE_DEVICES"),
+                                                     os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))]
+    for vis in lists:
+        if vis:
+            try:
+                devs = [devs[int(i)] for i in vis.split(",") if i.strip() != ""]
+            except (ValueError, IndexError):
+                return None, None  # UUID lists etc.: do not guess
     if not 0 <= local_rank < len(devs):
         return None, None
+    global _AFFINITY_PCI
+    _AFFINITY_PCI = os.path.basename(os.path.realpath(devs[local_rank]))  # cross-checked against the runtime's answer later
     try:
         node = int(open(os.path.join(devs[local_rank], "numa_node")).read().strip())
         cpus = _parse_cpulist(open(os.path.join(devs[local_rank], "local_cpulist")).read())
@@ -309,6 +314,22 @@ def gpu_local_cpus(local_rank, sysfs="/sys/class/drm", visible=None):
 
 
 AFFINITY = {"set": False, "why": "not attempted"}  # what init_distributed did, for the bench line
+_AFFINITY_PCI = None  # PCI address (sysfs) of the card the mask was taken from
+
+
+def check_affinity_device(device_index):
+    """After the device is up: does the runtime's device sit at the PCI address the affinity was taken from?  HIP's enumeration
+    order need not be PCI order; a mismatch costs performance only (a rank pinned to the other socket), so it is RECORDED in
+    AFFINITY (and thus in the bench line), never raised."""
+    if not AFFINITY.get("set") or _AFFINITY_PCI is None:
+        return AFFINITY
+    try:
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+        want = int(_AFFINITY_PCI.split(":")[1], 16)
+        AFFINITY["pci_matches_runtime"] = bool(int(bus) == want)
+    except Exception as e:  # noqa: BLE001  (a property this build lacks: say so)
+        AFFINITY["pci_matches_runtime"] = f"unknown ({type(e).__name__})"
+    return AFFINITY
 
 
 def set_rank_affinity(local_rank, sysfs="/sys/class/drm"):
@@ -353,8 +374,9 @@ def init_distributed(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force = os.environ.get("CABINET_FORCE_DDP") == "1"  # exercise the RCCL path on a single GPU (tests / bring-up)
+    share = os.environ.get("CABINET_SHARE_GPU") == "1"  # every rank on device 0 (gloo rehearsal on a single-GPU box)
     if world > 1:
-        set_rank_affinity(local)  # before the first GPU call below
+        set_rank_affinity(0 if share else local)  # before the first GPU call below; all ranks of a shared GPU take ITS node
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -366,6 +388,8 @@ def init_distributed(backend: Optional[str] = None):
                                     device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if os.environ.get("CABINET_SHARE_GPU") == "1":  # every rank on device 0 (gloo rehearsal on a single-GPU box)
+    if share:
         local = 0
+    if world > 1 and torch.cuda.is_available():
+        check_affinity_device(local)
     return rank, local, world

@@ -803,10 +803,10 @@ def conv3x3_bwd_hip(g, x0, x1, weight, need_dx=True, need_dw=True):
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(fn_ctx, x0, x1, weight):
+    def forward(fn_ctx, x0, x1, weight, bn_part=None):
         x0, weight = _f32c(x0), _f32c(weight)
         x1 = _f32c(x1) if x1 is not None else None
-        y = conv3x3_fwd_hip(x0, x1, weight)
+        y = conv3x3_fwd_hip(x0, x1, weight, bn_part)
         fn_ctx.save_for_backward(x0, x1, weight)
         return y
 
@@ -816,14 +816,23 @@ class _Conv3x3(torch.autograd.Function):
         x0, x1, weight = fn_ctx.saved_tensors
         need = fn_ctx.needs_input_grad
         dx0, dx1, dw = conv3x3_bwd_hip(_f32c(g), x0, x1, weight, need_dx=need[0] or (x1 is not None and need[1]), need_dw=need[2])
-        return dx0, dx1, dw
+        return (dx0, dx1, dw) + (None,) * (len(need) - 3)
 
 
-def conv3x3(x, weight, x1=None):
+def conv3x3_bn_part(x, out_channels):
+    """The (2, Co, blocks) buffer K11's epilogue fills with per-block (mean, M2) of its output for ``bn_act(..., conv_part=)``."""
+    B, _, H, W = x.shape
+    return torch.empty((2, out_channels, _lib.load().cabinet_conv3x3_tile_blocks(B, H, W)), dtype=torch.float32, device=x.device)
+
+
+def conv3x3(x, weight, x1=None, bn_part=None):
     """``F.conv2d(cat([x, x1], 1), weight, padding=1)`` (``x1`` optional) for a bias-free 3x3 stride-1 convolution of device
-    tensors, without the concat: reference cabinet.py:59, :68 + :88-89, :160."""
+    tensors, without the concat: reference cabinet.py:59, :68 + :88-89, :160.  ``bn_part`` (from :func:`conv3x3_bn_part`) receives
+    the statistics partials of the output for the training-mode BatchNorm that follows."""
     if not x.is_cuda:
         raise RuntimeError("conv3x3: device tensors only")
+    if bn_part is not None:
+        return _Conv3x3.apply(x, x1, weight, bn_part)
     return _Conv3x3.apply(x, x1, weight)
 
 
@@ -835,7 +844,7 @@ _ACT_CODES = {None: 0, "none": 0, "relu": 1, "hardswish": 2}
 class _BnAct(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(fn_ctx, x, weight, bias, run_mean, run_var, act, training, momentum, eps, residual=None):
+    def forward(fn_ctx, x, weight, bias, run_mean, run_var, act, training, momentum, eps, residual=None, conv_part=None):
         lib = _lib.load()
         x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
         residual = _f32c(residual) if residual is not None else None
@@ -844,12 +853,20 @@ class _BnAct(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws, nbytes = _workspace(lib.cabinet_bn_act_workspace_bytes(B, C, P), x.device)
-        with torch.cuda.device(x.device):
-            rc = lib.cabinet_bn_act_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(run_mean), _ptr(run_var), _ptr(residual), B, C, P, act,
-                                        int(training), float(momentum), float(eps), _ptr(y), _ptr(mean), _ptr(invstd),
-                                        _ptr(ws), nbytes, _stream_handle(x.device))
-        _lib.check(rc, "cabinet_bn_act_fwd")
+        if conv_part is not None and x.dim() == 4:
+            # x comes straight out of K11 with its per-block (mean, M2) pairs: no statistics pass over x
+            with torch.cuda.device(x.device):
+                rc = lib.cabinet_bn_act_fwd_part(_ptr(x), _ptr(conv_part), _ptr(weight), _ptr(bias), _ptr(run_mean), _ptr(run_var),
+                                                 _ptr(residual), B, C, x.shape[2], x.shape[3], act, int(training), float(momentum),
+                                                 float(eps), _ptr(y), _ptr(mean), _ptr(invstd), _stream_handle(x.device))
+            _lib.check(rc, "cabinet_bn_act_fwd_part")
+        else:
+            ws, nbytes = _workspace(lib.cabinet_bn_act_workspace_bytes(B, C, P), x.device)
+            with torch.cuda.device(x.device):
+                rc = lib.cabinet_bn_act_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(run_mean), _ptr(run_var), _ptr(residual), B, C, P,
+                                            act, int(training), float(momentum), float(eps), _ptr(y), _ptr(mean), _ptr(invstd),
+                                            _ptr(ws), nbytes, _stream_handle(x.device))
+            _lib.check(rc, "cabinet_bn_act_fwd")
         fn_ctx.save_for_backward(x, weight, bias, mean, invstd)
         fn_ctx.act, fn_ctx.training = act, bool(training)
         return y
@@ -872,14 +889,17 @@ class _BnAct(torch.autograd.Function):
         grads = (dx, dw, db, None, None, None, None, None, None)
         if len(fn_ctx.needs_input_grad) > 9:  # called with the optional residual operand: d(residual) = dy
             grads += (g if fn_ctx.needs_input_grad[9] else None,)
+        if len(fn_ctx.needs_input_grad) > 10:  # ... and the producer's statistics partials (a buffer, not a variable)
+            grads += (None,)
         return grads
 
 
-def bn_act(x, bn, act=None, residual=None):
+def bn_act(x, bn, act=None, residual=None, conv_part=None):
     """act(bn(x)) [+ residual] for a device tensor; ``bn`` is the nn.BatchNorm2d owning parameters and running
     buffers (updated in place in training mode), ``act`` one of None / "relu" / "hardswish"
     (reference cabinet.py:42-44, mobilenetv3.py:86-99); ``residual`` is the MBConv identity shortcut
-    (mobilenetv3.py:158), added in the same pass."""
+    (mobilenetv3.py:158), added in the same pass.  ``conv_part``: the (2, C, blocks) statistics partials ``conv3x3`` wrote
+    while it produced ``x`` -- the batch statistics then cost no pass over ``x``."""
     if not x.is_cuda:
         raise RuntimeError("bn_act: device tensors only (host tensors take the composite ATen path)")
     if act not in _ACT_CODES:
@@ -887,6 +907,9 @@ def bn_act(x, bn, act=None, residual=None):
     training, momentum = _bn_step(bn)
     if residual is not None and residual.shape != x.shape:
         raise RuntimeError(f"bn_act: residual {tuple(residual.shape)} does not match x {tuple(x.shape)}")
+    if conv_part is not None:
+        return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _ACT_CODES[act], training, momentum,
+                            bn.eps, residual, conv_part)
     return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _ACT_CODES[act], training, momentum,
                         bn.eps, residual)
 

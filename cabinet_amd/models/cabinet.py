@@ -25,8 +25,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as _functional
-from ..functional import (batched_bn_counters, bn_act, conv3x3, conv3x3_supported, ffm_fused, ffm_fused_upsampled,
-                          stem_conv, stem_conv_supported)
+from ..functional import (batched_bn_counters, bn_act, conv3x3, conv3x3_bn_part, conv3x3_supported, ffm_fused,
+                          ffm_fused_upsampled, stem_conv, stem_conv_supported)
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -44,13 +44,16 @@ def _is_plain_3x3(conv: nn.Conv2d) -> bool:
             conv.groups == 1 and conv.bias is None and conv.padding_mode == "zeros")
 
 
-def _conv3x3_or_stock(conv: nn.Conv2d, x: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``conv(cat([x, x1], 1))`` (``x1`` optional): on device tensors K11's fused Winograd kernels when the layer is a plain 3x3
-    with channel counts inside their coverage (the concat is then never materialised), else the stock convolution."""
+def _conv3x3_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``relu(bn(conv(cat([x, x1], 1))))`` (``x1`` optional) on device tensors: K11's fused Winograd kernels when the layer is a plain
+    3x3 with channel counts inside their coverage -- the concat is then never materialised and, in training mode, the BatchNorm's
+    batch statistics come out of the convolution's epilogue (no statistics pass over its output) -- else the stock convolution;
+    K7 (BatchNorm + ReLU in one streaming pass) either way."""
     c1 = 0 if x1 is None else x1.shape[1]
-    if x.is_cuda and _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels):
-        return conv3x3(x, conv.weight, x1)
-    return conv(x if x1 is None else torch.cat([x, x1], dim=1))
+    if _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels):
+        part = conv3x3_bn_part(x, conv.out_channels) if bn.training else None
+        return bn_act(conv3x3(x, conv.weight, x1, part), bn, "relu", conv_part=part)
+    return bn_act(conv(x if x1 is None else torch.cat([x, x1], dim=1)), bn, "relu")
 
 
 class ConvBNReLU(nn.Module):
@@ -65,13 +68,12 @@ class ConvBNReLU(nn.Module):
         self.init_weight()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.is_cuda and x.shape[1] == 3 and stem_conv_supported(self.conv):
-            x = stem_conv(x, self.conv)  # K9: the 7x7/2 image stem without NHWC round trips
-        else:
-            x = _conv3x3_or_stock(self.conv, x)  # K11 for conv_out's 256 -> 256 3x3 (cabinet.py:160)
-        if x.is_cuda:  # K7: BatchNorm + ReLU in one streaming pass pair instead of two library launches
-            return bn_act(x, self.bn, "relu")
-        return self.relu(self.bn(x))
+        if not x.is_cuda:
+            return self.relu(self.bn(self.conv(x)))
+        if x.shape[1] == 3 and stem_conv_supported(self.conv):
+            # K9: the 7x7/2 image stem without NHWC round trips; K7: BatchNorm + ReLU in one streaming pass pair
+            return bn_act(stem_conv(x, self.conv), self.bn, "relu")
+        return _conv3x3_bn_relu(self.conv, self.bn, x)  # K11 for conv_out's 256 -> 256 3x3 (cabinet.py:160)
 
     def init_weight(self) -> None:
         nn.init.kaiming_normal_(self.conv.weight, a=1)
@@ -96,10 +98,10 @@ class AttentionBranch(nn.Module):
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if x.is_cuda:
-            feat = self.a2block(bn_act(_conv3x3_or_stock(self.conva[0], x), self.conva[1], "relu"))
+            feat = self.a2block(_conv3x3_bn_relu(self.conva[0], self.conva[1], x))
             low_res_out = self.convb(feat)
             # K11 reads x and feat through two pointers: the (B, inplanes + 256, H', W') concat is never written
-            return low_res_out, self.b4(bn_act(_conv3x3_or_stock(self.b1, x, feat), self.b2, "relu"))
+            return low_res_out, self.b4(_conv3x3_bn_relu(self.b1, self.b2, x, feat))
         feat = self.a2block(self.conva(x))
         low_res_out = self.convb(feat)
         high_res_out = self.b4(self.b3(self.b2(self.b1(torch.cat([x, feat], dim=1)))))

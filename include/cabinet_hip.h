@@ -13,8 +13,10 @@
  *    device.  Pointers are borrowed; nothing is retained after the call returns.
  *  - Tensor pointers must be 16-byte aligned: the kernels move rows with 128-bit
  *    loads and stores.  (Any allocator's base pointer is; a view that starts 4 or
- *    8 bytes into an allocation is not -- copy it first.)  The attention and OHEM
- *    entry points check it and return CABINET_ERR_INVALID_ARG.
+ *    8 bytes into an allocation is not -- copy it first.)  The attention, OHEM, FFM,
+ *    q/k/v producer, 1x1 / 3x3 convolution and BatchNorm entry points check the
+ *    activation and weight pointers they move that way and return
+ *    CABINET_ERR_INVALID_ARG for a misaligned one.
  *  - Every call is asynchronous on `stream` (a hipStream_t; NULL = the default
  *    stream).  No call synchronises, allocates device memory or uses a private
  *    stream, so calls are hipGraph-capturable and re-entrant.
@@ -318,6 +320,13 @@ int cabinet_bn_act_fwd(const float* x, const float* weight, const float* bias,
                        int B, int C, int P, int act, int training, float momentum, float eps,
                        float* y, float* save_mean, float* save_invstd,
                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+/* The same forward when x (B,C,H,W) was just produced by cabinet_conv3x3_fwd with `bn_part`: the batch statistics come from
+ * those per-block (mean, M2) pairs (Chan-merged in double, as above) and the statistics pass over x is skipped.
+ * conv_part: [2][C][cabinet_conv3x3_tile_blocks(B,H,W)] floats; ignored when training == 0. */
+int cabinet_bn_act_fwd_part(const float* x, const float* conv_part, const float* weight, const float* bias,
+                            float* running_mean, float* running_var, const float* residual /* nullable */,
+                            int B, int C, int H, int W, int act, int training, float momentum, float eps,
+                            float* y, float* save_mean, float* save_invstd, cabinet_stream_t stream);
 int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, const float* bias,
                        const float* save_mean, const float* save_invstd,
                        int B, int C, int P, int act, int training,

@@ -48,9 +48,9 @@ def instrument(net):
         keep("mob", out)
 
     net.mobile.register_forward_hook(mobile_hook)
-    # the fusion head next to the CAB (reference cabinet.py:88-92, outside section 8): b1's output and the ReLU output that feeds b4
+    # the fusion head next to the CAB (reference cabinet.py:88-92): b1's output and the ReLU output that feeds b4
 
-    def b1_hook(module, args, out):
+    def b1_hook(module, args, out):   # the stock convolution (CABINET_CONV3X3=0, or channel counts outside K11's coverage)
         keep("ab.b1o", out)
 
     def b4_pre_hook(module, args):
@@ -58,7 +58,53 @@ def instrument(net):
 
     net.ab.b1.register_forward_hook(b1_hook)
     net.ab.b4.register_forward_pre_hook(b4_pre_hook)
+    # K11 (round 5): the three plain 3x3 convolutions of the decoder run through cabinet_amd.functional.conv3x3 with the layer's
+    # weight, not through nn.Conv2d.forward, so they are captured at that call: inputs, output and the gradients autograd sends back
+    _K11_REGISTRY.update({id(net.ab.conva[0].weight): (cap, keep, "ab.conva"), id(net.ab.b1.weight): (cap, keep, "ab.b1"),
+                          id(net.conv_out.conv.conv.weight): (cap, keep, "conv_out.conv")})
+    _install_k11_spy()
     return cap
+
+
+_K11_REGISTRY = {}
+
+
+def _install_k11_spy():
+    import cabinet_amd.models.cabinet as cm
+
+    if getattr(cm.conv3x3, "_insitu_spy", False):
+        return
+    orig = cm.conv3x3
+
+    def conv3x3_spy(x, weight, x1=None, bn_part=None):
+        hit = _K11_REGISTRY.get(id(weight))
+        if hit is None:
+            return orig(x, weight, x1, bn_part)
+        cap, keep, name = hit
+        # a VIEW of each input goes into the convolution: the hook on the view sees the gradient of THIS use only (the mobile
+        # features feed conva and b1, the CAB output feeds convb and b1: a hook on the tensor itself would see the sums)
+        x = keep(name + ".x", x.view_as(x))
+        if x1 is not None:
+            x1 = keep(name + ".x1", x1.view_as(x1))
+        y = keep(name + ".y", orig(x, weight, x1, bn_part))
+        if name == "ab.b1":
+            cap["ab.b1o"] = cap["ab.b1.y"]
+            y.register_hook(lambda g: cap.__setitem__("d.ab.b1o", g.detach().clone()))
+        return y
+
+    conv3x3_spy._insitu_spy = True
+    cm.conv3x3 = conv3x3_spy
+
+
+def replay_conv3x3(weight, x, x1, g, dtype):
+    """The reference's nn.Conv2d(3x3, padding=1, bias=False) (cabinet.py:59, :88-89, :160) on captured tensors:
+    -> y, dx, dx1 (None without a second input), dw."""
+    xo = x.detach().cpu().to(dtype).requires_grad_(True)
+    x1o = x1.detach().cpu().to(dtype).requires_grad_(True) if x1 is not None else None
+    w = weight.detach().cpu().to(dtype).requires_grad_(True)
+    y = torch.nn.functional.conv2d(torch.cat([xo, x1o], 1) if x1o is not None else xo, w, padding=1)
+    y.backward(g.detach().cpu().to(dtype))
+    return y.detach(), xo.grad, (x1o.grad if x1o is not None else None), w.grad
 
 
 def rel(a, b):
@@ -179,6 +225,19 @@ def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True, training=T
     for k, v in g64.items():
         put("ffm." + k, grads["ffm." + k], v, g32.get(k))
     del res
+    # ---- K11: the decoder's three plain 3x3 convolutions (conva, the two-pointer fusion head b1, conv_out.conv), when they ran
+    # through K11 (captured at the conv3x3 call, each input through a view of its own: the gradients are this use's alone)
+    for name, wkey in (("ab.conva", "ab.conva.0.weight"), ("ab.b1", "ab.b1.weight"), ("conv_out.conv", "conv_out.conv.conv.weight")):
+        if name + ".y" not in cap or "d." + name + ".y" not in cap:
+            continue
+        x1 = cap.get(name + ".x1")
+        y64, dx64, dx164, dw64 = replay_conv3x3(sd[wkey], cap[name + ".x"], x1, cap["d." + name + ".y"], torch.float64)
+        put(name + ".out", cap[name + ".y"], y64)
+        put(name + ".dw", grads[wkey], dw64)
+        put(name + ".dx", cap["d." + name + ".x"], dx64)
+        if x1 is not None:
+            put(name + ".dx1", cap["d." + name + ".x1"], dx164)
+        del y64, dx64, dx164, dw64
     # ---- the fusion head's BatchNorm + ReLU next to the CAB (K7; outside section 8, but the chain tables put the entry point
     # of the gradient noise between d.ab.r and d.ab.b1o: own-mask replay = arithmetic, fp64-mask replay = arithmetic + flips)
     b2 = replay_b2(sd, cap["ab.b1o"], cap["ab.r"], cap["d.ab.r"], training)

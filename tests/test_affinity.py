@@ -39,6 +39,24 @@ def test_gpu_to_numa_cores(tmp_path):
     assert ddp.gpu_local_cpus(0, str(tmp_path / "nowhere")) == (None, None)
 
 
+def test_visibility_lists_compose_and_cuda_alias_is_honoured(tmp_path, monkeypatch):
+    """ROCR_VISIBLE_DEVICES filters what the runtime sees, HIP_VISIBLE_DEVICES (alias: CUDA_VISIBLE_DEVICES) indexes into THAT
+    (ADVICE r04); the chosen card's PCI address is remembered for the cross-check against the runtime."""
+    gpus = [("0000:05:00.0", 0, "0-3"), ("0000:45:00.0", 0, "4-7"), ("0000:85:00.0", 1, "8-11"), ("0000:c5:00.0", 1, "12-15")]
+    sysfs = _fake_sysfs(str(tmp_path), gpus)
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,3,0")
+    assert ddp.gpu_local_cpus(0, sysfs) == (set(range(8, 12)), 1)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,2")          # of (2, 3, 0): cards 3 and 0
+    assert ddp.gpu_local_cpus(0, sysfs) == (set(range(12, 16)), 1) and ddp._AFFINITY_PCI == "0000:c5:00.0"
+    assert ddp.gpu_local_cpus(1, sysfs) == (set(range(0, 4)), 0) and ddp._AFFINITY_PCI == "0000:05:00.0"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "1")           # HIP honours the CUDA spelling too
+    assert ddp.gpu_local_cpus(0, sysfs) == (set(range(4, 8)), 0)
+
+
 def test_set_rank_affinity_pins_and_never_fails(tmp_path, monkeypatch):
     allowed = sorted(os.sched_getaffinity(0))
     if len(allowed) < 2:
@@ -49,6 +67,7 @@ def test_set_rank_affinity_pins_and_never_fails(tmp_path, monkeypatch):
     sysfs = _fake_sysfs(str(tmp_path), [("0000:05:00.0", 0, ",".join(map(str, half)))])
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
     try:
         info = ddp.set_rank_affinity(0, sysfs)
         assert info == {"set": True, "numa_node": 0, "cpus": len(half)} and os.sched_getaffinity(0) == set(half)

@@ -197,6 +197,32 @@ def test_conv3x3_production_grids_adjoint_identities_and_spot_values(name):
     assert abs(ip_y - ip_x) < 1e-6 * scale and abs(ip_y - ip_w) < 1e-6 * scale, (name, ip_y, ip_x, ip_w, scale)
 
 
+def test_bn_act_from_conv_partials_equals_bn_act_with_its_own_statistics_pass():
+    """cabinet_bn_act_fwd_part (statistics from K11's epilogue) against cabinet_bn_act_fwd (its own pass over x) and against
+    torch's BatchNorm2d in fp64: output, saved statistics and running buffers; odd sizes (ragged blocks) included."""
+    from cabinet_amd.functional import bn_act, conv3x3, conv3x3_bn_part
+
+    for (B, C, K, H, W) in [(2, 64, 64, 9, 35), (4, 64, 128, 32, 32), (1, 128, 64, 5, 70)]:
+        x0, _, w, _ = _case(B, C, 0, K, H, W, seed=31)
+        xd, wd = x0.cuda(), w.cuda()
+        bn_a, bn_b = torch.nn.BatchNorm2d(K).cuda().train(), torch.nn.BatchNorm2d(K).cuda().train()
+        with torch.no_grad():
+            bn_a.weight.uniform_(0.5, 1.5), bn_a.bias.normal_()
+            bn_b.load_state_dict(bn_a.state_dict())
+        part = conv3x3_bn_part(xd, K)
+        y = conv3x3(xd, wd, None, part)
+        out_a = bn_act(y, bn_a, "relu", conv_part=part)
+        out_b = bn_act(y, bn_b, "relu")
+        torch.cuda.synchronize()
+        assert rel(out_a, out_b) < 1e-6
+        assert rel(bn_a.running_mean, bn_b.running_mean) < 1e-6 and rel(bn_a.running_var, bn_b.running_var) < 1e-6
+        ref_bn = torch.nn.BatchNorm2d(K).double().train()
+        ref_bn.load_state_dict({k: v.double().cpu() for k, v in bn_b.state_dict().items() if k not in ("running_mean", "running_var", "num_batches_tracked")}, strict=False)
+        ref = torch.relu(ref_bn(y.double().cpu()))
+        assert rel(out_a, ref) < 1e-5
+        assert rel(bn_a.running_var, ref_bn.running_var) < 1e-5 and int(bn_a.num_batches_tracked) == 1
+
+
 def test_conv3x3_c_abi_errors():
     """Error behaviour of the entry points (include/cabinet_hip.h): unsupported channel counts, a short workspace and a misaligned
     pointer are error codes with a message, never a launch."""
@@ -235,9 +261,9 @@ def test_model_uses_k11_for_its_three_plain_3x3_convolutions(monkeypatch):
     calls = []
     orig = Fn._Conv3x3.apply
 
-    def spy(x0, x1, weight):
-        calls.append((tuple(x0.shape), None if x1 is None else tuple(x1.shape), tuple(weight.shape)))
-        return orig(x0, x1, weight)
+    def spy(x0, x1, weight, *part):
+        calls.append((tuple(x0.shape), None if x1 is None else tuple(x1.shape), tuple(weight.shape), len(part)))
+        return orig(x0, x1, weight, *part)
 
     monkeypatch.setattr(Fn._Conv3x3, "apply", staticmethod(spy))
     net = build_model("small", n_classes=8, device="cuda", seed=0, gamma=0.5).train()
@@ -245,6 +271,7 @@ def test_model_uses_k11_for_its_three_plain_3x3_convolutions(monkeypatch):
     out, out16 = net(im)
     assert [c[2] for c in calls] == [(256, 576, 3, 3), (256, 832, 3, 3), (256, 256, 3, 3)], calls
     assert calls[1][1] == (2, 256, 4, 4)   # feat rides along as the second pointer
+    assert all(c[3] == 1 for c in calls)   # training mode: each hands its BatchNorm the statistics partials of its epilogue
     monkeypatch.setattr(Fn, "CONV3X3_ENABLED", False)
     net2 = build_model("small", n_classes=8, device="cuda", seed=0, gamma=0.5).train()
     n_before = len(calls)

@@ -127,7 +127,9 @@ def _full_step(mode, batch, height, width, ncls, tag):
                            "reference against ITSELF with another summation order")
     del ref32_1t
     cab_insitu = cab_table(net, sd, cap)  # which CAB gradients of THIS run are exact on the model's own tensors
-    failures, listed = judge_gradients(rows, load_allowlist()[tag], cab_insitu)
+    # the in-situ-backed clause is gated on what ENTERS the CAB's backward in this run: d(cab.y) against the fp64 model's
+    failures, listed = judge_gradients(rows, load_allowlist()[tag], cab_insitu,
+                                       upstream={"d.cab.y": rel(cap["d.cab.y"], taps64["d.cab.y"])})
     worst = sorted(((r["gpu_vs_f64"], k) for k, r in rows.items() if not r["analytic_zero"]), reverse=True)[:10]
     # Where the gradient noise enters: distance from the fp64 model of every tensor either side of the
     # hot path, for the HIP model and for the fp32 CPU reference ...

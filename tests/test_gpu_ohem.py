@@ -52,6 +52,47 @@ def test_fused_ohem_vs_oracle(B, C, Hl, Wl, H, W, ignore_frac, thresh, n_min):
         assert x.grad is None or float(x.grad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_fused_ohem_with_a_200_nat_spike_in_one_low_res_column(paired):
+    """the x8 forward shifts the log-sum-exp of an interval's eight pixels by ONE bound (maximum over classes and the
+    three taps).  A +200 logit in one low-resolution column puts that bound ~288 (log2 units) above every logit of pixels whose own
+    convex combination gives the spike almost no weight... and zero weight for the pixels of the NEIGHBOURING interval's far half:
+    their shifted sum underflows.  F.cross_entropy is exact for any finite logits: per-pixel loss, loss and gradient must match the
+    fp64 oracle, and no pixel may drop out as -inf."""
+    from cabinet_amd.functional import ohem_up_fwd_hip
+    from cabinet_amd.loss import OhemCELoss, ohem_upsampled_pair
+    from oracle.model_ref import ohem_ce
+
+    B, C, Hl, Wl, H, W = 1, 8, 4, 64, 32, 512
+    g = torch.Generator().manual_seed(77)
+    low = torch.randn(B, C, Hl, Wl, generator=g)
+    low[0, 3, 1, 20] += 200.0          # one spike
+    low[0, 5, 2, 40:42] -= 150.0       # and a deep trough pair (every OTHER class towers above it)
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    n_min = H * W // 16
+    ref_in = low.double().requires_grad_(True)
+    up = F.interpolate(ref_in, size=(H, W), mode="bilinear", align_corners=False)
+    ref = ohem_ce(up, lab, 0.7, n_min)
+    ref.backward()
+    px_ref = F.cross_entropy(up.detach(), lab, reduction="none")
+    x = low.cuda().requires_grad_(True)
+    loss_px = ohem_up_fwd_hip(x.detach(), lab.cuda(), (H, W), 0.7, 255)[0]
+    assert bool(torch.isfinite(loss_px).all())
+    assert_close(loss_px.view(B, H, W), px_ref, 1e-5, "per-pixel loss", atol=1e-5)
+    crit = OhemCELoss(0.7, n_min, 255).cuda()
+    if paired:
+        x2 = low.cuda().requires_grad_(True)
+        loss = ohem_upsampled_pair(crit, x, OhemCELoss(0.7, n_min, 255).cuda(), x2, lab.cuda(), (H, W))
+        want = 2 * float(ref)
+    else:
+        loss = crit.forward_upsampled(x, lab.cuda(), (H, W))
+        want = float(ref)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - want) <= 1e-5 * abs(want)
+    assert_close(x.grad, ref_in.grad, TOL, "dlogits_low", atol=1e-9)
+
+
 def test_row_kernel_equals_segment_kernel():
     """The round-4 x pass (whole source rows per wave, resize adjoint in registers) against the round-3 segment kernel it
     replaces for W == 8 Wl, Wl % 64 == 0 -- same forward state, both heads, ignored pixels, a border-heavy narrow case."""
