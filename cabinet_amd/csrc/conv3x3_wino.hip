@@ -38,6 +38,7 @@ constexpr int WN_KB = 64;   // output channels per workgroup
 constexpr int WN_TB = 32;   // tiles per workgroup: 2 tile rows x 16 tile columns
 constexpr int WN_CC = 16;   // input channels per chunk
 constexpr int WN_VBUF = 16 * WN_CC * WN_TB;   // floats of one staged V chunk (32 KB)
+constexpr int WN_OOB = 0x40000000;           // byte offset of a tap outside the image: beyond every buffer resource (< 1 GB), no 32-bit wrap when two add up
 
 struct WinoArgs {
     const float* x0;   // (B, C0, H, W)
@@ -124,41 +125,43 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar, or every load offset built from it becomes a waterfall loop
+    // The channel block is the SLOW index of the XCD-chunked tile list: an XCD works on one 64-channel slice of U (3.9 MB at C = 960)
+    // and its share of the tile blocks.  (Measured and not kept: the channel block as the FAST index, so that an XCD fetches each
+    // input row once instead of once per channel block -- conv_out's 680 MB of fabric reads are Infinity-Cache hits, 683 vs 690 us;
+    // s_setprio 1 for waves 4-7: 185 vs 185, 223 vs 220, 688 vs 694 us.)
     const int tau = xcd_chunked_tile(blockIdx.x, a.ntb * a.nkb);
     const int kblk = tau / a.ntb, tb = tau - kblk * a.ntb;
     const int per_img = a.nby * a.nbx, b = tb / per_img, rem = tb - b * per_img, by = rem / a.nbx, bx = rem - by * a.nbx;
     const int HW = a.H * a.W, C = a.C0 + a.C1, nch = C / WN_CC, nch0 = a.C0 / WN_CC;
 
     // ---- this thread's patch: tile li of the block, channel 2 wave + h of the chunk --------------------------------------
+    // Zero padding costs nothing: a raw buffer load whose offset (per-lane + scalar) lies outside the resource returns 0 -- measured,
+    // tools/buf_oob_probe.hip: the range check covers voffset + soffset -- so a tap outside the image gets an offset of WN_OOB
+    // (>= every image tensor, which conv3x3_shape_ok keeps below 1 GB) instead of a clamped address and a select behind the load
+    // (round 5's first version: 16 v_cndmask per chunk and thread).
     const int ty = 2 * by + (li >> 4), tx = 16 * bx + (li & 15);
-    int roff[4], coff[4];
-    bool rv[4], cv[4];
+    int poff[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = 2 * ty - 1 + i, c = 2 * tx - 1 + i;
-        rv[i] = (unsigned)r < (unsigned)a.H, cv[i] = (unsigned)c < (unsigned)a.W;
-        roff[i] = (min(max(r, 0), a.H - 1) * a.W + (2 * wave + h) * HW) * 4;
-        coff[i] = min(max(c, 0), a.W - 1) * 4;
+        const int r = 2 * ty - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 2 * tx - 1 + j;
+            poff[4 * i + j] = ((unsigned)r < (unsigned)a.H && (unsigned)c < (unsigned)a.W) ? ((2 * wave + h) * HW + r * a.W + c) * 4 : WN_OOB;
+        }
     }
     const buf_rsrc rx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)((size_t)a.C0 * HW * 4));
     const buf_rsrc rx1 = make_rsrc(a.x1 ? a.x1 + (size_t)b * a.C1 * HW : a.x0, (unsigned)((size_t)(a.x1 ? a.C1 : a.C0) * HW * 4));
     float pd[16];
-    auto load_patch = [&](int n) {   // chunk n -> pd (zero padding applied when the values are used)
+    auto load_patch = [&](int n) {   // chunk n -> pd, zero padding included
         const bool first = n < nch0;   // wave-uniform
         const int soff = (first ? n : n - nch0) * WN_CC * HW * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                pd[4 * i + j] = bload(first ? rx0 : rx1, roff[i] + coff[j], soff);
+        for (int e = 0; e < 16; ++e) pd[e] = bload(first ? rx0 : rx1, poff[e], soff);
     };
     auto transform_store = [&](int buf) {
-        float d[16], v[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[4 * i + j] = (rv[i] && cv[j]) ? pd[4 * i + j] : 0.f;
-        wino_bt_d_b(d, v);
+        float v[16];
+        wino_bt_d_b(pd, v);
         float* dst = smem + buf * WN_VBUF + (2 * wave + h) * WN_TB + li;
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) dst[xi * WN_CC * WN_TB] = v[xi];
@@ -190,20 +193,20 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
 
     // ---- the chunk loop as ONE basic block per chunk, software-pipelined --------------------------------------------------------
     // A chunk is 32 MFMAs per wave (2 xi x 2 channel blocks x 8 k-steps) = 2048 cycles of the SIMD's matrix pipe; everything else a
-    // wave does for a chunk -- 8 filter loads, 16 patch loads, the input transform of the NEXT chunk (16 selects + 32 additions),
+    // wave does for a chunk -- 8 filter loads, 16 patch loads, the input transform of the NEXT chunk (32 additions),
     // 8 LDS stores, 8 LDS operand reads -- is ~100 instructions that must sit BETWEEN its MFMAs, or the two waves of a SIMD (in
     // lockstep through the barrier) leave the matrix pipe idle while they both transform: the first version, with the transform in
     // its own conditional block behind the 32 MFMAs, ran at 0.51 MFMA busy (profiles/r05_conv3x3_first_counters.json).  So the tail
     // is handled by clamping the chunk index (the last chunk transforms a chunk nobody reads) instead of branching, and four fenced
     // quarters of 8 MFMAs carry:
-    //   Q0  the filter loads of chunk n+1, the LDS operand reads of this chunk's second half, the 16 border selects of patch n+1
-    //   Q1  the 32 additions of B^T d B, then the 16 loads of patch n+2 (their registers are free once the selects have run)
+    //   Q0  the filter loads of chunk n+1, the LDS operand reads of this chunk's second half
+    //   Q1  the 32 additions of B^T d B on patch n+1, then the 16 loads of patch n+2 into the registers they free
     //   Q2  the 16 LDS stores of V[n+1]            -- barrier: V[n+1] is complete --
     //   Q3  the LDS operand reads of chunk n+1's first half (so no MFMA waits for LDS after the barrier)
     // All reads of V[n] are issued by the end of Q0 of chunk n, i.e. in front of barrier n; V[n+2] is written behind barrier n+1:
     // two buffers suffice.
     float bva[2][4], bvb[2][4];   // B operands (V) of half 0 / half 1 of the current chunk: [xi][k-step]
-    float dsel[16], vout[16];
+    float vout[16];
     auto read_v = [&](float (&dst)[2][4], int buf, int hc) {
         const float* vb = smem + buf * WN_VBUF + (2 * wave) * WN_CC * WN_TB + h * WN_TB + li;
 #pragma unroll
@@ -232,16 +235,12 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         load_u(unext, n1);
         read_v(bvb, buf, 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dsel[4 * i + j] = (rv[i] && cv[j]) ? pd[4 * i + j] : 0.f;
         mfma_quarter(ucur, bva, 0, 0);
         WN_PIN(4, 0x020, 2)    // 8 filter loads
         WN_PIN(4, 0x100, 2)    // LDS operand reads (ds_read2: 4 instructions; the recipe tolerates fewer)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q1
-        wino_bt_d_b(dsel, vout);
+        wino_bt_d_b(pd, vout);
         load_patch(n2);
         mfma_quarter(ucur, bva, 0, 2);
         WN_PIN(8, 0x002, 4)    // 32 additions
@@ -424,59 +423,46 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
 
     float px[16];
     f32x2 pg[2];
+    // zero padding and masked tiles through the buffer range check (see wino_conv_kernel): a tap outside the image -- row term in the
+    // scalar offset, column term in the per-lane offset -- is WN_OOB away and loads as 0; no clamps, no selects
     auto load_chunk = [&](const Pos& p) {
         const int tx = 8 * p.cx + tt;
-        // x patch: rows 2 ty - 1 + i (scalar), columns 2 tx - 1 + j (per lane); clamped addresses, zeros applied when used
         const buf_rsrc rx = make_rsrc(xsrc + (size_t)p.b * Cx * HW, (unsigned)((size_t)Cx * HW * 4));
         int cof[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cof[j] = (min(max(2 * tx - 1 + j, 0), a.W - 1) + (cfirst + ch) * HW) * 4;
+        for (int j = 0; j < 4; ++j) {
+            const int c = 2 * tx - 1 + j;
+            cof[j] = (unsigned)c < (unsigned)a.W ? (c + (cfirst + ch) * HW) * 4 : WN_OOB;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int so = min(max(2 * p.ty - 1 + i, 0), a.H - 1) * a.W * 4;
+            const int r = 2 * p.ty - 1 + i;
+            const int so = (unsigned)r < (unsigned)a.H ? r * a.W * 4 : WN_OOB;
 #pragma unroll
             for (int j = 0; j < 4; ++j) px[4 * i + j] = bload(rx, cof[j], so);
         }
         // dy tile: rows 2 ty, 2 ty + 1, columns 2 tx, 2 tx + 1
         const buf_rsrc rg = make_rsrc(a.dy + (size_t)p.b * a.K * HW, (unsigned)((size_t)a.K * HW * 4));
-        const int gx = min(2 * tx, a.W - 1), go = ((kblk * WG_KB + ch) * HW + gx) * 4;
+        const int gbase = (kblk * WG_KB + ch) * HW + 2 * tx;
+        const int g0 = 2 * tx < a.W ? gbase * 4 : WN_OOB, g1 = 2 * tx + 1 < a.W ? (gbase + 1) * 4 : WN_OOB;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int so = min(2 * p.ty + r, a.H - 1) * a.W * 4;
-            if constexpr (EVEN_W) pg[r] = bload2(rg, go, so);
-            else pg[r][0] = bload(rg, go, so), pg[r][1] = bload(rg, ((kblk * WG_KB + ch) * HW + min(2 * tx + 1, a.W - 1)) * 4, so);
+            const int so = 2 * p.ty + r < a.H ? (2 * p.ty + r) * a.W * 4 : WN_OOB;
+            if constexpr (EVEN_W) pg[r] = bload2(rg, g0, so);   // W even: column 2 tx + 1 is inside whenever 2 tx is
+            else pg[r][0] = bload(rg, g0, so), pg[r][1] = bload(rg, g1, so);
         }
     };
-    float dsel[16], gsel[4];   // selected patch / after stage 1 of B^T d B: t = B^T d (in place)
-    auto select_chunk = [&](const Pos& p) {   // zero padding / masked tiles applied to the loaded values
-        const int tx = 8 * p.cx + tt;
-        // the tile row is wave-uniform; seen as such, every `row valid ? x : 0` becomes a scalar BRANCH around the selects and cuts
-        // the chunk's basic block into pieces the pinned schedule cannot cross: made opaque, it is a lane mask like the column's
-        int ty = p.ty;
-        asm volatile("" : "+v"(ty));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool rvi = (unsigned)(2 * ty - 1 + i) < (unsigned)a.H;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)   // `&`, not `&&`: a select, not control flow
-                dsel[4 * i + j] = (rvi & ((unsigned)(2 * tx - 1 + j) < (unsigned)a.W)) ? px[4 * i + j] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const bool rvr = 2 * ty + r < a.H;
-            gsel[2 * r + 0] = (rvr & (2 * tx < a.W)) ? pg[r][0] : 0.f;
-            gsel[2 * r + 1] = (rvr & (2 * tx + 1 < a.W)) ? pg[r][1] : 0.f;
-        }
-    };
-    // The transforms are cut in two so that no transformed value lives across a quarter of the pipeline (with vout / mout kept from
-    // the additions to the stores the kernel needed 146 registers more than the 256 a wave has at two per SIMD):
-    //   stage A: dM = A g A^T, A = [[1,0],[1,1],[1,-1],[0,-1]], stored at once; t = B^T d in place of d
+    // The transforms are cut in pieces so that no transformed value lives across a quarter of the pipeline (with all of them kept
+    // from the additions to the stores the kernel needed 146 registers more than the 256 a wave has at two per SIMD):
+    //   stage M: dM = A g A^T, A = [[1,0],[1,1],[1,-1],[0,-1]], stored at once
+    //   stage A: t = B^T d (the loaded patch is dead afterwards: its registers take the next loads)
     //   stage B: V = t B, stored row by row
-    auto stage_a = [&](int buf) {
+    float tsel[16];
+    auto stage_m = [&](int buf) {
         float rr[4][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-            rr[0][e] = gsel[e], rr[1][e] = gsel[e] + gsel[2 + e], rr[2][e] = gsel[e] - gsel[2 + e], rr[3][e] = -gsel[2 + e];
+            rr[0][e] = pg[0][e], rr[1][e] = pg[0][e] + pg[1][e], rr[2][e] = pg[0][e] - pg[1][e], rr[3][e] = -pg[1][e];
         float* dm = smem + buf * WG_BUF + tt * WG_PITCH + ch;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -485,20 +471,22 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
             dm[(4 * i + 2) * WG_PLANE] = rr[i][0] - rr[i][1];
             dm[(4 * i + 3) * WG_PLANE] = -rr[i][1];
         }
+    };
+    auto stage_a = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float d0 = dsel[j], d1 = dsel[4 + j], d2 = dsel[8 + j], d3 = dsel[12 + j];
-            dsel[j] = d0 - d2, dsel[4 + j] = d1 + d2, dsel[8 + j] = d2 - d1, dsel[12 + j] = d1 - d3;
+            tsel[j] = px[j] - px[8 + j], tsel[4 + j] = px[4 + j] + px[8 + j];
+            tsel[8 + j] = px[8 + j] - px[4 + j], tsel[12 + j] = px[4 + j] - px[12 + j];
         }
     };
     auto stage_b = [&](int buf) {
         float* dv = smem + buf * WG_BUF + WG_OPBUF + tt * WG_PITCH + ch;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dv[(4 * i + 0) * WG_PLANE] = dsel[4 * i + 0] - dsel[4 * i + 2];
-            dv[(4 * i + 1) * WG_PLANE] = dsel[4 * i + 1] + dsel[4 * i + 2];
-            dv[(4 * i + 2) * WG_PLANE] = dsel[4 * i + 2] - dsel[4 * i + 1];
-            dv[(4 * i + 3) * WG_PLANE] = dsel[4 * i + 1] - dsel[4 * i + 3];
+            dv[(4 * i + 0) * WG_PLANE] = tsel[4 * i + 0] - tsel[4 * i + 2];
+            dv[(4 * i + 1) * WG_PLANE] = tsel[4 * i + 1] + tsel[4 * i + 2];
+            dv[(4 * i + 2) * WG_PLANE] = tsel[4 * i + 2] - tsel[4 * i + 1];
+            dv[(4 * i + 3) * WG_PLANE] = tsel[4 * i + 1] - tsel[4 * i + 3];
         }
     };
 
@@ -540,16 +528,17 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     }
 
     // Software pipeline, one basic block per chunk (see wino_conv_kernel): a chunk is four k-steps of 8 MFMAs; between them sit
-    //   Q0  operand reads of k-step 1, the border selects of chunk q+1's loaded values (their registers are then free)
-    //   Q1  operand reads of k-step 2, the loads of chunk q+2 (a whole chunk of MFMAs ahead of their use), stage A of the transforms
-    //       (dM stored)
+    //   Q0  operand reads of k-step 1, stage M of chunk q+1 (dM stored)
+    //   Q1  operand reads of k-step 2, stage A, then the loads of chunk q+2 (a whole chunk of MFMAs ahead of their use)
     //   Q2  operand reads of k-step 3, stage B (V stored)                              -- barrier --
     //   Q3  operand reads of k-step 0 of chunk q+1
-    // (every range holds at least one chunk: nsplit <= nchunks)
-    Pos p_cur = pos_of(q_lo), p_ld = p_cur;
+    // (every range holds at least one chunk: nsplit <= nchunks; a wave-uniform condition inside the loop body -- a clamp on the tile
+    // row, a `valid ? x : 0` -- becomes a scalar BRANCH that cuts the chunk's basic block: positions advance with selects and the
+    // tail re-loads the last chunk instead of branching)
+    Pos p_ld = pos_of(q_lo);
     load_chunk(p_ld);
-    select_chunk(p_cur);
-    stage_a(0);
+    stage_m(0);
+    stage_a();
     stage_b(0);
     advance(p_ld, q_lo + 1 < q_hi);
     load_chunk(p_ld);
@@ -559,21 +548,20 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     auto body = [&](int q, int buf) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q0
-        advance(p_cur, q + 1 < q_hi);   // position of chunk q + 1, whose values are in px / pg
         read_ops(o1, buf, 1);
-        select_chunk(p_cur);
+        stage_m(buf ^ 1);
         mfma_step(o0);
         WG_PIN(4, 0x100, 1)
-        WG_PIN(4, 0x002, 8)
+        WG_PIN(4, 0x002, 3)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q1
         read_ops(o0, buf, 2);
+        stage_a();
         advance(p_ld, q + 2 < q_hi);
         load_chunk(p_ld);
-        stage_a(buf ^ 1);
         mfma_step(o1);
         WG_PIN(4, 0x100, 1)
-        WG_PIN(4, 0x002, 10)
+        WG_PIN(4, 0x002, 6)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q2
         read_ops(o1, buf, 3);
@@ -656,7 +644,7 @@ bool conv3x3_supported(int C0, int C1, int K) {
 }
 bool conv3x3_shape_ok(const WinoShape& s) {
     const long long img_in = (long long)(s.C0 > s.C1 ? s.C0 : s.C1) * s.H * s.W * 4, img_out = (long long)s.K * s.H * s.W * 4;
-    return conv3x3_supported(s.C0, s.C1, s.K) && s.B > 0 && s.H > 0 && s.W > 0 && img_in < 0x7fffffffLL && img_out < 0x7fffffffLL &&
+    return conv3x3_supported(s.C0, s.C1, s.K) && s.B > 0 && s.H > 0 && s.W > 0 && img_in < WN_OOB && img_out < WN_OOB &&
            (long long)16 * s.K * (s.C0 + s.C1) * 4 < 0x7fffffffLL;
 }
 int conv3x3_tile_blocks(int B, int H, int W) { return B * ((wn_th(H) + 1) / 2) * ((wn_th(W) + 15) / 16); }

@@ -331,11 +331,12 @@ class GraphedDDPStep:
         host       one read-back (OHEM branch), as in GraphedTrainStep
         graph B1   loss, backward of the decoder down to the two boundary tensors (sb output, mobile output), gradients packed
                    into the decoder's flat buckets (one multi-tensor copy)
-        RCCL       all-reduce(AVG) of the decoder buckets, asynchronous on RCCL's stream        <- overlaps graphs B2, B3
         graph B2   backward of the backbone from its boundary gradient, packed into the backbone buckets
-        RCCL       all-reduce of the backbone buckets                                           <- overlaps graph B3
         graph B3   backward of the spatial branch, packed into its (single, < 0.5 MB) bucket
-        RCCL       all-reduce of that bucket -- the only exposed communication; join
+                   (B1, B2, B3 are enqueued back to back, an event recorded behind B1 and behind B2)
+        RCCL       all-reduce(AVG) of the decoder buckets behind B1's event, on a side stream      <- overlaps graphs B2, B3
+        RCCL       all-reduce of the backbone buckets behind B2's event                            <- overlaps graph B3
+        RCCL       all-reduce of the spatial branch's bucket behind B3 -- the only exposed communication; join
         eager      optimizer step (_OptimizerSegment: host-side schedules / clipping; opt-in graph for constant lr)
 
     Collectives are ordinary eager calls between replays (nothing of RCCL is captured), always the same buckets in the
@@ -393,6 +394,14 @@ class GraphedDDPStep:
                     dist.broadcast(t, src=0, group=process_group)
         self.graphs = None
         self.fallbacks = self._calls = 0
+        # side stream + events that order the collectives behind the graph segments (replay path, RCCL only);
+        # CABINET_DDP_INLINE_REDUCE=1 keeps round 4's issue order (A/B timing)
+        import os as _os
+
+        self._side, self._ev = None, None
+        if self.use_graphs and dev.type == "cuda" and _os.environ.get("CABINET_DDP_INLINE_REDUCE") != "1":
+            self._side = torch.cuda.Stream(device=dev)
+            self._ev = [torch.cuda.Event(), torch.cuda.Event()]
 
     # ---- the pieces of one step (run eagerly, or recorded once and replayed) ----
     def _clear(self):
@@ -544,12 +553,32 @@ class GraphedDDPStep:
         for views in self.seg_views:  # a caller's zero_grad(set_to_none=True) must not detach the bucket views
             for p, view in views:
                 p.grad = view
-        gB1.replay()
-        works = self._reduce(0)       # RCCL's stream waits for graph B1, the host goes on to launch B2
-        gB2.replay()
-        works += self._reduce(1)      # the backbone's buckets travel under the spatial branch's backward
-        gB3.replay()
-        works += self._reduce(2)      # < 0.5 MB: the only exposed communication
+        if self.backend == "nccl" and self._side is not None:
+            # Round 5: the three backward graphs are enqueued BACK TO BACK on the compute stream, with only an
+            # event record between them; the collectives are issued afterwards under a side stream that waits for the event behind
+            # the segment that produced the buckets.  Round 4 issued the decoder's four all_reduce calls between B1 and B2 (and
+            # the backbone's two between B2 and B3): whatever the host spent in those calls sat between two graph launches of the
+            # compute stream (profiles/r04_ddp_overlap_world1.md: every RCCL kernel with no compute kernel beside it, the next
+            # compute kernel 10-98 us later).  Same buckets, same order on every rank.
+            cur = torch.cuda.current_stream()
+            gB1.replay()
+            self._ev[0].record(cur)
+            gB2.replay()
+            self._ev[1].record(cur)
+            gB3.replay()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev[0])
+                works = self._reduce(0)   # the decoder's buckets travel under the backbone's and the spatial branch's backward
+                self._side.wait_event(self._ev[1])
+                works += self._reduce(1)  # the backbone's under the spatial branch's
+            works += self._reduce(2)      # < 0.5 MB behind graph B3: the only exposed communication
+        else:
+            gB1.replay()
+            works = self._reduce(0)       # the collective waits for graph B1, the host goes on to launch B2
+            gB2.replay()
+            works += self._reduce(1)      # the backbone's buckets travel under the spatial branch's backward
+            gB3.replay()
+            works += self._reduce(2)      # < 0.5 MB: the only exposed communication
         self._join(works)
         self.opt_seg.run()
         return self.s_loss

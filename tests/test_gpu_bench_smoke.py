@@ -23,7 +23,8 @@ def test_kernel_rooflines_run_at_a_small_size():
     names = [r["kernel"].split(" ")[0] for r in rows]
     for want in ("cab_attn_fwd", "cab_attn_bwd", "ffm_up_fwd", "ffm_up_bwd", "bn_act_fwd", "bn_act_bwd", "bn_dwconv_fwd",
                  "bn_dwconv_bwd", "stem_conv_fwd", "stem_conv_wrw", "pwconv_fwd", "pwconv_bwd", "ohem_up_fwd",
-                 "ohem_up_bwd", "cab_local_fwd", "cab_local_bwd", "cab_qkv_fwd", "cab_qkv_bwd"):
+                 "ohem_up_bwd", "cab_local_fwd", "cab_local_bwd", "cab_qkv_fwd", "cab_qkv_bwd", "conv3x3_conva_fwd",
+                 "conv3x3_conva_bwd", "conv3x3_b1_fwd", "conv3x3_b1_bwd", "conv3x3_out_fwd", "conv3x3_out_bwd"):
         assert want in names, want
     for r in rows:
         assert r["bound"] in ("hbm", "mfma") and r["ms_per_launch"] > 0
@@ -41,8 +42,9 @@ def test_kernel_rooflines_rectangular_19_classes():
     names = [r["kernel"].split(" ")[0] for r in rows]
     assert "ffm_fwd" not in names and "ohem_up_fwd" not in names  # only behind --all-kernels
     for want in ("cab_attn_fwd", "cab_attn_bwd", "ffm_up_fwd", "ffm_up_bwd", "ohem_up_pair_fwd", "ohem_up_pair_bwd",
-                 "cab_local_fwd", "cab_local_bwd", "cab_qkv_fwd", "cab_qkv_bwd"):
+                 "cab_local_fwd", "cab_local_bwd", "cab_qkv_fwd", "cab_qkv_bwd", "conv3x3_conva_fwd", "conv3x3_out_bwd"):
         assert want in names, want
+    assert not any(n.startswith(("bn_act_", "bn_dwconv_", "stem_conv_", "pwconv_")) for n in names)  # K7-K10: --all-kernels only
     assert all(r["ms_per_launch"] > 0 and math.isfinite(r["frac"]) for r in rows)
 
 
@@ -50,6 +52,29 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+@pytest.mark.timeout(1500)
+def test_bench_main_with_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU launch line rehearsed on ONE GPU: WORLD_SIZE = 8 under torchrun, every rank on device
+    0 over gloo, reduced size.  Eight processes go through rendezvous, per-rank MIOpen database copies, NUMA affinity (all ranks
+    take device 0's node), GraphedDDPStep capture and replay with the same bucket order on every rank, and the max-over-ranks
+    timing -- no hang, exit 0 on all ranks, one JSON line, global batch 8."""
+    env = dict(os.environ, CABINET_DIST_BACKEND="gloo", CABINET_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("MIOPEN_USER_DB_PATH", None)
+    env.pop("MIOPEN_CUSTOM_CACHE_DIR", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "2",
+           "--batch", "1", "--size", "256", "--mode", "small", "--no-cpu-baseline", "--no-kernel-roofline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1400, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    r = json.loads(lines[-1])
+    assert sum(ln.lstrip().startswith("{") for ln in lines) == 1
+    assert r["n_gpus"] == 8 and r["steps"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp8" and r["config"]["dist_backend"] == "gloo"
+    assert "GraphedDDPStep" in r["config"]["host_path"] and len(r["config"]["grad_buckets_mb"]) >= 3
+    assert r["value"] > 0 and math.isfinite(r["final_loss"])
 
 
 @pytest.mark.timeout(1200)
