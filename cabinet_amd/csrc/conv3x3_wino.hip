@@ -128,7 +128,9 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     // The channel block is the SLOW index of the XCD-chunked tile list: an XCD works on one 64-channel slice of U (3.9 MB at C = 960)
     // and its share of the tile blocks.  (Measured and not kept: the channel block as the FAST index, so that an XCD fetches each
     // input row once instead of once per channel block -- conv_out's 680 MB of fabric reads are Infinity-Cache hits, 683 vs 690 us;
-    // s_setprio 1 for waves 4-7: 185 vs 185, 223 vs 220, 688 vs 694 us.)
+    // s_setprio 1 for waves 4-7: 185 vs 185, 223 vs 220, 688 vs 694 us; one extra dword load per lane and chunk that pulls the
+    // wave's 64 lines of U for chunk n + 3 into L2 ahead of the real loads: 184 vs 179, 232 vs 211, 687 vs 643 us -- the filter
+    // stream is not what the MFMAs wait for.)
     const int tau = xcd_chunked_tile(blockIdx.x, a.ntb * a.nkb);
     const int kblk = tau / a.ntb, tb = tau - kblk * a.ntb;
     const int per_img = a.nby * a.nbx, b = tb / per_img, rem = tb - b * per_img, by = rem / a.nbx, bx = rem - by * a.nbx;

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
     };
     const float* ylc = yl + li * VW;   // this lane's channel in the two staged rows (second row: + 32 VW)
     float ev[6];
+    f32x4 val_even = {0.f, 0.f, 0.f, 0.f};   // the even quad of a pair, held until its odd neighbour exists (epi_compute)
     auto epi_read = [&](const Pending& q, int g) {
         const int m = (q.col0 + 8 * g + 4 * h) >> 2, xm = max(m - 1, 0), xp = min(m + 1, a.Wl - 1);
         ev[0] = ylc[xm], ev[1] = ylc[m], ev[2] = ylc[xp];
@@ -150,10 +151,34 @@ __global__ __launch_bounds__(512) void ffm_fwd_z_kernel(FzArgs a) {
             s1 += d;
             s2 = fmaf(d, d, s2);
         }
+        // Round 5: a lane's quad is 16 bytes of ITS channel row, so a store instruction used to write 32-byte
+        // pieces (h = 0, 1) of 32 different rows -- WRITE_SIZE 212 MB for a 134 MB tensor, partial sectors.  Quads 2m and 2m + 1
+        // of a row are neighbours in memory: the lanes of a channel pair (li, li ^ 1) swap one quad each (quad_perm [1,0,3,2],
+        // folded into the select), after which the even row's two quads sit in the pair's two lanes and leave in ONE instruction
+        // as a 64-byte piece (then the odd row's): whole sectors, half as many rows per instruction.  The statistics above use the
+        // lane's own values, before the swap.
+        if ((g & 1) == 0) {
+            val_even = val;   // quad 2m of this lane's row: waits for quad 2m + 1
+            return;
+        }
+        const bool odd_lane = (li & 1) != 0;
+        f32x4 lo, hi;   // lo: row li & ~1, hi: row li | 1; the even lane carries quad 2m, the odd lane quad 2m + 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // (the element goes through a scalar first: __builtin_bit_cast applied to a vector ELEMENT expression takes element 0 for
+            // every e with this compiler -- hipcc 7.2 -- which made all four swapped values the first one)
+            const float mine = val[e], mine_even = val_even[e];
+            const float from_odd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine), 0xB1, 0xF, 0xF, true));
+            const float from_even = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_even), 0xB1, 0xF, 0xF, true));
+            lo[e] = odd_lane ? from_odd : val_even[e];    // odd lane: the even partner's quad 2m + 1 (it reads `val` of lane li - 1)
+            hi[e] = odd_lane ? val[e] : from_even;        // even lane: the odd partner's quad 2m
+        }
         // block-uniform descriptor (a wave-dependent base makes every store a readfirstlane waterfall loop); the channel row is
         // part of the lane offset
         const buf_rsrc zr = make_rsrc(q.z, 0x7fffffffu);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), zr, q.voff + 32 * g, 0, 0);
+        const int quad = (g - 1) + (odd_lane ? 1 : 0), row_shift = odd_lane ? -a.P * 4 : 0;   // offset of row li & ~1 from row li
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), zr, q.voff + row_shift + 32 * quad, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), zr, q.voff + row_shift + a.P * 4 + 32 * quad, 0, 0);
     };
     auto epi_full = [&](const Pending& q, const f32x16& acc_) {   // not overlapped: row changes, end of the run
 #pragma unroll
