@@ -40,6 +40,17 @@ constexpr int WN_CC = 16;   // input channels per chunk
 constexpr int WN_VBUF = 16 * WN_CC * WN_TB;   // floats of one staged V chunk (32 KB)
 constexpr int WN_OOB = 0x40000000;           // byte offset of a tap outside the image: beyond every buffer resource (< 1 GB), no 32-bit wrap when two add up
 
+// -DWN_TRACE (tools/wino_trace.py): cycle stamps of waves 0 and 4 of one workgroup (the two waves of one SIMD) at the quarter
+// boundaries of the first 32 chunks
+#ifdef WN_TRACE
+__device__ unsigned long long wn_trace_buf[2 * 32 * 8];
+#define WN_T(i)                                                                                                            \
+    if (blockIdx.x == 100 && (tid & 255) == 0 && n < 32)                                                                    \
+    wn_trace_buf[((tid >> 8) * 32 + n) * 8 + (i)] = __builtin_readcyclecounter()
+#else
+#define WN_T(i)
+#endif
+
 struct WinoArgs {
     const float* x0;   // (B, C0, H, W)
     const float* x1;   // (B, C1, H, W) or null
@@ -207,6 +218,19 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     //   Q3  the LDS operand reads of chunk n+1's first half (so no MFMA waits for LDS after the barrier)
     // All reads of V[n] are issued by the end of Q0 of chunk n, i.e. in front of barrier n; V[n+2] is written behind barrier n+1:
     // two buffers suffice.
+    // What the cycle stamps (-DWN_TRACE, tools/wino_trace.py, profiles/r05_wino_phase_stamps.txt) say about the remaining third: a
+    // chunk takes 5600-5900 cycles for 2 x 32 MFMAs = 4096 cycles of the SIMD's pipe, and the difference is the other ~70 instructions
+    // of each wave, SERIALLY: on gfx950 the fp32 MFMA runs at the vector rate and nothing of the partner wave that touches the VGPR
+    // file executes beside it.  Three rebuilds of this loop measured that: (i) waves 0-3 running the chunk's 32 MFMAs back to back out
+    // of registers (2080 cycles: the pipe CAN be kept full) while waves 4-7 do the chunk's loads / transform / LDS traffic, then roles
+    // swapped at a barrier -- the working wave's first wait for returning data (a vmcnt wait, or with the loads removed the first LDS
+    // read) lasted exactly as long as the partner's matrix segment, every chunk, so the period was 2 x (2100 + 700) = 5600, no
+    // better; inserting s_nop gaps between the dense MFMAs changed nothing; (ii) the input region staged once per workgroup through
+    // LDS (3 wide loads per thread instead of 16 dword loads: the dword gathers cost ~23 cycles each in the texture path) -- 650
+    // vs 643 us, the LDS round trip costs what the gathers did; (iii) the barrier replaced by an LDS arrival counter with four MFMAs
+    // of slack: 686 vs 643 us (the older wave of a SIMD wins every arbitration, runs ahead and waits; the skew is systematic).
+    // So time = MFMA time + everything else, and the lever left is less "everything else" per MFMA (a 128-channel block per
+    // workgroup needs 64 more accumulator registers than two waves per SIMD have).
     float bva[2][4], bvb[2][4];   // B operands (V) of half 0 / half 1 of the current chunk: [xi][k-step]
     float vout[16];
     auto read_v = [&](float (&dst)[2][4], int buf, int hc) {
@@ -235,18 +259,21 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         const int n1 = min(n + 1, nch - 1), n2 = min(n + 2, nch - 1);
         // ---- Q0
         __builtin_amdgcn_sched_barrier(0);
+        WN_T(0);
         load_u(unext, n1);
         read_v(bvb, buf, 1);
         mfma_quarter(ucur, bva, 0, 0);
         WN_PIN(4, 0x020, 2)    // 8 filter loads
         WN_PIN(4, 0x100, 2)    // LDS operand reads (ds_read2: 4 instructions; the recipe tolerates fewer)
         __builtin_amdgcn_sched_barrier(0);
+        WN_T(1);
         // ---- Q1
         wino_bt_d_b(pd, vout);
         load_patch(n2);
         mfma_quarter(ucur, bva, 0, 2);
         WN_PIN(8, 0x002, 4)    // 32 additions
         __builtin_amdgcn_sched_barrier(0);
+        WN_T(2);
         // ---- Q2
         {
             float* dst = smem + (buf ^ 1) * WN_VBUF + (2 * wave + h) * WN_TB + li;
@@ -256,12 +283,15 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         mfma_quarter(ucur, bvb, 1, 0);
         WN_PIN(8, 0x200, 1)    // 8 LDS stores (ds_write2)
         __builtin_amdgcn_sched_barrier(0);
+        WN_T(3);
         __syncthreads();
+        WN_T(4);
         // ---- Q3
         read_v(bva, buf ^ 1, 0);
         mfma_quarter(ucur, bvb, 1, 2);
         WN_PIN(4, 0x100, 1)
         __builtin_amdgcn_sched_barrier(0);
+        WN_T(5);
     };
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------
@@ -534,6 +564,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     //   Q1  operand reads of k-step 2, stage A, then the loads of chunk q+2 (a whole chunk of MFMAs ahead of their use)
     //   Q2  operand reads of k-step 3, stage B (V stored)                              -- barrier --
     //   Q3  operand reads of k-step 0 of chunk q+1
+    // (Measured and not kept: a second register set for the loaded patches, i.e. requests two chunks ahead of their use instead of
+    // one: 820 vs 804, 233 vs 228, 281 vs 286 us -- latency is not what this loop waits for; see wino_conv_kernel on what it is.)
     // (every range holds at least one chunk: nsplit <= nchunks; a wave-uniform condition inside the loop body -- a clamp on the tile
     // row, a `valid ? x : 0` -- becomes a scalar BRANCH that cuts the chunk's basic block: positions advance with selects and the
     // tail re-loads the last chunk instead of branching)
@@ -743,3 +775,9 @@ hipError_t conv3x3_bwd_run(const WinoShape& s, const float* dy, const float* x0,
 }
 
 }  // namespace cabinet
+
+#ifdef WN_TRACE
+extern "C" int cabinet_debug_wn_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cabinet::wn_trace_buf), (size_t)n * sizeof(unsigned long long));
+}
+#endif
