@@ -139,7 +139,7 @@ def time_kernel(fn, iters, warm=3, reps=5):
     return start.elapsed_time(stop) / iters
 
 
-TRAFFIC_PROFILES = ("r04_pmc_traffic.json", "r04_config5_pmc_traffic.json")  # under profiles/: one per workload shape
+TRAFFIC_PROFILES = ("r05_pmc_traffic.json", "r05_config5_pmc_traffic.json")  # under profiles/: one per workload shape
 
 
 def load_traffic(batch, height, width, classes):
@@ -591,8 +591,11 @@ def main():
                                   algorithmic_bytes=round(k1["algorithmic_mbytes"] * 1e6),
                                   traffic_source=k1["traffic_source"],
                                   peak_is="dense fp32 MFMA (v_mfma_f32_32x32x2_f32), not bf16",
+                                  # `frac` of that group = algorithmic_gflop (bound "mfma") or algorithmic_mbytes (bound "hbm") of
+                                  # THIS entry over its time and peak: the quantity it divides travels with it
                                   longest_section8_group={k: dom8[k] for k in ("kernel", "ms_per_launch", "bound", "achieved",
-                                                                              "peak", "unit", "frac", "traffic")},
+                                                                              "peak", "unit", "frac", "traffic",
+                                                                              "algorithmic_gflop", "algorithmic_mbytes")},
                                   longest_kernel_group=dom["kernel"], longest_kernel_frac=dom["frac"],
                                   longest_kernel_scope=dom["scope"])
     if ddp:

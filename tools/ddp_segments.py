@@ -4,8 +4,8 @@ streams, tools/stream_overlap_probe.py shows they do not without it.)
 
     CABINET_FORCE_DDP=1 python tools/ddp_segments.py
 rows: wall time per step of (a) GraphedTrainStep, (b) GraphedDDPStep with its collectives, (c) the same without them (segmentation and
-packing alone), (d) with a 2 ms payload kernel sequence issued beside the decoder's collectives on their side stream: if the schedule
-overlaps, (d) - (b) is far below 2 ms; and HIP-event times of the three backward graphs of (b)."""
+packing alone), (d) with a 0.5 ms spin kernel issued beside the decoder's collectives on their side stream: if the schedule overlaps,
+(d) - (b) is ~0; and HIP-event times of the three backward graphs of (b)."""
 import os
 import sys
 import time
@@ -62,31 +62,31 @@ gd.always_reduce = False
 c = wall(gd)
 print(f"(c) the same without the collectives (segments + packing)   {c:7.3f} ms/step   (+{c - a:.3f})", flush=True)
 gd.always_reduce = True
-# (d) a payload beside the decoder's collectives: ~2 ms of small kernels on the side stream, behind B1's event
-pay = torch.zeros(1 << 22, device=dev)
+# (d) a payload beside the decoder's collectives: ONE kernel that spins ~0.5 ms on a single thread (torch.cuda._sleep: no memory
+# traffic, one wave), issued on the stream the collectives are issued on, behind B1's event.  Overlapped: it costs the step nothing;
+# serialised behind the backward: its full length.
+cycles = int(0.5e-3 * 2.0e9)
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+s.record()
+torch.cuda._sleep(cycles)
+e.record()
+torch.cuda.synchronize()
+payload_ms = s.elapsed_time(e)
 orig_reduce = gd._reduce
 
 
 def reduce_with_payload(seg):
     works = orig_reduce(seg)
     if seg == 0:
-        for _ in range(100):
-            pay.add_(1.0)   # 16 MB read + write each: ~20 us
+        torch.cuda._sleep(cycles)
     return works
 
 
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-torch.cuda.synchronize()
-s.record()
-for _ in range(100):
-    pay.add_(1.0)
-e.record()
-torch.cuda.synchronize()
-payload_ms = s.elapsed_time(e)
 gd._reduce = reduce_with_payload
 d = wall(gd)
-print(f"(d) (b) + a {payload_ms:.2f} ms payload beside the decoder's collectives   {d:7.3f} ms/step   (+{d - b:.3f} over (b): "
-      f"{'OVERLAPPED with the backward' if d - b < 0.35 * payload_ms else 'serialised'})", flush=True)
+print(f"(d) (b) + a {payload_ms:.2f} ms spin kernel beside the decoder's collectives   {d:7.3f} ms/step   (+{d - b:.3f} over (b): "
+      f"{'OVERLAPPED with the backward' if d - b < 0.35 * payload_ms else 'serialised' if d - b > 0.8 * payload_ms else 'partly overlapped'})", flush=True)
 gd._reduce = orig_reduce
 # HIP-event times of the backward graphs
 gA, gB1, gB2, gB3 = gd.graphs

@@ -93,7 +93,7 @@ if __name__ == "__main__":
         print("worst relative error", worst, flush=True)
         assert worst < 1e-4, worst
     if a.config5:
-        shapes = [("conva", 2, 960, 0, 256, 128, 64), ("b1", 2, 960, 256, 256, 128, 64), ("conv_out", 2, 256, 0, 256, 256, 128)]
+        shapes = [("conva", 2, 960, 0, 256, 64, 32), ("b1", 2, 960, 256, 256, 64, 32), ("conv_out", 2, 256, 0, 256, 256, 128)]
     else:
         shapes = [("conva", 8, 960, 0, 256, 32, 32), ("b1", 8, 960, 256, 256, 32, 32), ("conv_out", 8, 256, 0, 256, 128, 128)]
     for s in shapes:
