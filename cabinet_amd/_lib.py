@@ -12,7 +12,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcabinet_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
@@ -25,6 +25,8 @@ SIGNATURES = {
     "cabinet_cab_attn_precision_supported": (_INT, [_INT] * 3),
     "cabinet_cab_attn_fwd_workspace_bytes": (_SZ, [_INT] * 5),
     "cabinet_cab_attn_fwd": (_INT, [_PTR, _PTR, _PTR, _FLT, _INT, _INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _SZ, _PTR]),
+    "cabinet_cab_attn_proj_supported": (_INT, [_INT] * 5),
+    "cabinet_cab_attn_proj_fwd": (_INT, [_PTR] * 4 + [_FLT] + [_INT] * 5 + [_PTR] * 3 + [_PTR]),
     "cabinet_cab_attn_bwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_cab_attn_bwd": (_INT, [_PTR] * 6 + [_FLT] + [_INT] * 4 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_ffm_fwd_workspace_bytes": (_SZ, [_INT] * 7),

@@ -59,14 +59,21 @@ struct SgJob {
     const float* a_bias;  // optional (B, M): subtracted from every A row (m) of image b while staging (M-major A only)
     float alpha;      // scale applied to the result (0 means 1)
     size_t a_img_stride;  // floats between the A operands of consecutive images (0: one A shared by all images, a weight)
+    // optional epilogue (FAST launches only: sg_gemm's return value says whether it ran): per output row m, image b and 64-column
+    // tile nt the pair (mean, M2 = sum (d - mean)^2) of the tile's 64 values, stat[((m * B + b) * tiles_n + nt) * 2 + {0, 1}] --
+    // BatchNorm batch statistics of the product without a pass over it (merged by the consumer: equal counts, fixed order)
+    float* stat;
     int tiles_m, tiles_n, tile_base, nck[3], vec;  // filled by sg_gemm
 };
 struct SgJobs {
     SgJob j[12];
     int n;
+    int B;   // images (filled by sg_gemm)
 };
 const char* sg_gemm_unsupported(const SgJob& j);  // nullptr when the small path can take the job
-void sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb = 1);  // mb: 64-row blocks per workgroup tile (1 | 2)
+// mb: 64-row blocks per workgroup tile (1 | 2).  Returns true when the launch took the FAST kernel (every job: full tiles, whole
+// chunks, aligned rows) -- only then are the jobs' `stat` partials written.
+bool sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb = 1);
 
 struct SdJob {
     const float* a;   // (B, a_rows, P), rows [0, M)

@@ -339,10 +339,18 @@ __device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_byt
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
 }
 
-template <int KC, int VC>
+// PROJ (round 5): the CAB's output projection (reference cab.py:155, project_out: a bias-free 1x1 convolution
+// Co x VC) is applied to the merged 32-query context tile while it is in LDS -- glob[co][i] = sum_c W[co][c] ctx[c][i], wave w owns
+// output channels 32w .. 32w+31 (+256 per further block), A = W rows as 16-byte quads straight from L2 (requested before the merge
+// barriers), B = the tile from LDS (row pitch PROJ_STR: the two k-halves of a step land in different bank halves).  The separate
+// small-GEMM launch (18 us at config 3, an 8 MB round trip of ctx) becomes 64 MFMAs per wave behind the merge; ctx itself is only
+// written when the caller wants it for the backward (ctx != nullptr).
+constexpr int PROJ_STR = 40;
+template <int KC, int VC, bool PROJ = false>
 __global__ __launch_bounds__(512) void cab_attn_fwd_w8_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit, int B) {
+    float* __restrict__ ctx, float* __restrict__ lse, int n, float qscale, int kvsplit, int B,
+    const float* __restrict__ w_out, float* __restrict__ glob, int Co) {
     constexpr int KB = KC / 32, VB = VC / 32, NW = 8, NBATCH = KB + VB;
     static_assert(NBATCH % 2 == 0, "the buffer parity of batch 0 must repeat from tile to tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -452,6 +460,14 @@ __global__ __launch_bounds__(512) void cab_attn_fwd_w8_kernel(
     for (int cb = 0; cb < VB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) vs[(cb * 32 + acc_row(r) + 4 * h) * 32 + li] = o[cb][r];
+    // PROJ: the weight rows of this wave's first output block travel while the merge runs (MFMA step (j, e) contracts
+    // channel 8j + 4h + e: a lane's operands are 16-byte quads of ITS row)
+    f32x4 wq[PROJ ? VC / 8 : 1];
+    if constexpr (PROJ) {
+        const float* wrow = w_out + (size_t)(wave * 32 + li) * VC + 4 * h;
+#pragma unroll
+        for (int j = 0; j < VC / 8; ++j) wq[j] = *reinterpret_cast<const f32x4*>(wrow + 8 * j);
+    }
     __syncthreads();
     float ms = -INFINITY, lt = 0.f;
     if (threadIdx.x < NW * 32) {
@@ -468,6 +484,7 @@ __global__ __launch_bounds__(512) void cab_attn_fwd_w8_kernel(
     }
     __syncthreads();
     const size_t out_base = ((size_t)split * B + b) * VC * n;
+    float* mg = s_f + NW * 32;  // PROJ: [VC][PROJ_STR] merged context tile
     for (int idx = threadIdx.x; idx < VC * 8; idx += 512) {  // four consecutive queries per thread (n % 4 == 0)
         const int c = idx >> 3, i = (idx & 7) * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -478,10 +495,38 @@ __global__ __launch_bounds__(512) void cab_attn_fwd_w8_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += ov[e] * fv[e];
         }
-        if (i0 + i < n) *reinterpret_cast<f32x4*>(ctx + out_base + (size_t)c * n + i0 + i) = acc;
+        if constexpr (PROJ) {
+            *reinterpret_cast<f32x4*>(mg + c * PROJ_STR + i) = acc;
+            if (ctx != nullptr && i0 + i < n) *reinterpret_cast<f32x4*>(ctx + out_base + (size_t)c * n + i0 + i) = acc;
+        } else {
+            if (i0 + i < n) *reinterpret_cast<f32x4*>(ctx + out_base + (size_t)c * n + i0 + i) = acc;
+        }
     }
     if (threadIdx.x < 32 && i0 + threadIdx.x < n)
         lse[((size_t)split * B + b) * n + i0 + threadIdx.x] = (lt > 0.f) ? (ms + fast_log2(lt)) * LN2_F : -INFINITY;
+    if constexpr (PROJ) {
+        __syncthreads();  // the merged tile is complete
+        const float* bt = mg + 4 * h * PROJ_STR + li;
+        for (int cob = wave; cob * 32 < Co; cob += NW) {
+            if (cob != wave) {
+                const float* wrow = w_out + (size_t)(cob * 32 + li) * VC + 4 * h;
+#pragma unroll
+                for (int j = 0; j < VC / 8; ++j) wq[j] = *reinterpret_cast<const f32x4*>(wrow + 8 * j);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < VC / 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma32(wq[j][e], bt[(8 * j + e) * PROJ_STR], acc);
+            if (i0 + li < n) {
+                float* dst = glob + ((size_t)b * Co + cob * 32 + 4 * h) * n + i0 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(size_t)acc_row(r) * n] = acc[r];
+            }
+        }
+    }
 }
 
 // merge kvsplit partial results: lse = logsumexp_s(lse_s), ctx = sum_s exp(lse_s - lse) ctx_s
@@ -531,7 +576,8 @@ static hipError_t launch_fwd(const float* q, const float* k, const float* v, flo
         const size_t lds8 = (size_t)(8 * VC * 32 + 3 * 8 * 32) * sizeof(float);
         static lds_attr_mask mask8{0};
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern8), lds8, mask8); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern8, grid, dim3(512), lds8, stream, q, k, v, out_ctx, out_lse, n, scale * LOG2E_F, kvsplit, B);
+        hipLaunchKernelGGL(kern8, grid, dim3(512), lds8, stream, q, k, v, out_ctx, out_lse, n, scale * LOG2E_F, kvsplit, B,
+                           static_cast<const float*>(nullptr), static_cast<float*>(nullptr), 0);
         if (kvsplit > 1) launch_attn_merge(part_ctx, part_lse, ctx, lse, B, VC, n, kvsplit, stream);
         return hipGetLastError();
       }
@@ -561,6 +607,33 @@ int attn_fwd_kvsplit(int B, int n) {
     // price of 71 MB of partial results -- a case nobody measured.
     if (best > 1 && best_cost > 0.85 * cost1) best = 1;
     return best;
+}
+
+// ---- K1 with the output projection in its epilogue (PROJ above): one workgroup must own a query tile for ALL keys (no key
+// split: the projection needs the merged tile), the 8-wave kernel's shapes only
+bool attn_fwd_proj_supported(int B, int Kc, int Vc, int Co, int n) {
+    if (!((Kc == 128 && Vc == 128) || (Kc == 64 && Vc == 64))) return false;
+    if (B <= 0 || n <= 0 || (n & 3) || Co < 32 || (Co & 31)) return false;
+    return attn_fwd_kvsplit(B, n) == 1;
+}
+
+template <int KC, int VC>
+static hipError_t launch_fwd_proj(const float* q, const float* k, const float* v, const float* w_out, float scale, int B, int Co,
+                                  int n, float* ctx, float* glob, float* lse, hipStream_t stream) {
+    auto kern = cab_attn_fwd_w8_kernel<KC, VC, true>;
+    const size_t lds = (size_t)(8 * VC * 32 + 3 * 8 * 32 + VC * PROJ_STR) * sizeof(float);
+    static lds_attr_mask mask{0};
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, mask); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(((n + 31) / 32) * B), dim3(512), lds, stream, q, k, v, ctx, lse, n, scale * LOG2E_F, 1, B, w_out,
+                       glob, Co);
+    return hipGetLastError();
+}
+
+hipError_t attn_fwd_proj_dispatch(const float* q, const float* k, const float* v, const float* w_out, float scale, int B, int Kc,
+                                  int Vc, int Co, int n, float* ctx, float* glob, float* lse, hipStream_t stream) {
+    if (Kc == 128 && Vc == 128) return launch_fwd_proj<128, 128>(q, k, v, w_out, scale, B, Co, n, ctx, glob, lse, stream);
+    if (Kc == 64 && Vc == 64) return launch_fwd_proj<64, 64>(q, k, v, w_out, scale, B, Co, n, ctx, glob, lse, stream);
+    return hipErrorInvalidValue;
 }
 
 bool attn_shape_supported(int Kc, int Vc) {

@@ -46,6 +46,7 @@ static PyrGeom make_geom(const QkvShape& q) {
 }
 
 constexpr int QC_T = 512;  // threads of the channel-resident kernels
+constexpr int SG_TILE_P = 64;  // positions per tile of sg_gemm (small_gemm.hip): one statistics partial each
 __device__ __forceinline__ int bin_start(int r, int n, int s) { return (r * n) / s; }            // floor(r*n/s)
 __device__ __forceinline__ int bin_end(int r, int n, int s) { return ((r + 1) * n + s - 1) / s; }  // ceil((r+1)*n/s)
 
@@ -167,6 +168,142 @@ __global__ __launch_bounds__(256) void qkv_plane_fwd_kernel(const float* __restr
         binv[t] = val;
     }
     __syncthreads();
+    for (int it = tid; it < g.ns * g.NBp; it += 256) {
+        const int i = it / g.NBp, t = it - i * g.NBp;
+        const bool mine = t >= g.off[i] && t < g.off[i] + g.s[i] * g.s[i];
+        pooled[(((size_t)b * g.ns + i) * nch + ch) * g.NBp + t] = mine ? binv[t] : 0.f;
+    }
+}
+
+// ---- round 5: the same pass with the BatchNorm finalize in its prologue -----------------------------------------------------------
+// With `part` (training): the (mean, M2) partials the projection GEMM's epilogue left per (channel, image, 64-column tile) are merged
+// here -- equal counts, fixed order, double -- by wave 0 of every workgroup of the channel (128 pairs at config 3: two per lane) while
+// the other waves' plane loads are in flight; the b == 0 workgroup writes save_mean / save_invstd and the running buffers: the
+// statistics launch is gone (4 -> 3 launches).  Without `part` the workgroup reads save_mean / save_invstd (eval mode, or shapes the
+// GEMM epilogue does not take: qk_bn_stats_kernel ran in front).
+// Measured and not kept: ONE WAVE per plane (four 16-byte loads per lane, the phases ordered by the wave's own in-order LDS queue, no
+// s_barrier, four planes per workgroup): K6 forward 77 vs 72 us at config 3, 83 vs 60 us at config 5 -- a plane's four dependent
+// phases are a latency chain, and 256 threads per plane walk it with a quarter of the work per thread.
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+struct PlaneWArgs {
+    const float *zqk, *vv;
+    const float* part;            // [2Kc][npairs][2] (mean, M2) per 64-value tile, or null
+    int npairs;                   // pairs per channel (B * tiles of 64 positions)
+    float momentum, eps;
+    float *q_rm, *q_rv, *k_rm, *k_rv, *save_mean, *save_invstd;
+    const float *bnq_w, *bnq_b, *bnk_w, *bnk_b;
+    int B, Kc, Vc;
+    float *q, *kk, *pooled_k, *pooled_v;
+};
+__global__ __launch_bounds__(256) void qkv_plane_fwd_w_kernel(PlaneWArgs a, PyrGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float s_stat[2];
+    const int P = g.H * g.W, Mtot = 2 * a.Kc + a.Vc, tid = threadIdx.x;
+    const int b = blockIdx.x / Mtot, m = blockIdx.x - b * Mtot;
+    const int WS = g.W + 1;
+    float* plane = smem;                       // [H][WS]
+    float* rowpart = plane + g.H * WS;         // [H][NCB]
+    float* binv = rowpart + g.H * g.NCB;       // [NBp]
+    const bool is_q = m < a.Kc, is_v = m >= 2 * a.Kc;
+    const int ch = is_q ? m : (is_v ? m - 2 * a.Kc : m - a.Kc);
+    const float* src = is_v ? a.vv + ((size_t)b * a.Vc + ch) * P : a.zqk + ((size_t)b * 2 * a.Kc + m) * P;
+    // the first values of the plane are requested before the statistics are touched
+    constexpr int PRE = 4;
+    float pre[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) pre[u] = src[min(tid + 256 * u, P - 1)];
+    float mu = 0.f, inv = 1.f, gam = 1.f, bet = 0.f;
+    if (!is_v) {
+        gam = is_q ? a.bnq_w[ch] : a.bnk_w[ch], bet = is_q ? a.bnq_b[ch] : a.bnk_b[ch];
+        if (a.part != nullptr) {
+            if (tid < 64) {
+                const float* pp = a.part + (size_t)m * a.npairs * 2;
+                double sm = 0.0;
+                for (int i = tid; i < a.npairs; i += 64) sm += (double)pp[2 * i];
+                const double mean = wave_sum_d(sm) / (double)a.npairs;
+                double m2 = 0.0;
+                for (int i = tid; i < a.npairs; i += 64) {
+                    const double d = (double)pp[2 * i] - mean;
+                    m2 += (double)pp[2 * i + 1] + 64.0 * d * d;
+                }
+                const double count = 64.0 * (double)a.npairs;
+                const double var = wave_sum_d(m2) / count;
+                if (tid == 0) {
+                    const float muf = (float)mean, invf = (float)(1.0 / sqrt(var + (double)a.eps));
+                    s_stat[0] = muf, s_stat[1] = invf;
+                    if (b == 0) {
+                        a.save_mean[m] = muf, a.save_invstd[m] = invf;
+                        float* rm = is_q ? a.q_rm + ch : a.k_rm + ch;
+                        float* rv = is_q ? a.q_rv + ch : a.k_rv + ch;
+                        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                        *rm = (float)((1.0 - (double)a.momentum) * (double)*rm + (double)a.momentum * mean);
+                        *rv = (float)((1.0 - (double)a.momentum) * (double)*rv + (double)a.momentum * unbiased);
+                    }
+                }
+            }
+            __syncthreads();
+            mu = s_stat[0], inv = s_stat[1];
+        } else {
+            mu = a.save_mean[m], inv = a.save_invstd[m];
+        }
+    }
+    float* dst = is_q ? a.q + ((size_t)b * a.Kc + ch) * P : a.kk + ((size_t)b * a.Kc + ch) * P;
+    if (is_q) {
+        auto put = [&](int p, float v) { dst[p] = fmaxf(fmaf((v - mu) * inv, gam, bet), 0.f); };
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (tid + 256 * u < P) put(tid + 256 * u, pre[u]);
+        for (int p = tid + 256 * PRE; p < P; p += 256) put(p, src[p]);
+        return;
+    }
+    {
+        const float inv_w = 1.f / (float)g.W;
+        auto put = [&](int p, float v) {
+            if (!is_v) {
+                v = fmaxf(fmaf((v - mu) * inv, gam, bet), 0.f);  // same expression as the backward mask
+                dst[p] = v;
+            }
+            const int y = idiv_small(p, inv_w);
+            plane[y * WS + (p - y * g.W)] = v;
+        };
+#pragma unroll
+        for (int u = 0; u < PRE; ++u)
+            if (tid + 256 * u < P) put(tid + 256 * u, pre[u]);
+        for (int p = tid + 256 * PRE; p < P; p += 256) put(p, src[p]);
+    }
+    __syncthreads();
+    // separable adaptive average pooling: column bins per row, then row bins (the arithmetic of qkv_plane_fwd_kernel, same order)
+    for (int it = tid; it < g.H * g.NCB; it += 256) {
+        const int y = it / g.NCB, cb = it - y * g.NCB;
+        int i = 0;
+        while (i + 1 < g.ns && cb >= g.coff[i + 1]) ++i;
+        const int c = cb - g.coff[i], xs = bin_start(c, g.W, g.s[i]), xe = bin_end(c, g.W, g.s[i]);
+        float acc = 0.f;
+        for (int x = xs; x < xe; ++x) acc += plane[y * WS + x];
+        rowpart[it] = acc;
+    }
+    __syncthreads();
+    for (int t = tid; t < g.NBp; t += 256) {
+        float val = 0.f;
+        if (t < g.NB) {
+            int i = 0;
+            while (i + 1 < g.ns && t >= g.off[i + 1]) ++i;
+            const int s = g.s[i], r = (t - g.off[i]) / s, c = (t - g.off[i]) - r * s;
+            const int ys = bin_start(r, g.H, s), ye = bin_end(r, g.H, s);
+            const int xs = bin_start(c, g.W, s), xe = bin_end(c, g.W, s);
+            float acc = 0.f;
+            for (int y = ys; y < ye; ++y) acc += rowpart[y * g.NCB + g.coff[i] + c];
+            val = acc / (float)((ye - ys) * (xe - xs));
+        }
+        binv[t] = val;
+    }
+    __syncthreads();
+    float* pooled = is_v ? a.pooled_v : a.pooled_k;
+    const int nch = is_v ? a.Vc : a.Kc;
     for (int it = tid; it < g.ns * g.NBp; it += 256) {
         const int i = it / g.NBp, t = it - i * g.NBp;
         const bool mine = t >= g.off[i] && t < g.off[i] + g.s[i] * g.s[i];
@@ -644,7 +781,7 @@ static FwdWs fwd_layout(const QkvShape& s) {
         off += fbytes(floats);
         return o;
     };
-    w.stat = take((size_t)2 * 2 * 2 * s.Kc * s.B);  // doubles
+    w.stat = take((size_t)2 * 2 * s.Kc * s.B * ceil_div(s.H * s.W, SG_TILE_P));  // (mean, M2) per (q | k channel, image, 64-position tile)
     w.tk = take((size_t)s.B * s.Kc * g.NBp);
     w.tv = take((size_t)s.B * s.Vc * g.NBp);
     w.total = off;
@@ -668,20 +805,41 @@ hipError_t qkv_fwd_run(const QkvShape& s, const QkvParams& w, const float* x, in
     char* base = static_cast<char*>(ws);
     auto at = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
     const bool fused = qkv_fused_fwd_supported(s);
+    // round 5: BatchNorm statistics from the projection GEMM's epilogue, finalize in the plane pass's prologue (3 launches instead of
+    // 4 where the output stage is fused too); CABINET_QKV_STATS_FUSED=0 keeps the round-4 launches (A/B timing)
+    static const bool plane_wave_on = [] { const char* e = getenv("CABINET_QKV_STATS_FUSED"); return !(e && e[0] == '0'); }();
+    const bool wplane = plane_wave_on && P < (1 << 21);
+    const int tiles_p = ceil_div(P, SG_TILE_P);
+    bool stats_in_gemm = false;
     {
         SgJobs jobs{};
         jobs.n = 3;
         jobs.j[0] = sg_job(w.wq, s.C, 1, x, s.C, s.C, s.Kc, P, sv.zqk, 2 * s.Kc);
         jobs.j[1] = sg_job(w.wk, s.C, 1, x, s.C, s.C, s.Kc, P, sv.zqk + (size_t)s.Kc * P, 2 * s.Kc);
         jobs.j[2] = sg_job(w.wv, s.C, 1, x, s.C, s.C, s.Vc, P, sv.vv, s.Vc);
-        sg_gemm(jobs, s.B, stream);
+        if (wplane && training) {
+            jobs.j[0].stat = at(L.stat);
+            jobs.j[1].stat = at(L.stat) + (size_t)s.Kc * s.B * tiles_p * 2;
+        }
+        stats_in_gemm = sg_gemm(jobs, s.B, stream) && wplane && training;
     }
     // (a channel-resident form of these two launches -- statistics + plane pass of one stacked channel over all B images in one
     // workgroup, as the backward uses -- measured 36 us against 5 + 19: 384 workgroups leave the pooling phases latency-bound)
-    hipLaunchKernelGGL(qk_bn_stats_kernel, dim3(2 * s.Kc), dim3(QS_T), 0, stream, sv.zqk, s.B, s.Kc, P, training, momentum, eps,
-                       w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean, sv.invstd);
-    hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
-                       sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);
+    if (!stats_in_gemm)
+        hipLaunchKernelGGL(qk_bn_stats_kernel, dim3(2 * s.Kc), dim3(QS_T), 0, stream, sv.zqk, s.B, s.Kc, P, training, momentum, eps,
+                           w.bnq_rm, w.bnq_rv, w.bnk_rm, w.bnk_rv, sv.mean, sv.invstd);
+    if (wplane) {
+        PlaneWArgs pa{};
+        pa.zqk = sv.zqk, pa.vv = sv.vv, pa.part = stats_in_gemm ? at(L.stat) : nullptr, pa.npairs = s.B * tiles_p;
+        pa.momentum = momentum, pa.eps = eps;
+        pa.q_rm = w.bnq_rm, pa.q_rv = w.bnq_rv, pa.k_rm = w.bnk_rm, pa.k_rv = w.bnk_rv, pa.save_mean = sv.mean, pa.save_invstd = sv.invstd;
+        pa.bnq_w = w.bnq_w, pa.bnq_b = w.bnq_b, pa.bnk_w = w.bnk_w, pa.bnk_b = w.bnk_b;
+        pa.B = s.B, pa.Kc = s.Kc, pa.Vc = s.Vc, pa.q = q, pa.kk = sv.kk, pa.pooled_k = sv.pooled_k, pa.pooled_v = sv.pooled_v;
+        hipLaunchKernelGGL(qkv_plane_fwd_w_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, pa, g);
+    } else {
+        hipLaunchKernelGGL(qkv_plane_fwd_kernel, dim3(s.B * Mtot), dim3(256), lds_fwd_plane(g), stream, sv.zqk, sv.vv, sv.mean,
+                           sv.invstd, w.bnq_w, w.bnq_b, w.bnk_w, w.bnk_b, s.Kc, s.Vc, g, q, sv.kk, sv.pooled_k, sv.pooled_v);
+    }
     if (fused) {  // the output products with the pyramid terms formed per workgroup (one launch instead of two)
         if (hipError_t e = qkv_fused_out(s, w, sv, k, v, stream); e != hipSuccess) return e;
         return hipGetLastError();

@@ -17,6 +17,9 @@ bool attn_shape_supported(int Kc, int Vc);
 hipError_t attn_fwd_dispatch(const float* q, const float* k, const float* v, float scale, int B, int Kc,
                              int Vc, int n, float* ctx, float* lse, float* part_ctx, float* part_lse,
                              int kvsplit, hipStream_t stream);
+bool attn_fwd_proj_supported(int B, int Kc, int Vc, int Co, int n);
+hipError_t attn_fwd_proj_dispatch(const float* q, const float* k, const float* v, const float* w_out, float scale, int B, int Kc,
+                                  int Vc, int Co, int n, float* ctx, float* glob, float* lse, hipStream_t stream);
 // cab_attn_bf16.hip
 bool attn_bf16_supported(int Kc, int Vc);
 size_t attn_bf16_pack_bytes(int B, int Kc, int Vc, int n, int precision);
@@ -214,6 +217,26 @@ int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float s
     return hip_status(cabinet::attn_fwd_dispatch(q, k, v, scale, B, Kc, Vc, n, ctx, lse, part_ctx, part_lse,
                                                  split, static_cast<hipStream_t>(stream)),
                       "cab_attn_fwd launch");
+}
+
+int cabinet_cab_attn_proj_supported(int B, int Kc, int Vc, int Co, int n) {
+    return cabinet::attn_fwd_proj_supported(B, Kc, Vc, Co, n) ? 1 : 0;
+}
+
+int cabinet_cab_attn_proj_fwd(const float* q, const float* k, const float* v, const float* w_out, float scale, int B, int Kc,
+                              int Vc, int Co, int n, float* ctx, float* glob, float* lse, cabinet_stream_t stream) {
+    if (int rc = check_attn_shape(B, Kc, Vc, n)) return rc;
+    if (Co <= 0) return fail(CABINET_ERR_INVALID_ARG, "cab_attn_proj_fwd: non-positive Co=%d", Co);
+    if (!cabinet::attn_fwd_proj_supported(B, Kc, Vc, Co, n))
+        return fail(CABINET_ERR_UNSUPPORTED,
+                    "cab_attn_proj_fwd: (B=%d, Kc=%d, Vc=%d, Co=%d, n=%d) is outside the fused form (see "
+                    "cabinet_cab_attn_proj_supported); use cabinet_cab_attn_fwd + cabinet_conv1x1_fwd",
+                    B, Kc, Vc, Co, n);
+    if (!q || !k || !v || !w_out || !glob || !lse) return fail(CABINET_ERR_INVALID_ARG, "cab_attn_proj_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("cab_attn_proj_fwd", q, k, v, w_out, ctx, glob, lse);
+    return hip_status(cabinet::attn_fwd_proj_dispatch(q, k, v, w_out, scale, B, Kc, Vc, Co, n, ctx, glob, lse,
+                                                      static_cast<hipStream_t>(stream)),
+                      "cab_attn_proj_fwd launch");
 }
 
 size_t cabinet_cab_attn_bwd_workspace_bytes(int B, int Kc, int Vc, int n) {

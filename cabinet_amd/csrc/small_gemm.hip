@@ -197,6 +197,43 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
             const int m = m0 + mb * 64 + wm * 32 + acc_row(r) + 4 * h;
             if (FAST || (m < M && p < P)) dst[(size_t)m * ldp + p] = acc[mb][r] * alpha;
         }
+    // Optional statistics epilogue (K6: the q / k projections feed a training-mode BatchNorm): the tile meets in LDS (the operand
+    // ring is dead behind the loop's last barrier), four threads walk one row -- 16 values each, sums of (d - pivot) and
+    // (d - pivot)^2 with the row's first value as pivot, so nothing cancels -- and two quad exchanges combine them.  Replaces the
+    // statistics launch (5 us + a launch boundary on a chain of dependent launches); measured in round 3 as 160 cross-lane
+    // shuffles per wave on the accumulator registers it cost 5 us, through LDS it is 16 stores + 16 loads per thread.
+    if constexpr (FAST) {
+        if (J.stat != nullptr) {
+            constexpr int TP = 65;   // pitch: the 16 rows x 4 segments a wave reads in one step fall in 64 different banks
+            float* T = &As[0][0];
+            static_assert(2 * SG_BK * (SG_T * MB + 4) >= SG_T * MB * TP, "the tile must fit the A ring");
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[(mb * 64 + wm * 32 + acc_row(r) + 4 * h) * TP + wn * 32 + li] = acc[mb][r] * alpha;
+            __syncthreads();
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int row = mb * 64 + (tid >> 2), seg = tid & 3;
+                const float* tr = T + row * TP;
+                const float pivot = tr[0];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float d = tr[seg * 16 + j] - pivot;
+                    s1 += d, s2 = fmaf(d, d, s2);
+                }
+                s1 += __shfl_xor(s1, 1, 64), s2 += __shfl_xor(s2, 1, 64);
+                s1 += __shfl_xor(s1, 2, 64), s2 += __shfl_xor(s2, 2, 64);
+                if (seg == 0) {
+                    const float mean_d = s1 * (1.f / 64.f);
+                    f32x2 o = {pivot + mean_d, fmaxf(s2 - s1 * mean_d, 0.f)};
+                    *reinterpret_cast<f32x2*>(J.stat + (((size_t)(m0 + row) * jobs.B + b) * J.tiles_n + nt) * 2) = o;
+                }
+            }
+        }
+    }
 }
 
 const char* sg_gemm_unsupported(const SgJob& j) {
@@ -207,9 +244,10 @@ const char* sg_gemm_unsupported(const SgJob& j) {
     return nullptr;
 }
 
-void sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb) {
+bool sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb) {
     const int MT = SG_T * (mb == 2 ? 2 : 1);
     int base = 0;
+    jobs.B = B;
     bool fast = true;
     for (int i = 0; i < jobs.n; ++i) {
         SgJob& j = jobs.j[i];
@@ -231,6 +269,7 @@ void sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb) {
     auto kernel = mb == 2 ? (fast ? sg_gemm_kernel<2, true> : sg_gemm_kernel<2, false>)
                           : (fast ? sg_gemm_kernel<1, true> : sg_gemm_kernel<1, false>);
     hipLaunchKernelGGL(kernel, dim3(base), dim3(256), 0, stream, jobs);
+    return fast;
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients

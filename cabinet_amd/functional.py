@@ -174,6 +174,80 @@ def cab_attention(q, k, v, scale, precision=None):
     return torch.bmm(v, attn.transpose(1, 2))
 
 
+class _CabAttentionProj(torch.autograd.Function):
+    """K1 with the CAB's output projection in its epilogue: ``project_out(attention(q, k, v))`` in ONE launch
+    (cabinet_cab_attn_proj_fwd).  Backward = the projection's backward (cabinet_conv1x1_bwd: dctx, dw) + K2."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, q, k, v, w_out, scale):
+        lib = _lib.load()
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        w2 = _f32c(w_out.detach()).reshape(w_out.shape[0], -1)
+        B, Kc, n = q.shape
+        Vc, Co = v.shape[1], w2.shape[0]
+        need_ctx = any(fn_ctx.needs_input_grad[:4])
+        ctx = torch.empty((B, Vc, n), dtype=torch.float32, device=q.device) if need_ctx else None
+        glob = torch.empty((B, Co, n), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, n), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = lib.cabinet_cab_attn_proj_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(w2), float(scale), B, Kc, Vc, Co, n, _ptr(ctx),
+                                               _ptr(glob), _ptr(lse), _stream_handle(q.device))
+        _lib.check(rc, "cabinet_cab_attn_proj_fwd")
+        if need_ctx:
+            fn_ctx.save_for_backward(q, k, v, ctx, lse, w2)
+        fn_ctx.scale, fn_ctx.w_shape = scale, w_out.shape
+        return glob
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        q, k, v, ctx, lse, w2 = fn_ctx.saved_tensors
+        g = _f32c(g)
+        B, Vc, n = ctx.shape
+        Co = w2.shape[0]
+        need_attn, need_w = any(fn_ctx.needs_input_grad[:3]), fn_ctx.needs_input_grad[3]
+        dctx = torch.empty_like(ctx) if need_attn else None
+        dw = torch.empty_like(w2) if need_w else None
+        ws, nbytes = _workspace(lib.cabinet_conv1x1_bwd_workspace_bytes(B, Vc, Co, n), g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.cabinet_conv1x1_bwd(_ptr(g), _ptr(ctx), _ptr(w2), B, Vc, Co, n, _ptr(dctx), _ptr(dw), _ptr(ws), nbytes,
+                                         _stream_handle(g.device))
+        _lib.check(rc, "cabinet_conv1x1_bwd")
+        dq = dk = dv = None
+        if need_attn:
+            dq, dk, dv = attn_bwd_hip(dctx, q, k, v, ctx, lse, fn_ctx.scale)
+        return dq, dk, dv, (dw.reshape(fn_ctx.w_shape) if need_w else None), None
+
+
+def cab_attention_proj_supported(q, v, w_out):
+    """True when ``project_out(cab_attention(q, k, v))`` runs as ONE kernel (K1 with the projection in its epilogue): device
+    tensors, the 8-wave kernel's channel pairs, n % 4 == 0, Co % 32 == 0, a batch the forward runs without a key split, fp32 MFMA
+    (the split-bf16 precisions keep the two-launch form)."""
+    if not (q.is_cuda and q.dim() == 3 and v.dim() == 3 and w_out.dim() in (2, 4)) or ATTN_PRECISION != "fp32" or not PROJ_FUSED:
+        return False
+    if w_out.dim() == 4 and tuple(w_out.shape[2:]) != (1, 1):
+        return False
+    B, Kc, n = q.shape
+    return bool(_lib.load().cabinet_cab_attn_proj_supported(int(B), int(Kc), int(v.shape[1]), int(w_out.shape[0]), int(n)))
+
+
+# CABINET_ATTN_PROJ_FUSED=0 keeps the round-4 pair of launches (K1, then the projection as a small GEMM): A/B timing
+PROJ_FUSED = _os.environ.get("CABINET_ATTN_PROJ_FUSED", "1") != "0"
+
+
+def cab_attention_proj(q, k, v, w_out, scale):
+    """``conv1x1(cab_attention(q, k, v, scale), w_out)`` -> (B, Co, n).  Reference: cab.py:149-155.  ONE launch where
+    :func:`cab_attention_proj_supported`, the two operators otherwise."""
+    if cab_attention_proj_supported(q, v, w_out) and k.shape == q.shape and v.shape[0] == q.shape[0] and v.shape[2] == q.shape[2] \
+            and w_out.shape[1] == v.shape[1]:
+        return _CabAttentionProj.apply(q, k, v, w_out, float(scale))
+    ctx = cab_attention(q, k, v, scale)
+    B, Vc, n = ctx.shape
+    return conv1x1(ctx.reshape(B, Vc, n, 1), w_out).reshape(B, -1, n)
+
+
 # --------------------------------------------------------------------------- FFM
 
 

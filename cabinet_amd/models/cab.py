@@ -17,8 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..functional import (cab_attention, cab_local, cab_local_supported, cab_qkv, cab_qkv_supported,
-                          conv1x1)
+from ..functional import (cab_attention, cab_attention_proj, cab_local, cab_local_supported, cab_qkv, cab_qkv_supported)
 
 
 def _conv_bn_relu_1x1(cin, cout):
@@ -83,9 +82,10 @@ class GlobalContextAttention(nn.Module):
         n = hd * wd
         if xd.is_cuda and self._native_producers(xd):
             # K6: projections, BatchNorm, ReLU and both pyramid poolings as a short chain of MFMA GEMMs and
-            # plane passes (no concat, no full-resolution pyramid maps), then K1/K2 and the output projection
+            # plane passes (no concat, no full-resolution pyramid maps), then K1 with project_out (cab.py:155) applied to
+            # each context tile in its epilogue -- one launch; K1 + a small GEMM for the shapes the fused form does not take
             q, k, v = cab_qkv(xd, self)
-            ctx = conv1x1(cab_attention(q, k, v, k.shape[1] ** -0.5).reshape(b, -1, hd, wd), self.project_out.weight)
+            ctx = cab_attention_proj(q, k, v, self.project_out.weight, k.shape[1] ** -0.5).reshape(b, -1, hd, wd)
             if self.scale > 1:
                 ctx = F.interpolate(ctx, size=(h, w), mode="bilinear", align_corners=False)
             return ctx

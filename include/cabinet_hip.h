@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CABINET_ABI_VERSION 5
+#define CABINET_ABI_VERSION 6
 
 #define CABINET_OK 0
 #define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
@@ -83,6 +83,22 @@ int cabinet_cab_attn_fwd(const float* q, const float* k, const float* v, float s
                          int B, int Kc, int Vc, int n, int precision,
                          float* ctx /* (B,Vc,n) */, float* lse /* (B,n) */,
                          void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+/* K1 with the CAB's output projection in its epilogue (round 5).  Replaces src/models/cab.py:149-155, i.e. the span above
+ * plus   context = self.project_out(context)   (a bias-free 1x1 convolution, w_out: (Co,Vc) row-major):
+ *   glob[b,o,i] = sum_c w_out[o,c] ctx[b,c,i]
+ * applied to each 32-query context tile while the kernel still holds it in LDS: one launch instead of two, and ctx only
+ * reaches memory when the caller asks for it (ctx != NULL: training saves it for cabinet_cab_attn_bwd and the projection's
+ * weight gradient; pass NULL for inference).  fp32 MFMA only.  cabinet_cab_attn_proj_supported() answers 1 for the shapes
+ * the fused form takes -- (Kc,Vc) in {(128,128), (64,64)}, n % 4 == 0, Co % 32 == 0, and a (B, n) the forward runs
+ * without a key split (every BASELINE configuration with B * n/32 >= ~200 query tiles) -- callers use
+ * cabinet_cab_attn_fwd + cabinet_conv1x1_fwd otherwise.  Backward: cabinet_conv1x1_bwd (dctx = w_out^T dglob,
+ * dw_out = dglob ctx^T) followed by cabinet_cab_attn_bwd; no new entry point. */
+int cabinet_cab_attn_proj_supported(int B, int Kc, int Vc, int Co, int n);
+int cabinet_cab_attn_proj_fwd(const float* q, const float* k, const float* v, const float* w_out /* (Co,Vc) */,
+                              float scale, int B, int Kc, int Vc, int Co, int n,
+                              float* ctx /* (B,Vc,n) or NULL */, float* glob /* (B,Co,n) */, float* lse /* (B,n) */,
+                              cabinet_stream_t stream);
 
 /* Backward of the span above (what autograd derives for cab.py:149-154).
  * Recomputes the affinity tiles from q, k and lse; dctx is dL/dctx (B,Vc,n). */

@@ -266,3 +266,76 @@ def test_attn_bwd_lds_attribute_covers_a_later_larger_n():
         assert_close(qd.grad, dq_ref, TOL, f"dq n={n}")
         assert_close(kd.grad, dk_ref, TOL, f"dk n={n}")
         assert_close(vd.grad, dv_ref, TOL, f"dv n={n}")
+
+
+def _proj_reference(q, k, v, w, g, scale):
+    """project_out(attention(q, k, v)) and its gradients in fp64: the reference's own ops (cab.py:149-155)."""
+    q64, k64, v64, w64 = (t.double().requires_grad_(True) for t in (q, k, v, w))
+    attn = torch.softmax(torch.bmm(q64.transpose(1, 2), k64) * scale, dim=-1)
+    ctx = torch.bmm(v64, attn.transpose(1, 2))
+    glob = torch.einsum("oc,bcn->bon", w64, ctx)
+    glob.backward(g.double())
+    return glob.detach(), ctx.detach(), q64.grad, k64.grad, v64.grad, w64.grad
+
+
+@pytest.mark.parametrize("B,Kc,Vc,Co,n,fused", [(8, 128, 128, 256, 1024, True),   # BASELINE config 3's CAB
+                                                (8, 128, 128, 256, 1000, True),   # ragged last query tile
+                                                (1, 128, 128, 64, 4, True), (1, 128, 128, 256, 36, True),
+                                                (8, 64, 64, 512, 1024, True),     # two output blocks per wave
+                                                (16, 128, 128, 32, 512, True),
+                                                (2, 128, 128, 256, 2048, False),  # key split (config 5): K1 + small GEMM
+                                                (2, 128, 128, 256, 1001, False),  # n % 4 != 0
+                                                (1, 256, 128, 512, 160, False)])  # Kc = 256: one wave per SIMD kernel
+def test_attn_proj_autograd_vs_fp64(B, Kc, Vc, Co, n, fused):
+    """cab_attention_proj = project_out(attention): K1 with the projection in its epilogue (one launch) where
+    cabinet_cab_attn_proj_supported says so, K1 + conv1x1 elsewhere -- both against the fp64 composite, forward and all four
+    gradients; the fused form is also bit-reproducible and writes no ctx under no_grad."""
+    from cabinet_amd.functional import cab_attention_proj, cab_attention_proj_supported
+
+    gen = torch.Generator().manual_seed(77 + n + Co)
+    q = torch.randn(B, Kc, n, generator=gen).relu()
+    k = torch.randn(B, Kc, n, generator=gen)
+    v = torch.randn(B, Vc, n, generator=gen)
+    w = torch.randn(Co, Vc, 1, 1, generator=gen) * Vc ** -0.5
+    g = torch.randn(B, Co, n, generator=gen)
+    scale = Kc ** -0.5
+    qd, kd, vd, wd = (t.cuda().requires_grad_(True) for t in (q, k, v, w))
+    assert cab_attention_proj_supported(qd, vd, wd) == fused
+    glob = cab_attention_proj(qd, kd, vd, wd, scale)
+    glob.backward(g.cuda())
+    torch.cuda.synchronize()
+    ref, _, dq, dk, dv, dw = _proj_reference(q, k, v, w.flatten(1), g, scale)
+    assert_close(glob, ref, 2e-5, "glob vs fp64")
+    assert_close(qd.grad, dq, 1e-4, "dq")
+    assert_close(kd.grad, dk, 1e-4, "dk")
+    assert_close(vd.grad, dv, 1e-4, "dv")
+    assert_close(wd.grad.flatten(1), dw, 1e-4, "dw_out")
+    with torch.no_grad():
+        again = cab_attention_proj(qd, kd, vd, wd, scale)
+    assert torch.equal(again, glob.detach())
+
+
+def test_attn_proj_equals_the_two_launch_form():
+    """Fused epilogue vs cab_attention followed by conv1x1 on the same tensors (config-3 grid): the projection contracts the SAME
+    fp32 context values, in another order -- agreement to fp32 rounding, and the C entry point refuses what it does not take."""
+    import cabinet_amd.functional as Fn
+    from cabinet_amd import _lib
+
+    B, C, n, Co = 8, 128, 1024, 256
+    gen = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(B, C, n, generator=gen).cuda() for _ in range(3))
+    w = (torch.randn(Co, C, generator=gen) * C ** -0.5).cuda()
+    fused = Fn.cab_attention_proj(q, k, v, w, C ** -0.5)
+    ctx = Fn.cab_attention(q, k, v, C ** -0.5)
+    two = Fn.conv1x1(ctx.reshape(B, C, n, 1), w).reshape(B, Co, n)
+    assert rel_err(fused, two) < 2e-6
+    lib = _lib.load()
+    assert lib.cabinet_cab_attn_proj_supported(2, 128, 128, 256, 2048) == 0   # key split
+    assert lib.cabinet_cab_attn_proj_supported(8, 128, 128, 250, 1024) == 0   # Co % 32
+    assert lib.cabinet_cab_attn_proj_supported(8, 256, 128, 256, 1024) == 0   # Kc = 256
+    glob = torch.empty(2, 256, 2048, device="cuda")
+    lse = torch.empty(2, 2048, device="cuda")
+    q2 = torch.randn(2, 128, 2048, device="cuda")
+    rc = lib.cabinet_cab_attn_proj_fwd(q2.data_ptr(), q2.data_ptr(), q2.data_ptr(), w.data_ptr(), 1.0, 2, 128, 128, 256, 2048, None,
+                                       glob.data_ptr(), lse.data_ptr(), None)
+    assert rc == -2 and b"outside the fused form" in lib.cabinet_last_error()
