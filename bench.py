@@ -212,6 +212,12 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
         yield (f"cab_attn_fwd_{name} (K1 on the bf16 matrix pipe: operands split into bf16 pieces, pack pass + attention)",
                lambda c=code: Fh.attn_fwd_hip(q, k, v, scale, c), 2.0 * B * n * n * (Kc + Vc),
                4.0 * B * n * (2 * Kc + 2 * Vc) + 4.0 * B * n, "mfma-" + name)
+    wpo = (torch.randn(2 * Vc, Vc, generator=g) * Vc ** -0.5).to(dev)
+    if Fh.cab_attention_proj_supported(q, v, wpo):   # the form the model's CAB runs where the forward needs no key split
+        qg = q.clone().requires_grad_(True)          # training: ctx is written for the backward
+        yield ("cab_attn_proj_fwd (K1 + the CAB's output projection 128 -> 256 applied to the context tile in its epilogue)",
+               lambda: Fh.cab_attention_proj(qg, k, v, wpo, scale), 2.0 * B * n * n * (Kc + Vc) + 2.0 * B * n * Vc * 2 * Vc,
+               4.0 * B * n * (2 * Kc + 2 * Vc + 2 * Vc) + 4.0 * B * n, "mfma")
     yield ("cab_attn_bwd (K2: dk/dv + stored dS, dq = dS (K - mean K) as a small GEMM)", lambda: Fh.attn_bwd_hip(dctx, q, k, v, ctx, lse, scale), 2.0 * B * n * n * (3 * Kc + 2 * Vc),
           4.0 * B * n * (3 * Kc + 3 * Vc) * 2 + 8.0 * B * n, "mfma")
 
@@ -293,7 +299,7 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
     q3 = Fh.cab_qkv(xc, cab.global_attn)
     gq = [torch.randn_like(t) for t in q3]
     fl_q = 2.0 * B * n * (256 * 384 + 2 * 128 * 128)
-    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 4 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
+    yield ("cab_qkv_fwd (K6: projections + BN + PSP, 3 launches)", lambda: Fh.cab_qkv(xc.detach(), cab.global_attn), fl_q, 4.0 * B * n * (256 + 3 * 128), "mfma")
     yield ("cab_qkv_bwd (K6: adjoint chain, 6 launches)", lambda: Fh._CabQkv.backward(q3[0].grad_fn, *gq), 2.0 * fl_q, 4.0 * B * n * (2 * 256 + 6 * 128), "mfma")
     del cab, xc, gc, yl, q3, gq
     torch.cuda.empty_cache()
@@ -316,6 +322,32 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
         yield (f"conv3x3_{tag}_bwd (K11: data gradient + weight gradient, both Winograd, ordered slab sum)",
                lambda: Fh.conv3x3_bwd_hip(dy, x0, x1, wt), 2.0 * fl, 2.0 * io, "mfma")
         del x0, x1, wt, dy
+        torch.cuda.empty_cache()
+
+    # ---- K12: BatchNorm -> ReLU -> 1x1 classifier as one streaming operator behind K11 (conv_out's tail,
+    # cabinet.py:160-172; f2: the fusion head's b2 -> b3 -> b4, cabinet.py:90-92), statistics from K11's epilogue partials as in
+    # the step.  Algorithmic bytes = the passes a training-mode BatchNorm cannot avoid when the activation is never written:
+    # forward read z + write the logits; backward read z and dy twice + write dz.
+    import torch.nn as nn
+
+    for tag, hh, ww, has_bias in (("out", h, w, False), ("head", hl, wl, True)):
+        Cz = 256
+        x0 = torch.randn(B, Cz, hh, ww, generator=g).to(dev)
+        wt = (torch.randn(Cz, Cz, 3, 3, generator=g) * 0.02).to(dev)
+        part = Fh.conv3x3_bn_part(x0, Cz)
+        zc = Fh.conv3x3(x0, wt, None, part).requires_grad_(True)
+        bn = nn.BatchNorm2d(Cz).to(dev).train()
+        cls = nn.Conv2d(Cz, ncls, 1, bias=has_bias).to(dev)
+        gy = torch.randn(B, ncls, hh, ww, generator=g).to(dev)
+        del x0, wt
+        nz, ny = 4.0 * zc.numel(), 4.0 * gy.numel()
+        yk = Fh.bn_relu_cls(zc, bn, cls, conv_part=part)
+        if type(yk.grad_fn).__name__ == "_BnClsBackward":
+            yield (f"bn_cls_{tag}_fwd (K12: BatchNorm finalize + table, then ONE pass: relu(bn(z)) in registers, {ncls} logits out)",
+                   lambda: Fh.bn_relu_cls(zc.detach(), bn, cls, conv_part=part), 2.0 * zc.numel() * ncls, nz + ny, "hbm")
+            yield (f"bn_cls_{tag}_bwd (K12: reduce with da formed on the fly, ordered finalize, dz pass; the activation's gradient never exists)",
+                   lambda: Fh._BnCls.backward(yk.grad_fn, gy), 4.0 * zc.numel() * ncls, 3 * nz + 2 * ny, "hbm")
+        del zc, yk, gy, part
         torch.cuda.empty_cache()
 
 
@@ -385,7 +417,8 @@ def _backbone_cases(B, H, W, g, dev):
 _NOTES = {
     "cab_local_fwd": "one workgroup per channel, whole chain in LDS: bound by LDS latency / barriers, not HBM",
     "cab_local_bwd": "one workgroup per channel, chain recomputed in LDS: bound by LDS latency / barriers, not HBM",
-    "cab_qkv_fwd": "4 dependent launches of <= 21 us each on 8192 positions: latency / small-tile MFMA bound",
+    "cab_qkv_fwd": "3 dependent launches (round 5: BatchNorm statistics from the projection GEMM's epilogue) on 8192 positions: "
+                   "latency / small-tile MFMA bound",
     "cab_qkv_bwd": "6 dependent launches on 8192 positions: latency / small-tile MFMA bound",
     "cab_attn_bwd": "traffic above the algorithmic bytes is the stored dS (33.5 MB written once, read by the dq product) "
                     ": it replaces recomputing S and dP for dq (4.3 GFLOP)",
@@ -395,6 +428,8 @@ _NOTES = {
     "conv3x3_b1_bwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
     "conv3x3_out_fwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
     "conv3x3_out_bwd": "executed FLOPs (Winograd: direct / 2.25); direct-equivalent rate = 2.25 x tflops",
+    "bn_cls_out_fwd": "one pass over z (the 3x3's output); a = relu(bn(z)) lives in registers; per-channel scalars by scalar loads",
+    "bn_cls_out_bwd": "two passes over z; da = W^T dy is formed per element (8 FMAs), dW and the BatchNorm sums in the same pass",
     "ohem_up_fwd": "exp/log and VALU bound (8 exps per pixel), not HBM",
     "ohem_up_pair_fwd": "what the step runs: both heads per launch; exp/log and VALU bound (16 exps per pixel, one log-sum-exp "
                         "shift per source interval), not HBM",

@@ -12,7 +12,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcabinet_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers
 _INT, _FLT, _SZ, _PTR = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
@@ -59,6 +59,12 @@ SIGNATURES = {
     "cabinet_bn_act_workspace_bytes": (_SZ, [_INT] * 3),
     "cabinet_bn_act_fwd": (_INT, [_PTR] * 6 + [_INT] * 5 + [_FLT, _FLT] + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
     "cabinet_bn_act_bwd": (_INT, [_PTR] * 6 + [_INT] * 5 + [_PTR] * 3 + [_PTR, _SZ, _PTR]),
+    "cabinet_bn_cls_supported": (_INT, [_INT] * 3),
+    "cabinet_bn_cls_table_floats": (_INT, [_INT] * 2),
+    "cabinet_bn_cls_fwd_workspace_bytes": (_SZ, [_INT] * 3),
+    "cabinet_bn_cls_fwd": (_INT, [_PTR] * 8 + [_INT] * 6 + [_FLT, _FLT] + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
+    "cabinet_bn_cls_bwd_workspace_bytes": (_SZ, [_INT] * 4),
+    "cabinet_bn_cls_bwd": (_INT, [_PTR] * 3 + [_INT] * 6 + [_PTR] * 5 + [_PTR, _SZ, _PTR]),
     "cabinet_gate_act_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR]),
     "cabinet_gate_act_bwd_workspace_bytes": (_SZ, [_INT] * 3),
     "cabinet_gate_act_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),

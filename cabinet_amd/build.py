@@ -25,8 +25,8 @@ OBJ_DIR = os.path.join(PKG_DIR, "csrc", "build")
 LIB_PATH = os.path.join(PKG_DIR, "libcabinet_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["capi.hip", "cab_attn_fwd.hip", "cab_attn_bf16.hip", "cab_attn_bwd.hip", "ffm.hip", "ffm_bwd_fused.hip", "ffm_bwd_adj.hip", "ffm_fwd_fused.hip", "gemm_bf16.hip", "ohem.hip", "cab_local.hip", "cab_local_tiled.hip", "cab_qkv.hip", "cab_qkv_fused.hip", "bn_act.hip", "dwconv.hip", "stem_conv.hip", "pwconv.hip", "small_gemm.hip", "conv3x3_wino.hip"]
-HEADERS = ["common.hpp", "cab_local.hpp", "cab_qkv.hpp", "blocks.hpp", "act.hpp", os.path.join("..", "..", "include", "cabinet_hip.h")]
+SOURCES = ["capi.hip", "cab_attn_fwd.hip", "cab_attn_bf16.hip", "cab_attn_bwd.hip", "ffm.hip", "ffm_bwd_fused.hip", "ffm_bwd_adj.hip", "ffm_fwd_fused.hip", "gemm_bf16.hip", "ohem.hip", "cab_local.hip", "cab_local_tiled.hip", "cab_qkv.hip", "cab_qkv_fused.hip", "bn_act.hip", "dwconv.hip", "stem_conv.hip", "pwconv.hip", "small_gemm.hip", "conv3x3_wino.hip", "bn_cls.hip"]
+HEADERS = ["common.hpp", "cab_local.hpp", "cab_qkv.hpp", "blocks.hpp", "act.hpp", "bn_finalize.hpp", os.path.join("..", "..", "include", "cabinet_hip.h")]
 
 
 def _hipcc():

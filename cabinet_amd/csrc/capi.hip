@@ -77,6 +77,16 @@ size_t gate_act_workspace(int rows, int P);
 hipError_t gate_act_fwd_run(const float* x, const float* gate, int rows, int P, int act, float* y, hipStream_t stream);
 hipError_t gate_act_bwd_run(const float* dy, const float* x, const float* gate, int rows, int P, int act, float* dx,
                             float* dgate, void* ws, hipStream_t stream);
+// bn_cls.hip
+bool bn_cls_supported(int C, int K, int P);
+int bn_cls_table_floats(int C, int K);
+size_t bn_cls_fwd_workspace(int B, int C, int P);
+size_t bn_cls_bwd_workspace(int B, int C, int K, int P);
+hipError_t bn_cls_fwd_run(const float* z, const float* conv_part, const float* bn_w, const float* bn_b, float* run_mean, float* run_var,
+                          const float* w_cls, const float* bias, int B, int C, int K, int H, int W, int training, float momentum,
+                          float eps, float* y, float* tab, void* ws, hipStream_t stream);
+hipError_t bn_cls_bwd_run(const float* dy, const float* z, const float* tab, int B, int C, int K, int H, int W, int training, float* dz,
+                          float* dbn_w, float* dbn_b, float* dw_cls, float* dbias, void* ws, hipStream_t stream);
 // dwconv.hip
 bool dwconv_supported(int K, int S);
 size_t dwconv_bwd_workspace(int B, int C, int H, int W, int K);
@@ -754,6 +764,55 @@ int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, con
     return hip_status(cabinet::bn_act_bwd_run(dy, x, weight, bias, save_mean, save_invstd, B, C, P, act, training, dx,
                                               dweight, dbias, workspace, static_cast<hipStream_t>(stream)),
                       "bn_act_bwd launch");
+}
+
+// ------------------------------------------------------ BatchNorm + ReLU + 1x1 classifier (K12)
+int cabinet_bn_cls_supported(int C, int K, int P) { return cabinet::bn_cls_supported(C, K, P) ? 1 : 0; }
+int cabinet_bn_cls_table_floats(int C, int K) { return (C > 0 && K > 0 && K <= 32) ? cabinet::bn_cls_table_floats(C, K) : 0; }
+
+static int check_bn_cls(int B, int C, int K, int H, int W, const char* who) {
+    if (B <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0) return fail(CABINET_ERR_INVALID_ARG, "%s: non-positive dimension", who);
+    if (!cabinet::bn_cls_supported(C, K, H * W))
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: (C=%d, K=%d, H*W=%d) outside C %% 64 == 0, K <= 32, (H*W) %% 4 == 0", who, C, K, H * W);
+    if ((long long)B * ((H * W + 63) / 64) > 2147483647LL || (long long)B * C * H * W >= (1LL << 40))
+        return fail(CABINET_ERR_UNSUPPORTED, "%s: grid too large", who);
+    return CABINET_OK;
+}
+
+size_t cabinet_bn_cls_fwd_workspace_bytes(int B, int C, int P) {
+    return (B > 0 && C > 0 && P > 0) ? cabinet::bn_cls_fwd_workspace(B, C, P) : 0;
+}
+
+int cabinet_bn_cls_fwd(const float* z, const float* conv_part, const float* bn_weight, const float* bn_bias, float* running_mean,
+                       float* running_var, const float* w_cls, const float* bias, int B, int C, int K, int H, int W, int training,
+                       float momentum, float eps, float* y, float* table, void* workspace, size_t workspace_bytes,
+                       cabinet_stream_t stream) {
+    if (int rc = check_bn_cls(B, C, K, H, W, "bn_cls_fwd")) return rc;
+    if (!z || !bn_weight || !bn_bias || !running_mean || !running_var || !w_cls || !y || !table)
+        return fail(CABINET_ERR_INVALID_ARG, "bn_cls_fwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("bn_cls_fwd", z, y, table);
+    const size_t need = cabinet::bn_cls_fwd_workspace(B, C, H * W);
+    if (!workspace || workspace_bytes < need) return fail(CABINET_ERR_WORKSPACE, "bn_cls_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::bn_cls_fwd_run(z, conv_part, bn_weight, bn_bias, running_mean, running_var, w_cls, bias, B, C, K, H, W,
+                                              training, momentum, eps, y, table, workspace, static_cast<hipStream_t>(stream)),
+                      "bn_cls_fwd launch");
+}
+
+size_t cabinet_bn_cls_bwd_workspace_bytes(int B, int C, int K, int P) {
+    return (B > 0 && C > 0 && K > 0 && K <= 32 && P > 0) ? cabinet::bn_cls_bwd_workspace(B, C, K, P) : 0;
+}
+
+int cabinet_bn_cls_bwd(const float* dy, const float* z, const float* table, int B, int C, int K, int H, int W, int training, float* dz,
+                       float* dbn_weight, float* dbn_bias, float* dw_cls, float* dbias, void* workspace, size_t workspace_bytes,
+                       cabinet_stream_t stream) {
+    if (int rc = check_bn_cls(B, C, K, H, W, "bn_cls_bwd")) return rc;
+    if (!dy || !z || !table || !dz || !dbn_weight || !dbn_bias || !dw_cls) return fail(CABINET_ERR_INVALID_ARG, "bn_cls_bwd: null tensor pointer");
+    CABINET_REQUIRE_ALIGNED("bn_cls_bwd", dy, z, table, dz);
+    const size_t need = cabinet::bn_cls_bwd_workspace(B, C, K, H * W);
+    if (!workspace || workspace_bytes < need) return fail(CABINET_ERR_WORKSPACE, "bn_cls_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::bn_cls_bwd_run(dy, z, table, B, C, K, H, W, training, dz, dbn_weight, dbn_bias, dw_cls, dbias, workspace,
+                                              static_cast<hipStream_t>(stream)),
+                      "bn_cls_bwd launch");
 }
 
 // ------------------------------------------------------ depthwise convolution

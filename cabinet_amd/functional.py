@@ -5,6 +5,7 @@
 ``cab_local``       cab.py:182-184 and :213-216                           (K5)
 ``ffm_fused``       src/models/cabinet.py:142-153                         (K3 / K4; ``ffm_fused_upsampled`` + :228-230)
 ``bn_act``          cabinet.py:42-44 and every BatchNorm2d(+act) pair     (K7)     ``gate_act``  mobilenetv3.py:79-83
+``bn_relu_cls``     cabinet.py:90-92, :161-172 (BN -> ReLU -> 1x1 classifier)  (K12)   ``conv3x3``  cabinet.py:59, :88-89, :160 (K11)
 ``dwconv`` / ``bn_act_dwconv``   mobilenetv3.py:118-126,135-143           (K8)
 ``stem_conv``       cabinet.py:111                                        (K9)     ``pwconv``   mobilenetv3.py:128-131
 OHEM head           src/utils/loss.py:51-80 + cabinet.py:240-245          (``ohem_up_*``, used by cabinet_amd.loss)
@@ -986,6 +987,84 @@ def bn_act(x, bn, act=None, residual=None, conv_part=None):
                             bn.eps, residual, conv_part)
     return _BnAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, _ACT_CODES[act], training, momentum,
                         bn.eps, residual)
+
+
+# --------------------------------------------------------------------------- BatchNorm + ReLU + 1x1 classifier (K12)
+
+# CABINET_BN_CLS=0 keeps the round-4 pair (K7 BatchNorm + ReLU, then the stock 1x1 convolution): A/B timing
+BN_CLS_ENABLED = _os.environ.get("CABINET_BN_CLS", "1") != "0"
+
+
+class _BnCls(torch.autograd.Function):
+    """``conv1x1(relu(bn(z)))`` as one streaming operator (cabinet_bn_cls_fwd / _bwd): the activation and its gradient are never
+    written.  Saved for backward: z and the per-channel table (classifier column, mean, invstd, gamma, beta)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, z, bn_w, bn_b, run_mean, run_var, w_cls, bias, training, momentum, eps, conv_part=None):
+        lib = _lib.load()
+        z = _f32c(z)
+        B, C, H, W = z.shape
+        K = w_cls.shape[0]
+        w2 = _f32c(w_cls.detach()).reshape(K, C)
+        y = torch.empty((B, K, H, W), dtype=torch.float32, device=z.device)
+        tab = torch.empty(lib.cabinet_bn_cls_table_floats(C, K), dtype=torch.float32, device=z.device)
+        ws, nbytes = _workspace(lib.cabinet_bn_cls_fwd_workspace_bytes(B, C, H * W), z.device)
+        with torch.cuda.device(z.device):
+            rc = lib.cabinet_bn_cls_fwd(_ptr(z), _ptr(conv_part), _ptr(bn_w), _ptr(bn_b), _ptr(run_mean), _ptr(run_var), _ptr(w2),
+                                        _ptr(bias), B, C, K, H, W, int(training), float(momentum), float(eps), _ptr(y), _ptr(tab),
+                                        _ptr(ws), nbytes, _stream_handle(z.device))
+        _lib.check(rc, "cabinet_bn_cls_fwd")
+        fn_ctx.save_for_backward(z, tab)
+        fn_ctx.training, fn_ctx.w_shape, fn_ctx.has_bias = bool(training), w_cls.shape, bias is not None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        z, tab = fn_ctx.saved_tensors
+        g = _f32c(g)
+        B, C, H, W = z.shape
+        K = g.shape[1]
+        dz = torch.empty_like(z)
+        dbn_w = torch.empty(C, dtype=torch.float32, device=z.device)
+        dbn_b = torch.empty(C, dtype=torch.float32, device=z.device)
+        dw = torch.empty((K, C), dtype=torch.float32, device=z.device)
+        db = torch.empty(K, dtype=torch.float32, device=z.device) if fn_ctx.has_bias else None
+        ws, nbytes = _workspace(lib.cabinet_bn_cls_bwd_workspace_bytes(B, C, K, H * W), z.device)
+        with torch.cuda.device(z.device):
+            rc = lib.cabinet_bn_cls_bwd(_ptr(g), _ptr(z), _ptr(tab), B, C, K, H, W, int(fn_ctx.training), _ptr(dz), _ptr(dbn_w),
+                                        _ptr(dbn_b), _ptr(dw), _ptr(db), _ptr(ws), nbytes, _stream_handle(z.device))
+        _lib.check(rc, "cabinet_bn_cls_bwd")
+        grads = (dz, dbn_w, dbn_b, None, None, dw.view(fn_ctx.w_shape), db, None, None, None)
+        if len(fn_ctx.needs_input_grad) > 10:  # called with the producer's statistics partials (a buffer, not a variable)
+            grads += (None,)
+        return grads
+
+
+def bn_relu_cls_supported(z, bn, cls):
+    """True when ``cls(relu(bn(z)))`` runs as K12: a device (B,C,H,W) tensor, ``cls`` a plain 1x1 nn.Conv2d (stride 1, no padding,
+    one group; bias optional), C % 64 == 0, at most 32 classes, H*W % 4 == 0."""
+    if not (BN_CLS_ENABLED and z.is_cuda and z.dim() == 4):
+        return False
+    if not (cls.kernel_size == (1, 1) and cls.stride == (1, 1) and cls.padding == (0, 0) and cls.dilation == (1, 1)
+            and cls.groups == 1 and cls.in_channels == z.shape[1] and bn.num_features == z.shape[1] and bn.affine
+            and bn.track_running_stats):
+        return False
+    return bool(_lib.load().cabinet_bn_cls_supported(int(z.shape[1]), int(cls.out_channels), int(z.shape[2] * z.shape[3])))
+
+
+def bn_relu_cls(z, bn, cls, conv_part=None):
+    """``cls(relu(bn(z)))`` for a device tensor: ``bn`` the nn.BatchNorm2d (running buffers updated in place in training mode),
+    ``cls`` the 1x1 nn.Conv2d classifier behind it (reference cabinet.py:90-92 and :161-172).  ONE operator (K12) where
+    :func:`bn_relu_cls_supported`, K7 + the stock convolution otherwise.  ``conv_part``: the statistics partials ``conv3x3`` wrote
+    while it produced ``z``."""
+    if not bn_relu_cls_supported(z, bn, cls):
+        return cls(bn_act(z, bn, "relu", conv_part=conv_part))
+    training, momentum = _bn_step(bn)
+    args = (z, bn.weight, bn.bias, bn.running_mean, bn.running_var, cls.weight, cls.bias, training, momentum, bn.eps)
+    return _BnCls.apply(*args, conv_part) if conv_part is not None else _BnCls.apply(*args)
 
 
 # --------------------------------------------------------------------------- depthwise convolution (K8)

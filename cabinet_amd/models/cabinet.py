@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as _functional
-from ..functional import (batched_bn_counters, bn_act, conv3x3, conv3x3_bn_part, conv3x3_supported, ffm_fused,
+from ..functional import (batched_bn_counters, bn_act, bn_relu_cls, conv3x3, conv3x3_bn_part, conv3x3_supported, ffm_fused,
                           ffm_fused_upsampled, stem_conv, stem_conv_supported)
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
@@ -54,6 +54,18 @@ def _conv3x3_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, x1: O
         part = conv3x3_bn_part(x, conv.out_channels) if bn.training else None
         return bn_act(conv3x3(x, conv.weight, x1, part), bn, "relu", conv_part=part)
     return bn_act(conv(x if x1 is None else torch.cat([x, x1], dim=1)), bn, "relu")
+
+
+def _conv3x3_bn_relu_cls(conv: nn.Conv2d, bn: nn.BatchNorm2d, cls: nn.Conv2d, x: torch.Tensor,
+                         x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``cls(relu(bn(conv(cat([x, x1], 1)))))``: K11 for the 3x3 (as :func:`_conv3x3_bn_relu`), then K12 -- BatchNorm, ReLU and the
+    1x1 classifier as one streaming operator that never writes the (B, 256, H', W') activation or, in backward, its gradient
+    (reference cabinet.py:88-92 and :160-172); shapes outside K12's coverage take K7 + the stock 1x1 convolution."""
+    c1 = 0 if x1 is None else x1.shape[1]
+    if _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels):
+        part = conv3x3_bn_part(x, conv.out_channels) if bn.training else None
+        return bn_relu_cls(conv3x3(x, conv.weight, x1, part), bn, cls, conv_part=part)
+    return bn_relu_cls(conv(x if x1 is None else torch.cat([x, x1], dim=1)), bn, cls)
 
 
 class ConvBNReLU(nn.Module):
@@ -101,7 +113,8 @@ class AttentionBranch(nn.Module):
             feat = self.a2block(_conv3x3_bn_relu(self.conva[0], self.conva[1], x))
             low_res_out = self.convb(feat)
             # K11 reads x and feat through two pointers: the (B, inplanes + 256, H', W') concat is never written
-            return low_res_out, self.b4(_conv3x3_bn_relu(self.b1, self.b2, x, feat))
+            # ... and K12 runs b2 -> b3 -> b4 as one operator: the ReLU output is never written
+            return low_res_out, _conv3x3_bn_relu_cls(self.b1, self.b2, self.b4, x, feat)
         feat = self.a2block(self.conva(x))
         low_res_out = self.convb(feat)
         high_res_out = self.b4(self.b3(self.b2(self.b1(torch.cat([x, feat], dim=1)))))
@@ -172,6 +185,8 @@ class CABiNetOutput(nn.Module):
         self.conv_out = nn.Conv2d(mid_chan, n_classes, kernel_size=1, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and x.shape[1] != 3:   # K11 (3x3) + K12 (BatchNorm -> ReLU -> classifier in one pass over the 3x3's output)
+            return _conv3x3_bn_relu_cls(self.conv.conv, self.conv.bn, self.conv_out, x)
         return self.conv_out(self.conv(x))
 
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CABINET_ABI_VERSION 6
+#define CABINET_ABI_VERSION 7
 
 #define CABINET_OK 0
 #define CABINET_ERR_INVALID_ARG (-1) /* null pointer, non-positive dim            */
@@ -347,6 +347,37 @@ int cabinet_bn_act_bwd(const float* dy, const float* x, const float* weight, con
                        const float* save_mean, const float* save_invstd,
                        int B, int C, int P, int act, int training,
                        float* dx, float* dweight, float* dbias,
+                       void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * BatchNorm2d -> ReLU -> 1x1 classifier convolution as ONE streaming operator (round 5, K12).
+ * Replaces the tail of src/models/cabinet.py:156-172 (CABiNetOutput.forward: `self.conv_out(relu(bn(conv(x))))`, behind
+ * cabinet_conv3x3_fwd) and of the fusion head, cabinet.py:90-92 (`self.b4(self.b3(self.b2(.)))`):
+ *     y[b,k,p] = bias[k] + sum_c w_cls[k,c] * relu(bn_weight[c] * (z[b,c,p] - mean[c]) * invstd[c] + bn_bias[c])
+ * z (B,C,H,W): the convolution output in front of the BatchNorm;  w_cls (K,C): the 1x1 classifier;  bias (K) or NULL.
+ * The (B,C,H,W) activation and, in backward, its gradient are never written: forward reads z once and writes the K
+ * logits; backward reads z and dy twice and writes dz.  training != 0: batch statistics -- from conv_part when given (the
+ * (mean, M2) pairs cabinet_conv3x3_fwd left: [2][C][cabinet_conv3x3_tile_blocks(B,H,W)], no statistics pass), else from a
+ * pass over z -- and running_mean / running_var updated like nn.BatchNorm2d; training == 0: running statistics.
+ * `table` (cabinet_bn_cls_table_floats(C,K) floats) is written by fwd and read by bwd: per channel the classifier column
+ * and [mean, invstd, bn_weight, bn_bias, bn_weight * invstd].  Covered: C % 64 == 0, K <= 32, (H*W) % 4 == 0
+ * (cabinet_bn_cls_supported).  Deterministic (ordered partial sums, no atomics).
+ *   bwd: du = (pre > 0) * sum_k w_cls[k,c] dy[k];  dbn_weight = sum du * xhat;  dbn_bias = sum du;
+ *        dz = bn_weight * invstd * (du - mean(du) - xhat * mean(du * xhat))  (training; eval: bn_weight * invstd * du);
+ *        dw_cls[k,c] = sum dy[k] * relu(pre);  dbias[k] = sum dy[k]  (dbias may be NULL).
+ * ------------------------------------------------------------------------- */
+int cabinet_bn_cls_supported(int C, int K, int P);
+int cabinet_bn_cls_table_floats(int C, int K);
+size_t cabinet_bn_cls_fwd_workspace_bytes(int B, int C, int P);
+int cabinet_bn_cls_fwd(const float* z, const float* conv_part /* nullable */, const float* bn_weight, const float* bn_bias,
+                       float* running_mean, float* running_var, const float* w_cls /* (K,C) */, const float* bias /* nullable */,
+                       int B, int C, int K, int H, int W, int training, float momentum, float eps,
+                       float* y /* (B,K,H,W) */, float* table,
+                       void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+size_t cabinet_bn_cls_bwd_workspace_bytes(int B, int C, int K, int P);
+int cabinet_bn_cls_bwd(const float* dy /* (B,K,H,W) */, const float* z, const float* table,
+                       int B, int C, int K, int H, int W, int training,
+                       float* dz, float* dbn_weight, float* dbn_bias, float* dw_cls, float* dbias /* nullable */,
                        void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
 
 /* ------------------------------------------------------------------------- *

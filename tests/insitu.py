@@ -63,6 +63,12 @@ def instrument(net):
     _K11_REGISTRY.update({id(net.ab.conva[0].weight): (cap, keep, "ab.conva"), id(net.ab.b1.weight): (cap, keep, "ab.b1"),
                           id(net.conv_out.conv.conv.weight): (cap, keep, "conv_out.conv")})
     _install_k11_spy()
+    # K12 (round 5): b2 -> b3 -> b4 and conv_out's BatchNorm -> ReLU -> classifier run as ONE operator that never writes the ReLU
+    # output: b4's pre-hook above does not fire.  The spy rebuilds what the hook would have seen from what the operator saved --
+    # r = relu(bn(z)) with the operator's own mean / invstd and its own mask, d(r) = W^T d(logits) -- so that the tables below keep
+    # their meaning (own-mask replay = the operator's arithmetic; fp64-mask replay = arithmetic + flipped units).
+    _K12_REGISTRY.update({id(net.ab.b4.weight): (cap, "ab"), id(net.conv_out.conv_out.weight): (cap, "conv_out")})
+    _install_k12_spy()
     return cap
 
 
@@ -94,6 +100,62 @@ def _install_k11_spy():
 
     conv3x3_spy._insitu_spy = True
     cm.conv3x3 = conv3x3_spy
+
+
+_K12_REGISTRY = {}
+
+
+def own_relu_output(z, mean, invstd, gamma, beta):
+    """relu(bn(z)) as K7 / K12 evaluate it -- pre = fmaf((z - mean) * invstd, gamma, beta), fp32 -- with THEIR mask: the difference and
+    the product are single fp32 operations (emulated exactly by fp32 tensor ops), the fused multiply-add is emulated in fp64 (the
+    product of two fp32 numbers is exact there and the sum keeps its sign), so `pre > 0` here is `pre > 0` in the kernel."""
+    v = lambda t: t.detach().view(1, -1, 1, 1)
+    xh = (z.detach() - v(mean)) * v(invstd)
+    pre = xh.double() * v(gamma).double() + v(beta).double()
+    return pre.clamp_min(0).float()
+
+
+def _install_k12_spy():
+    import cabinet_amd.models.cabinet as cm
+
+    if getattr(cm.bn_relu_cls, "_insitu_spy", False):
+        return
+    orig = cm.bn_relu_cls
+
+    def bn_relu_cls_spy(z, bn, cls, conv_part=None):
+        y = orig(z, bn, cls, conv_part)
+        hit = _K12_REGISTRY.get(id(cls.weight))
+        if hit is None or y.grad_fn is None or type(y.grad_fn).__name__ != "_BnClsBackward":
+            return y   # not instrumented, or the unfused path ran (then b4's own pre-hook captured the ReLU output)
+        cap, name = hit
+        C = z.shape[1]
+        tab = y.grad_fn.saved_tensors[1].view(C, -1)
+        kt = tab.shape[1] - 8
+        cap[name + ".bn_mean"], cap[name + ".bn_invstd"] = tab[:, kt].detach().clone(), tab[:, kt + 1].detach().clone()
+        cap[name + ".r"] = own_relu_output(z, tab[:, kt], tab[:, kt + 1], bn.weight, bn.bias)
+        cap[name + ".hi"] = y.detach().clone()
+        w = cls.weight.detach().double().flatten(1)
+
+        def hook(g):
+            cap["d." + name + ".hi"] = g.detach().clone()
+            cap["d." + name + ".r"] = torch.einsum("kc,bkhw->bchw", w, g.detach().double()).float()
+
+        y.register_hook(hook)
+        return y
+
+    bn_relu_cls_spy._insitu_spy = True
+    cm.bn_relu_cls = bn_relu_cls_spy
+
+
+def replay_cls(weight, bias, r, d_hi):
+    """The 1x1 classifier behind the ReLU (reference cabinet.py:92 / :172) in fp64 on the operator's own ReLU output `r` and the captured
+    gradient of its logits: -> logits, dw, dbias."""
+    w = weight.detach().cpu().double().flatten(1)
+    a, g = r.detach().cpu().double(), d_hi.detach().cpu().double()
+    y = torch.einsum("kc,bchw->bkhw", w, a)
+    if bias is not None:
+        y = y + bias.detach().cpu().double().view(1, -1, 1, 1)
+    return y, torch.einsum("bkhw,bchw->kc", g, a).view_as(weight), g.sum(dim=(0, 2, 3))
 
 
 def replay_conv3x3(weight, x, x1, g, dtype):
@@ -144,7 +206,7 @@ def replay_head(low, labels, size, n_min, dtype, thresh=0.7):
     return float(loss.detach()), lo.grad
 
 
-def replay_b2(sd, z, r_gpu, d_r, training=True, eps=1e-5):
+def replay_b2(sd, z, r_gpu, d_r, training=True, eps=1e-5, prefix="ab.b2"):
     """The fusion head's BatchNorm + ReLU (reference cabinet.py:90-91; here K7 ``bn_act``) on the captured b1 output ``z``
     and the captured gradient ``d_r`` of its ReLU output, in fp64, TWICE: with the mask the fp64 forward produces and with
     the mask the GPU's own forward produced (``r_gpu > 0``).  A gradient that equals the own-mask replay is exact BatchNorm /
@@ -152,14 +214,14 @@ def replay_b2(sd, z, r_gpu, d_r, training=True, eps=1e-5):
     -> dict(out, flips, units, own=(dz, dgamma, dbeta), f64=(dz, dgamma, dbeta))"""
     z = z.detach().cpu().double()
     g = d_r.detach().cpu().double()
-    gamma = sd["ab.b2.weight"].double().view(1, -1, 1, 1)
-    beta = sd["ab.b2.bias"].double().view(1, -1, 1, 1)
+    gamma = sd[prefix + ".weight"].double().view(1, -1, 1, 1)
+    beta = sd[prefix + ".bias"].double().view(1, -1, 1, 1)
     if training:
         mean = z.mean(dim=(0, 2, 3), keepdim=True)
         var = z.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
     else:
-        mean = sd["ab.b2.running_mean"].double().view(1, -1, 1, 1)
-        var = sd["ab.b2.running_var"].double().view(1, -1, 1, 1)
+        mean = sd[prefix + ".running_mean"].double().view(1, -1, 1, 1)
+        var = sd[prefix + ".running_var"].double().view(1, -1, 1, 1)
     invstd = (var + eps).rsqrt()
     xhat = (z - mean) * invstd
     y = gamma * xhat + beta
@@ -249,6 +311,24 @@ def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True, training=T
         flipped_units_vs_f64_mask=b2["flips"], units=b2["units"], gpu_vs_f64_mask_replay=rel(cap["d.ab.b1o"], b2["f64"][0]),
         own_mask_vs_f64_mask_replay=rel(b2["own"][0], b2["f64"][0]))
     del b2
+    # ---- K12 (round 5): where b2 -> b3 -> b4 and conv_out's BatchNorm -> ReLU -> classifier ran as one operator, its logits and the
+    # classifier's gradients against the fp64 replay on the operator's own ReLU output, and conv_out's BatchNorm rows as b2's above
+    if "ab.hi" in cap:
+        y64, dw64, db64 = replay_cls(sd["ab.b4.weight"], sd.get("ab.b4.bias"), cap["ab.r"], cap["d.ab.hi"])
+        put("ab.b4.out", cap["ab.hi"], y64)
+        put("ab.b4.weight", grads["ab.b4.weight"], dw64)
+        put("ab.b4.bias", grads["ab.b4.bias"], db64)
+    if "conv_out.hi" in cap and "conv_out.conv.y" in cap:
+        y64, dw64, _ = replay_cls(sd["conv_out.conv_out.weight"], None, cap["conv_out.r"], cap["d.conv_out.hi"])
+        put("conv_out.conv_out.out", cap["conv_out.hi"], y64)
+        put("conv_out.conv_out.weight", grads["conv_out.conv_out.weight"], dw64)
+        bo = replay_b2(sd, cap["conv_out.conv.y"], cap["conv_out.r"], cap["d.conv_out.r"], training, prefix="conv_out.conv.bn")
+        put("conv_out.bn.dx_own_mask", cap["d.conv_out.conv.y"], bo["own"][0])
+        put("conv_out.bn.weight_own_mask", grads["conv_out.conv.bn.weight"], bo["own"][1])
+        put("conv_out.bn.bias_own_mask", grads["conv_out.conv.bn.bias"], bo["own"][2])
+        rows["conv_out.bn.dx_own_mask"].update(flipped_units_vs_f64_mask=bo["flips"], units=bo["units"],
+                                               own_mask_vs_f64_mask_replay=rel(bo["own"][0], bo["f64"][0]))
+        del bo, y64, dw64
     # ---- the two fused OHEM heads (upstream gradient of each is exactly 1: loss = head + head16)
     losses = {}
     for name in ("head", "head16"):
@@ -275,6 +355,6 @@ def judge_operator_table(rows, tol, training=True):
             r["analytic_zero"] = True
             if not (r["norm"] < 1e-3 * scale_ref and r["gpu_vs_f64"] * r["norm"] < 1e-3 * scale_ref):
                 bad[k] = r
-        elif not r["gpu_vs_f64"] <= (B2_OWN_MASK_TOL if k == "ab.b2.dx_own_mask" else tol):
+        elif not r["gpu_vs_f64"] <= (B2_OWN_MASK_TOL if k in ("ab.b2.dx_own_mask", "conv_out.bn.dx_own_mask") else tol):
             bad[k] = r
     return bad

@@ -114,7 +114,8 @@ def flip_bound(cfg):
     return FLIPS / (256.0 * cfg["cab_positions"]) ** 0.5
 
 
-GATE_PREFIXES = ("ffm.", "head.", "head16.", "conv_out.conv.", "ab.b1.", "ab.conva.")
+GATE_PREFIXES = ("ffm.", "head.", "head16.", "conv_out.conv.", "ab.b1.", "ab.conva.",
+                 "conv_out.bn.", "conv_out.conv_out.", "ab.b2.", "ab.b4.")   # round 5: + K12's rows (the classifier tails sit between the loss and the CAB too)
 
 
 def upstream_gate(insitu_rows, cfg=None, upstream=None):

@@ -55,8 +55,9 @@ def _insitu(mode, batch, height, width, ncls, tag):
         tensors=rows))
     assert abs(float(loss) - loss64) <= 1e-5 * abs(loss64), (float(loss), loss64)
     assert not bad, {k: {n: (f"{v:.2e}" if isinstance(v, float) else v) for n, v in r.items()} for k, r in bad.items()}
-    # 2 + 20 CAB, 3 + 5 FFM, 4 fusion-head BatchNorm, 2 loss heads, 10 K11 (conva: out dw dx; b1: out dw dx dx1; conv_out.conv: out dw dx)
-    assert len(rows) == 2 + 20 + 3 + 5 + 4 + 2 + 10, sorted(rows)
+    # 2 + 20 CAB, 3 + 5 FFM, 4 fusion-head BatchNorm, 2 loss heads, 10 K11 (conva: out dw dx; b1: out dw dx dx1; conv_out.conv: out dw dx),
+    # 8 K12 (ab.b4: out weight bias; conv_out.conv_out: out weight; conv_out's BatchNorm with the operator's own mask: dx weight bias)
+    assert len(rows) == 2 + 20 + 3 + 5 + 4 + 2 + 10 + 8, sorted(rows)
 
 
 @pytest.mark.timeout(1800)

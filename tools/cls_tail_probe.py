@@ -11,7 +11,7 @@ for (B, C, H, W, K, tag) in ((8, 256, 128, 128, 8, "conv_out tail"), (8, 256, 32
     g = torch.randn(B, K, H, W, device=dev)
     def step():
         z.grad = None
-        y = cls(Fh.bn_act(z, bn, "relu"))
+        y = Fh.bn_relu_cls(z, bn, cls)   # CABINET_BN_CLS=0: K7 + the stock 1x1 convolution
         y.backward(g)
     for _ in range(3): step()
     torch.cuda.synchronize()
@@ -22,7 +22,7 @@ for (B, C, H, W, K, tag) in ((8, 256, 128, 128, 8, "conv_out tail"), (8, 256, 32
     print("==", tag)
     for e in sorted(prof.key_averages(), key=lambda e: -e.device_time_total):
         if e.device_type.name != "CUDA" and e.self_device_time_total <= 0: continue
-        if e.self_device_time_total > 0 and not e.key.startswith(("aten::", "autograd", "_BnAct", "torch")):
+        if e.self_device_time_total > 0 and not e.key.startswith(("aten::", "autograd", "_BnAct", "_BnCls", "torch")):
             print(f"{e.self_device_time_total / 5:9.1f} us/step  x{e.count // 5}  {e.key[:100]}")
             tot += e.self_device_time_total / 5
     print(f"   total {tot:.1f} us/step")

@@ -10,7 +10,7 @@ TAG=${1:-r05}
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
 C5="--height 2048 --width 1024 --batch 2 --classes 19"
-S8_GROUPS="cab_attn_fwd cab_attn_fwd_bf16x6 cab_attn_fwd_bf16x3 cab_attn_bwd ffm_up_fwd ffm_up_bwd ohem_up_pair_fwd ohem_up_pair_bwd cab_local_fwd cab_local_bwd cab_qkv_fwd cab_qkv_bwd conv3x3_conva_fwd conv3x3_conva_bwd conv3x3_b1_fwd conv3x3_b1_bwd conv3x3_out_fwd conv3x3_out_bwd"
+S8_GROUPS="cab_attn_fwd cab_attn_fwd_bf16x6 cab_attn_fwd_bf16x3 cab_attn_bwd ffm_up_fwd ffm_up_bwd ohem_up_pair_fwd ohem_up_pair_bwd cab_local_fwd cab_local_bwd cab_qkv_fwd cab_qkv_bwd conv3x3_conva_fwd conv3x3_conva_bwd conv3x3_b1_fwd conv3x3_b1_bwd conv3x3_out_fwd conv3x3_out_bwd cab_attn_proj_fwd bn_cls_out_fwd bn_cls_out_bwd bn_cls_head_fwd bn_cls_head_bwd"
 cd $GRAFT_REPO_ROOT
 # ---- benches first, on the fresh box (behind the profiler passes MIOpen's find database has been seen to change solver choices)
 python bench.py $C5 > $O/${TAG}_config5_bench_n1.json 2> $O/${TAG}_config5_bench_n1.log
