@@ -54,6 +54,9 @@ SIGNATURES = {
     "cabinet_cab_qkv_bwd": (_INT, [_PTR] * 20 + [_INT] * 7 + [_PTR] + [_INT] + [_PTR] * 9 + [_PTR, _SZ, _PTR]),
     "cabinet_conv1x1_fwd_workspace_bytes": (_SZ, [_INT] * 2),
     "cabinet_conv1x1_fwd": (_INT, [_PTR] * 2 + [_INT] * 4 + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_conv1x1_bias_supported": (_INT, [_INT] * 4),
+    "cabinet_conv1x1_bias_fwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] + [_PTR, _SZ, _PTR]),
+    "cabinet_channel_sum": (_INT, [_PTR] + [_INT] * 3 + [_PTR] + [_PTR]),
     "cabinet_conv1x1_bwd_workspace_bytes": (_SZ, [_INT] * 4),
     "cabinet_conv1x1_bwd": (_INT, [_PTR] * 3 + [_INT] * 4 + [_PTR] * 2 + [_PTR, _SZ, _PTR]),
     "cabinet_bn_act_workspace_bytes": (_SZ, [_INT] * 3),

@@ -63,6 +63,7 @@ struct SgJob {
     // tile nt the pair (mean, M2 = sum (d - mean)^2) of the tile's 64 values, stat[((m * B + b) * tiles_n + nt) * 2 + {0, 1}] --
     // BatchNorm batch statistics of the product without a pass over it (merged by the consumer: equal counts, fixed order)
     float* stat;
+    const float* out_bias;  // optional (M): added to every output row m (a 1x1 convolution's bias)
     int tiles_m, tiles_n, tile_base, nck[3], vec;  // filled by sg_gemm
 };
 struct SgJobs {
@@ -88,6 +89,8 @@ struct SdJobs {
     SdJob j[8];
     int n, total_tiles, total_elems;
 };
+// out[c] = sum over images and positions of d (B, C, P): the bias gradient of a 1x1 convolution; one workgroup per channel, fixed order
+hipError_t channel_sum_run(const float* d, int B, int C, int P, float* out, hipStream_t stream);
 size_t sd_plan(SdJobs& jobs, int B);  // slab floats needed for `part`
 hipError_t sd_run(SdJobs& jobs, int B, float* part, hipStream_t stream);
 

@@ -988,15 +988,19 @@ size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P) {
     return small > big ? small : big;
 }
 
+bool conv1x1_bias_supported(int B, int Ci, int Co, int P) { return conv1x1_small(B, Ci, Co, P); }
+
 hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int Co, int P, float* y, void* ws,
-                           hipStream_t stream) {
+                           hipStream_t stream, const float* bias) {
     if (conv1x1_small(B, Ci, Co, P)) {
         SgJobs jobs{};
         jobs.n = 1;
         jobs.j[0] = sg_job(wgt, Ci, 1, x, Ci, Ci, Co, P, y, Co);
+        jobs.j[0].out_bias = bias;
         sg_gemm(jobs, B, stream);
         return hipGetLastError();
     }
+    if (bias != nullptr) return hipErrorInvalidValue;   // the big-plane path has no bias term (capi.hip asks conv1x1_bias_supported first)
     float* wt = static_cast<float*>(ws);  // W^T, [align16(Ci)][Co], zero rows past Ci (K tail of the GEMM)
     if (Ci & 15) {
         hipError_t e = hipMemsetAsync(wt + (size_t)Ci * Co, 0, (size_t)(k16(Ci) - Ci) * Co * sizeof(float), stream);

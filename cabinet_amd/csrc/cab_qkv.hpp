@@ -54,7 +54,8 @@ hipError_t qkv_dx_run(const QkvShape& s, const QkvParams& w, const float* dzqk, 
 size_t conv1x1_fwd_workspace(int Ci, int Co);
 size_t conv1x1_bwd_workspace(int B, int Ci, int Co, int P);
 hipError_t conv1x1_fwd_run(const float* x, const float* wgt, int B, int Ci, int Co, int P, float* y, void* ws,
-                           hipStream_t stream);
+                           hipStream_t stream, const float* bias = nullptr);
+bool conv1x1_bias_supported(int B, int Ci, int Co, int P);   // the small-grid path (CAB resolution) takes an output bias
 hipError_t conv1x1_bwd_run(const float* dy, const float* x, const float* wgt, int B, int Ci, int Co, int P, float* dx,
                            float* dw, void* ws, hipStream_t stream);
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include "blocks.hpp"
 #include "cab_local.hpp"
 #include "cab_qkv.hpp"
 #include "common.hpp"
@@ -689,6 +690,31 @@ int cabinet_conv1x1_fwd(const float* x, const float* w, int B, int Ci, int Co, i
         return fail(CABINET_ERR_WORKSPACE, "conv1x1_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
     return hip_status(cabinet::conv1x1_fwd_run(x, w, B, Ci, Co, P, y, workspace, static_cast<hipStream_t>(stream)),
                       "conv1x1_fwd launch");
+}
+
+int cabinet_conv1x1_bias_supported(int B, int Ci, int Co, int P) {
+    return (B > 0 && Ci > 0 && Co > 0 && P > 0 && cabinet::conv1x1_bias_supported(B, Ci, Co, P)) ? 1 : 0;
+}
+
+int cabinet_conv1x1_bias_fwd(const float* x, const float* w, const float* bias, int B, int Ci, int Co, int P, float* y, void* workspace,
+                             size_t workspace_bytes, cabinet_stream_t stream) {
+    if (int rc = check_conv1x1(B, Ci, Co, P, "conv1x1_bias_fwd")) return rc;
+    if (!x || !w || !bias || !y) return fail(CABINET_ERR_INVALID_ARG, "conv1x1_bias_fwd: null tensor pointer");
+    if (!cabinet::conv1x1_bias_supported(B, Ci, Co, P))
+        return fail(CABINET_ERR_UNSUPPORTED, "conv1x1_bias_fwd: (B=%d, Ci=%d, Co=%d, P=%d) is outside the small-grid path "
+                    "(cabinet_conv1x1_bias_supported)", B, Ci, Co, P);
+    CABINET_REQUIRE_ALIGNED("conv1x1_bias_fwd", x, w, y);
+    const size_t need = cabinet::conv1x1_fwd_workspace(Ci, Co);
+    if (!workspace || workspace_bytes < need)
+        return fail(CABINET_ERR_WORKSPACE, "conv1x1_bias_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return hip_status(cabinet::conv1x1_fwd_run(x, w, B, Ci, Co, P, y, workspace, static_cast<hipStream_t>(stream), bias),
+                      "conv1x1_bias_fwd launch");
+}
+
+int cabinet_channel_sum(const float* d, int B, int C, int P, float* out, cabinet_stream_t stream) {
+    if (B <= 0 || C <= 0 || P <= 0) return fail(CABINET_ERR_INVALID_ARG, "channel_sum: non-positive dimension");
+    if (!d || !out) return fail(CABINET_ERR_INVALID_ARG, "channel_sum: null tensor pointer");
+    return hip_status(cabinet::channel_sum_run(d, B, C, P, out, static_cast<hipStream_t>(stream)), "channel_sum launch");
 }
 
 size_t cabinet_conv1x1_bwd_workspace_bytes(int B, int Ci, int Co, int P) {

@@ -190,12 +190,13 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
     float* dst = J.dst + (size_t)b * J.dst_rows * ldp;
     const int p = p0 + wn * 32 + li;
     const float alpha = J.alpha != 0.f ? J.alpha : 1.f;
+    const float* ob = J.out_bias;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mb * 64 + wm * 32 + acc_row(r) + 4 * h;
-            if (FAST || (m < M && p < P)) dst[(size_t)m * ldp + p] = acc[mb][r] * alpha;
+            if (FAST || (m < M && p < P)) dst[(size_t)m * ldp + p] = ob ? fmaf(acc[mb][r], alpha, ob[m]) : acc[mb][r] * alpha;
         }
     // Optional statistics epilogue (K6: the q / k projections feed a training-mode BatchNorm): the tile meets in LDS (the operand
     // ring is dead behind the loop's last barrier), four threads walk one row -- 16 values each, sums of (d - pivot) and
@@ -372,6 +373,27 @@ __global__ __launch_bounds__(256) void sd_reduce_kernel(const SdJobs jobs, const
     }
     for (; k < J.nsplit; ++k) s0 += p[(size_t)k * count];
     J.out[(size_t)(i / J.N) * J.ldo + J.col_off + (i % J.N)] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ d, int B, int C, int P, float* __restrict__ out) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* row = d + ((size_t)b * C + c) * P;
+        float sb = 0.f;
+        for (int p = threadIdx.x; p < P; p += 256) sb += row[p];
+        s += (double)sb;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+hipError_t channel_sum_run(const float* d, int B, int C, int P, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, stream, d, B, C, P, out);
+    return hipGetLastError();
 }
 
 // fills the launch geometry of every job; returns the slab floats needed

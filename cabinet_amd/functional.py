@@ -175,6 +175,22 @@ def cab_attention(q, k, v, scale, precision=None):
     return torch.bmm(v, attn.transpose(1, 2))
 
 
+def attn_proj_fwd_hip(q, k, v, w2, scale, need_ctx=True):
+    """q,k (B,Kc,n), v (B,Vc,n), w2 (Co,Vc) fp32 device tensors -> glob (B,Co,n), ctx (B,Vc,n) or None, lse (B,n): K1 with the output
+    projection in its epilogue (cabinet_cab_attn_proj_fwd)."""
+    lib = _lib.load()
+    B, Kc, n = q.shape
+    Vc, Co = v.shape[1], w2.shape[0]
+    ctx = torch.empty((B, Vc, n), dtype=torch.float32, device=q.device) if need_ctx else None
+    glob = torch.empty((B, Co, n), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B, n), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = lib.cabinet_cab_attn_proj_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(w2), float(scale), B, Kc, Vc, Co, n, _ptr(ctx),
+                                           _ptr(glob), _ptr(lse), _stream_handle(q.device))
+    _lib.check(rc, "cabinet_cab_attn_proj_fwd")
+    return glob, ctx, lse
+
+
 class _CabAttentionProj(torch.autograd.Function):
     """K1 with the CAB's output projection in its epilogue: ``project_out(attention(q, k, v))`` in ONE launch
     (cabinet_cab_attn_proj_fwd).  Backward = the projection's backward (cabinet_conv1x1_bwd: dctx, dw) + K2."""
@@ -182,19 +198,10 @@ class _CabAttentionProj(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(fn_ctx, q, k, v, w_out, scale):
-        lib = _lib.load()
         q, k, v = _f32c(q), _f32c(k), _f32c(v)
         w2 = _f32c(w_out.detach()).reshape(w_out.shape[0], -1)
-        B, Kc, n = q.shape
-        Vc, Co = v.shape[1], w2.shape[0]
         need_ctx = any(fn_ctx.needs_input_grad[:4])
-        ctx = torch.empty((B, Vc, n), dtype=torch.float32, device=q.device) if need_ctx else None
-        glob = torch.empty((B, Co, n), dtype=torch.float32, device=q.device)
-        lse = torch.empty((B, n), dtype=torch.float32, device=q.device)
-        with torch.cuda.device(q.device):
-            rc = lib.cabinet_cab_attn_proj_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(w2), float(scale), B, Kc, Vc, Co, n, _ptr(ctx),
-                                               _ptr(glob), _ptr(lse), _stream_handle(q.device))
-        _lib.check(rc, "cabinet_cab_attn_proj_fwd")
+        glob, ctx, lse = attn_proj_fwd_hip(q, k, v, w2, scale, need_ctx)
         if need_ctx:
             fn_ctx.save_for_backward(q, k, v, ctx, lse, w2)
         fn_ctx.scale, fn_ctx.w_shape = scale, w_out.shape
@@ -826,11 +833,68 @@ class _Conv1x1(torch.autograd.Function):
         return dx, (dw.view(fn_ctx.w_shape) if dw is not None else None)
 
 
-def conv1x1(x, weight):
-    """Bias-free 1x1 convolution of a (B,Ci,...) device tensor with a (Co,Ci[,1,1]) weight (reference cab.py:155)."""
+class _Conv1x1Bias(torch.autograd.Function):
+    """1x1 convolution WITH bias on the small-grid path (``AttentionBranch.convb``, reference cabinet.py:65-66, :86)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(fn_ctx, x, weight, bias):
+        lib = _lib.load()
+        x = _f32c(x)
+        Co, Ci = weight.shape[0], weight.shape[1]
+        w2 = _f32c(weight).view(Co, Ci)
+        B, P = x.shape[0], x[0, 0].numel()
+        y = torch.empty((B, Co) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        ws, nbytes = _workspace(lib.cabinet_conv1x1_fwd_workspace_bytes(Ci, Co), x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.cabinet_conv1x1_bias_fwd(_ptr(x), _ptr(w2), _ptr(_f32c(bias)), B, Ci, Co, P, _ptr(y), _ptr(ws), nbytes,
+                                              _stream_handle(x.device))
+        _lib.check(rc, "cabinet_conv1x1_bias_fwd")
+        fn_ctx.save_for_backward(x, w2)
+        fn_ctx.w_shape = weight.shape
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(fn_ctx, g):
+        lib = _lib.load()
+        x, w2 = fn_ctx.saved_tensors
+        g = _f32c(g)
+        Co, Ci = w2.shape
+        B, P = x.shape[0], x[0, 0].numel()
+        dx = torch.empty_like(x) if fn_ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w2) if fn_ctx.needs_input_grad[1] else None
+        db = torch.empty(Co, dtype=torch.float32, device=x.device) if fn_ctx.needs_input_grad[2] else None
+        ws, nbytes = _workspace(lib.cabinet_conv1x1_bwd_workspace_bytes(B, Ci, Co, P), x.device)
+        with torch.cuda.device(x.device):
+            if dx is not None or dw is not None:
+                rc = lib.cabinet_conv1x1_bwd(_ptr(g), _ptr(x), _ptr(w2), B, Ci, Co, P, _ptr(dx), _ptr(dw), _ptr(ws), nbytes,
+                                             _stream_handle(x.device))
+                _lib.check(rc, "cabinet_conv1x1_bwd")
+            if db is not None:
+                _lib.check(lib.cabinet_channel_sum(_ptr(g), B, Co, P, _ptr(db), _stream_handle(x.device)), "cabinet_channel_sum")
+        return dx, (dw.view(fn_ctx.w_shape) if dw is not None else None), db
+
+
+def conv1x1(x, weight, bias=None):
+    """1x1 convolution of a (B,Ci,...) device tensor with a (Co,Ci[,1,1]) weight (reference cab.py:155; with ``bias``:
+    cabinet.py:65-66, ``convb``).  The bias form exists on the small-grid path only (``conv1x1_bias_supported``)."""
     if not x.is_cuda:
         raise RuntimeError("conv1x1: device tensors only")
+    if bias is not None:
+        return _Conv1x1Bias.apply(x, weight, bias)
     return _Conv1x1.apply(x, weight)
+
+
+def conv1x1_bias_supported(x, conv):
+    """True when ``conv(x)`` -- a plain 1x1 nn.Conv2d with bias -- runs through the small-grid MFMA path (the CAB's resolution)."""
+    if not (x.is_cuda and x.dim() == 4 and conv.bias is not None and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == x.shape[1]):
+        return False
+    if conv.in_channels % 4 or conv.out_channels % 4:
+        return False
+    return bool(_lib.load().cabinet_conv1x1_bias_supported(int(x.shape[0]), int(conv.in_channels), int(conv.out_channels),
+                                                           int(x.shape[2] * x.shape[3])))
 
 
 # --------------------------------------------------------------------------- dense 3x3 convolution (K11, Winograd on the fp32 MFMA)

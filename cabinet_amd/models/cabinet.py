@@ -25,8 +25,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as _functional
-from ..functional import (batched_bn_counters, bn_act, bn_relu_cls, conv3x3, conv3x3_bn_part, conv3x3_supported, ffm_fused,
-                          ffm_fused_upsampled, stem_conv, stem_conv_supported)
+from ..functional import (batched_bn_counters, bn_act, bn_relu_cls, conv1x1, conv1x1_bias_supported, conv3x3, conv3x3_bn_part,
+                          conv3x3_supported, ffm_fused, ffm_fused_upsampled, stem_conv, stem_conv_supported)
 from .cab import ContextAggregationBlock
 from .constants import MODEL_CONFIG, MOBILENETV3_CFGS
 from .mobilenetv3 import MobileNetV3
@@ -111,7 +111,9 @@ class AttentionBranch(nn.Module):
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if x.is_cuda:
             feat = self.a2block(_conv3x3_bn_relu(self.conva[0], self.conva[1], x))
-            low_res_out = self.convb(feat)
+            # convb (1x1 with bias, cabinet.py:65-66): the small-grid MFMA product with the bias in its epilogue
+            low_res_out = conv1x1(feat, self.convb.weight, self.convb.bias) if conv1x1_bias_supported(feat, self.convb) \
+                else self.convb(feat)
             # K11 reads x and feat through two pointers: the (B, inplanes + 256, H', W') concat is never written
             # ... and K12 runs b2 -> b3 -> b4 as one operator: the ReLU output is never written
             return low_res_out, _conv3x3_bn_relu_cls(self.b1, self.b2, self.b4, x, feat)

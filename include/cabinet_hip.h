@@ -311,6 +311,14 @@ int cabinet_cab_qkv_bwd(const float* dq, const float* dk, const float* dv, const
 size_t cabinet_conv1x1_fwd_workspace_bytes(int Ci, int Co);
 int cabinet_conv1x1_fwd(const float* x, const float* w, int B, int Ci, int Co, int P, float* y,
                         void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+/* The same with an output bias (`AttentionBranch.convb`, src/models/cabinet.py:65-66, 86: a 1x1 convolution WITH bias on the CAB's
+ * output) on the small-grid path (cabinet_conv1x1_bias_supported: the CAB's resolution; larger planes use the stock operator).
+ * Backward: cabinet_conv1x1_bwd for dx / dw, cabinet_channel_sum(dy, B, Co, P, dbias) for the bias gradient
+ * (dbias[c] = sum over images and positions, one workgroup per channel, fixed order). */
+int cabinet_conv1x1_bias_supported(int B, int Ci, int Co, int P);
+int cabinet_conv1x1_bias_fwd(const float* x, const float* w, const float* bias /* (Co) */, int B, int Ci, int Co, int P, float* y,
+                             void* workspace, size_t workspace_bytes, cabinet_stream_t stream);
+int cabinet_channel_sum(const float* d /* (B,C,P) */, int B, int C, int P, float* out /* (C) */, cabinet_stream_t stream);
 size_t cabinet_conv1x1_bwd_workspace_bytes(int B, int Ci, int Co, int P);
 int cabinet_conv1x1_bwd(const float* dy, const float* x, const float* w, int B, int Ci, int Co, int P,
                         float* dx, float* dw, void* workspace, size_t workspace_bytes, cabinet_stream_t stream);

@@ -236,7 +236,8 @@ def test_reference_amp_gradscaler_clip_step():
             return real(*args, **kw)
         return real, wrapped
 
-    names = ["attn_fwd_hip", "attn_bwd_hip", "ffm_up_fwd_hip", "ffm_up_bwd_hip", "cab_local_fwd_hip", "cab_local_bwd_hip",
+    # (round 5: the model's CAB runs K1 with the output projection in its epilogue -- attn_proj_fwd_hip -- at this shape)
+    names = ["attn_proj_fwd_hip", "attn_bwd_hip", "ffm_up_fwd_hip", "ffm_up_bwd_hip", "cab_local_fwd_hip", "cab_local_bwd_hip",
              "ohem_up_pair_fwd_hip", "ohem_up_pair_bwd_hip"]
     results = {}
     for amp in (False, True):

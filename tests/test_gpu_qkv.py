@@ -119,6 +119,43 @@ def test_conv1x1_vs_oracle(B, Ci, Co, shape):
     assert_close(wd.grad, wo.grad, TOL, "dw")
 
 
+@pytest.mark.parametrize("B,Ci,Co,shape", [(8, 256, 256, (32, 32)), (2, 256, 256, (64, 32)), (1, 48, 16, (5, 7)), (2, 24, 72, (16, 16))])
+def test_conv1x1_with_bias_vs_fp64(B, Ci, Co, shape):
+    """`AttentionBranch.convb` (reference cabinet.py:65-66, :86: nn.Conv2d(256, 256, 1, bias=True) on the CAB's output): the small-grid MFMA
+    product with the bias in its epilogue, dx / dw by cabinet_conv1x1_bwd, dbias by cabinet_channel_sum -- against F.conv2d in fp64;
+    the first two shapes are the config-3 and config-5 grids; bit-reproducible."""
+    import torch.nn as nn
+
+    from cabinet_amd.functional import conv1x1, conv1x1_bias_supported
+
+    g0 = torch.Generator().manual_seed(6)
+    conv = nn.Conv2d(Ci, Co, 1, bias=True)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(Co, generator=g0))
+    x = torch.randn(B, Ci, *shape, generator=g0)
+    g = torch.randn(B, Co, *shape, generator=g0)
+    xo = x.double().requires_grad_(True)
+    wo, bo = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    yo = F.conv2d(xo, wo, bo)
+    yo.backward(g.double())
+    conv = conv.cuda()
+    xd = x.cuda().requires_grad_(True)
+    assert conv1x1_bias_supported(xd, conv)
+    y = conv1x1(xd, conv.weight, conv.bias)
+    y.backward(g.cuda())
+    assert_close(y, yo, 2e-5, "y")
+    assert_close(xd.grad, xo.grad, 2e-5, "dx")
+    assert_close(conv.weight.grad, wo.grad, 2e-5, "dw")
+    assert_close(conv.bias.grad, bo.grad, 2e-5, "dbias")
+    dx1, dw1, db1 = xd.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()
+    xd.grad = conv.weight.grad = conv.bias.grad = None
+    y2 = conv1x1(xd, conv.weight, conv.bias)
+    y2.backward(g.cuda())
+    assert torch.equal(y2, y) and torch.equal(xd.grad, dx1) and torch.equal(conv.weight.grad, dw1) and torch.equal(conv.bias.grad, db1)
+    big = torch.randn(8, 256, 128, 128, device="cuda")   # a large plane: the bias form does not exist there, the model keeps the stock operator
+    assert not conv1x1_bias_supported(big, nn.Conv2d(256, 256, 1).cuda())
+
+
 def test_global_branch_runs_native_kernels_and_is_deterministic():
     from cabinet_amd import _lib
 
