@@ -27,7 +27,10 @@ hipError_t bn_stats_run(const float* x, float* running_mean, float* running_var,
 size_t bn_act_workspace(int B, int C, int P);
 
 constexpr int BC_X = 8;          // table row = KT weights + [mean, invstd, gamma, beta, gamma * invstd, 0, 0, 0]
-constexpr int BC_TPW = 4096;     // positions one wave of the reduce kernel sweeps (64 lanes x 4 x 16)
+#ifndef BC_TPW_VALUE
+#define BC_TPW_VALUE 2048
+#endif
+constexpr int BC_TPW = BC_TPW_VALUE;   // positions one wave of the reduce kernel sweeps (64 lanes x 4 per step)
 
 static inline int bc_kt(int K) { return K <= 8 ? 8 : (K <= 20 ? 20 : 32); }
 
@@ -173,24 +176,37 @@ __global__ __launch_bounds__(256) void bn_cls_reduce_kernel(const float* __restr
 }
 
 // ---- backward, finalize: block c < C: ordered sums of channel c's partials (double) -> dgamma, dbeta, batch means, dw[:, c];
-//      block C: dbias ----
-__global__ __launch_bounds__(64) void bn_cls_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int ntiles,
-                                                              int C, int K, int KT, double count, int training,
-                                                              float* __restrict__ dbn_w, float* __restrict__ dbn_b,
-                                                              float* __restrict__ dw_cls, float* __restrict__ dbias,
-                                                              float* __restrict__ coef) {
-    const int c = blockIdx.x, v = threadIdx.x, NV = KT + 2;
-    if (c == C) {
-        if (v < K && dbias != nullptr) {
-            double s = 0.0;
-            for (int t = 0; t < ntiles; ++t) s += (double)bpart[(size_t)t * KT + v];
-            dbias[v] = (float)s;
+//      block C: dbias.  256 threads: lane v of wave q adds the tiles q, q + 4, ... of value v (four loads in flight), the four wave
+//      sums are added in a fixed order ----
+__global__ __launch_bounds__(256) void bn_cls_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ bpart, int ntiles,
+                                                               int C, int K, int KT, double count, int training,
+                                                               float* __restrict__ dbn_w, float* __restrict__ dbn_b,
+                                                               float* __restrict__ dw_cls, float* __restrict__ dbias,
+                                                               float* __restrict__ coef) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x, v = threadIdx.x & 63, q = threadIdx.x >> 6, NV = KT + 2;
+    const bool bias_blk = c == C;
+    const int nv = bias_blk ? K : NV;
+    double s = 0.0;
+    if (v < nv) {
+        const float* src = bias_blk ? bpart + v : part + (size_t)c * ntiles * NV + v;
+        const size_t stride = bias_blk ? (size_t)KT : (size_t)NV;
+        int t = q;
+        for (; t + 12 < ntiles; t += 16) {
+            const float x0 = src[(size_t)t * stride], x1 = src[(size_t)(t + 4) * stride], x2 = src[(size_t)(t + 8) * stride],
+                        x3 = src[(size_t)(t + 12) * stride];
+            s += (double)x0, s += (double)x1, s += (double)x2, s += (double)x3;
         }
+        for (; t < ntiles; t += 4) s += (double)src[(size_t)t * stride];
+    }
+    red[q][v] = s;
+    __syncthreads();
+    if (q != 0 || v >= nv) return;
+    s = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
+    if (bias_blk) {
+        if (dbias != nullptr) dbias[v] = (float)s;
         return;
     }
-    if (v >= NV) return;
-    double s = 0.0;
-    for (int t = 0; t < ntiles; ++t) s += (double)part[((size_t)c * ntiles + t) * NV + v];
     if (v < KT) {
         if (v < K) dw_cls[(size_t)v * C + c] = (float)s;
     } else if (v == KT) {
@@ -284,7 +300,7 @@ hipError_t bn_cls_bwd_run(const float* dy, const float* z, const float* tab, int
         case 20: hipLaunchKernelGGL((bn_cls_reduce_kernel<20, 4>), dim3(ntiles, ceil_div(C, 16)), block, 0, stream, dy, z, tab, C, P, K, tiles_img, part, bpart); break;
         default: hipLaunchKernelGGL((bn_cls_reduce_kernel<32, 2>), dim3(ntiles, ceil_div(C, 8)), block, 0, stream, dy, z, tab, C, P, K, tiles_img, part, bpart); break;
     }
-    hipLaunchKernelGGL(bn_cls_bwd_final_kernel, dim3(C + 1), dim3(64), 0, stream, part, bpart, ntiles, C, K, KT, (double)B * (double)P, training,
+    hipLaunchKernelGGL(bn_cls_bwd_final_kernel, dim3(C + 1), dim3(256), 0, stream, part, bpart, ntiles, C, K, KT, (double)B * (double)P, training,
                        dbn_w, dbn_b, dw_cls, dbias, coef);
     const dim3 grid(B * tiles);
     switch (KT) {

@@ -612,6 +612,193 @@ __global__ __launch_bounds__(256) void ohem_up_bwd_x8row_kernel(OhemBwdHeads hd,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5 (second half): the same x pass WITHOUT the intermediate T (opt-in: see ohem_up_bwd_run for what it measured).  T (B x C x H x Wl per head: 67 MB for both
+// heads at config 3) was written by the row kernel and read back by the y pass -- 134 of the backward's 293 MB.  The y adjoint of
+// an x8 resize is local: the eight output rows 8k+4 .. 8k+11 (a BAND) lerp the same two source rows k and k+1, so a workgroup that
+// walks a band row by row can keep  sum (1 - ly) T_row  (for source row k) and  sum ly T_row  (for k+1) in registers -- a lane's
+// IPL columns of the wave's classes -- and write them once: P0[k] and P1[k+1].  Every source row then gets exactly two addends,
+// dlow[ys] = P1[ys] + P0[ys] (ohem_up_bwd_comb_kernel: 8 MB in, 4 MB out), bands -1 (rows 0..3, all weight on source row 0) and
+// Hl-1 (rows H-4..H-1, all weight on the last row) included: fixed order, no atomics.  The two source rows are loaded ONCE per band
+// (the row kernel fetched them once per output row) and re-lerped per row with the forward's own expression, so lse = loss +
+// x_label still reconstructs the forward's log-sum-exp bit for bit.  Phases 1 and 2 are the row kernel's, per row.
+template <int IPL>
+__global__ __launch_bounds__(256) void ohem_up_bwd_x8band_kernel(OhemBwdHeads hd, const long long* __restrict__ labels, int NH,
+                                                                 int B, int C, int Hl, int H, float rh, float thresh,
+                                                                 int ignore_lb, float coef) {
+    constexpr int Wl = 64 * IPL, W = 8 * Wl, NCI = 8;   // NCI: classes per wave (C <= 32)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CW = C * Wl;
+    float* a0 = smem;                // [C][Wl]  source row k   (raw logits)
+    float* a1 = a0 + CW;             // [C][Wl]  source row k+1
+    float* v = a1 + CW;              // [C][Wl]  vertically interpolated logits of the current output row, exp2 domain
+    float* lse = v + CW;             // [2 IPL][64][4]
+    float* ohL = lse + W;            // [C][Wl]
+    float* ohM = ohL + CW;
+    float* ohR = ohM + CW;
+    const int nb = Hl + 1, items = nb * B, per_xcd = (items + 7) >> 3;
+    const int slot = blockIdx.x >> 3, head = slot % NH, item = (blockIdx.x & 7) * per_xcd + slot / NH;
+    if (item >= items) return;
+    const int k = item % nb - 1, b = item / nb, tid = threadIdx.x;
+    const float* __restrict__ low = hd.low[head];
+    const float* __restrict__ loss_px = hd.loss_px[head];
+    float* __restrict__ P = hd.T[head];   // [2][B][C][Hl][Wl]
+    const size_t plane = (size_t)Hl * Wl, half = (size_t)B * C * plane;
+    const int oy_lo = max(8 * k + 4, 0), oy_hi = min(8 * k + 12, H);
+    int ya, yb;   // the two source rows every output row of the band interpolates (the taps of its first row)
+    {
+        float l0;
+        bilinear_taps(oy_lo, rh, Hl, ya, yb, l0);
+    }
+    {
+        const float* low_b = low + (size_t)b * C * plane;
+        const int q4 = CW >> 2;
+        for (int i = tid; i < q4; i += 256) {
+            const int c = (4 * i) / Wl, xs = 4 * i - c * Wl;
+            const float* p = low_b + (size_t)c * plane + xs;
+            *reinterpret_cast<f32x4*>(a0 + 4 * i) = *reinterpret_cast<const f32x4*>(p + ya * Wl);
+            *reinterpret_cast<f32x4*>(a1 + 4 * i) = *reinterpret_cast<const f32x4*>(p + yb * Wl);
+        }
+    }
+    const int wave = tid >> 6, lane = tid & 63, g0 = lane * IPL;
+    float accA[NCI][IPL], accB[NCI][IPL];
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+        for (int u = 0; u < IPL; ++u) accA[ci][u] = 0.f, accB[ci][u] = 0.f;
+    __syncthreads();
+    for (int oy = oy_lo; oy < oy_hi; ++oy) {
+        int y0, y1;
+        float ly;
+        bilinear_taps(oy, rh, Hl, y0, y1, ly);   // the forward's weights; (y0, y1) == (ya, yb) for every row of the band
+        const float dd = (float)(oy - (8 * k + 4));
+        const float wb = k < 0 ? 1.f : (dd + 0.5f) * 0.125f;                               // the y pass's closed-form triangle,
+        const float wa = k == Hl - 1 ? 1.f : 1.f - (dd + 0.5f) * 0.125f;                   // weight 1 where the clamp folds the window
+        for (int i = tid; i < (CW >> 2); i += 256) {
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(a0 + 4 * i), r1 = *reinterpret_cast<const f32x4*>(a1 + 4 * i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ((1.f - ly) * r0[e] + ly * r1[e]) * LOG2E_F;
+            *reinterpret_cast<f32x4*>(v + 4 * i) = o;
+        }
+        __syncthreads();
+        // ---- phase 1 (the row kernel's): one thread per source interval g: lse and the one-hot sums
+        for (int g = tid; g < Wl; g += 256) {
+            const size_t pix = ((size_t)b * H + oy) * W + 8 * g;
+            long long lb[8];
+            float ls[8];
+            {
+                const longlong2* lp = reinterpret_cast<const longlong2*>(labels + pix);
+                const f32x4* sp = reinterpret_cast<const f32x4*>(loss_px + pix);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const longlong2 t = lp[u];
+                    lb[2 * u] = t.x, lb[2 * u + 1] = t.y;
+                }
+                const f32x4 s0 = sp[0], s1 = sp[1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ls[e] = s0[e], ls[4 + e] = s1[e];
+            }
+            for (int c = 0; c < C; ++c) ohL[c * Wl + g] = 0.f, ohM[c * Wl + g] = 0.f, ohR[c * Wl + g] = 0.f;
+            const int gm = max(g - 1, 0), gp = min(g + 1, Wl - 1);
+            float out[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lam = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+                const float t = j < 4 ? -(1.f - lam) : lam;
+                const bool sel = lb[j] != (long long)ignore_lb && ls[j] > thresh;
+                const bool inrange = lb[j] >= 0 && lb[j] < (long long)C;
+                const int lrow = inrange ? (int)lb[j] * Wl : 0;
+                const float* vl = v + lrow;
+                const float xl = j < 4 ? fmaf(t, vl[g] - vl[gm], vl[g]) : fmaf(t, vl[gp] - vl[g], vl[g]);
+                out[j] = sel ? fmaf(ls[j], LOG2E_F, xl) : INFINITY;
+                if (sel && inrange) {
+                    if (j < 4) {
+                        ohL[lrow + g] += 1.f - lam;
+                        ohM[lrow + g] += lam;
+                    } else {
+                        ohM[lrow + g] += 1.f - lam;
+                        ohR[lrow + g] += lam;
+                    }
+                }
+            }
+            const int gl = g / IPL, gu = g - gl * IPL;
+            *reinterpret_cast<f32x4*>(lse + ((2 * gu) * 64 + gl) * 4) = f32x4{out[0], out[1], out[2], out[3]};
+            *reinterpret_cast<f32x4*>(lse + ((2 * gu + 1) * 64 + gl) * 4) = f32x4{out[4], out[5], out[6], out[7]};
+        }
+        __syncthreads();
+        // ---- phase 2 (the row kernel's): a wave per class row, a lane per IPL consecutive intervals; T stays in registers
+        float lr[8 * IPL];
+#pragma unroll
+        for (int u = 0; u < 2 * IPL; ++u) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(lse + (u * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lr[4 * u + e] = t[e];
+        }
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci) {
+            const int c = wave + 4 * ci;
+            if (c < C) {
+                const float* vc = v + c * Wl;
+                float Lg[IPL], Mg[IPL], Rg[IPL];
+#pragma unroll
+                for (int u = 0; u < IPL; ++u) {
+                    const int g = g0 + u;
+                    const float xc = vc[g], dm = xc - vc[max(g - 1, 0)], dp = vc[min(g + 1, Wl - 1)] - xc;
+                    float L = 0.f, M = 0.f, R = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float lam = j < 4 ? ((float)j + 4.5f) * 0.125f : ((float)j - 3.5f) * 0.125f;
+                        const float e = fast_exp2(fmaf(j < 4 ? -(1.f - lam) : lam, j < 4 ? dm : dp, xc) - lr[8 * u + j]);
+                        if (j < 4) {
+                            L = fmaf(1.f - lam, e, L);
+                            M = fmaf(lam, e, M);
+                        } else {
+                            M = fmaf(1.f - lam, e, M);
+                            R = fmaf(lam, e, R);
+                        }
+                    }
+                    Lg[u] = coef * (L - ohL[c * Wl + g]);
+                    Mg[u] = coef * (M - ohM[c * Wl + g]);
+                    Rg[u] = coef * (R - ohR[c * Wl + g]);
+                }
+                float rprev = __shfl_up(Rg[IPL - 1], 1, 64), lnext = __shfl_down(Lg[0], 1, 64);
+                if (lane == 0) rprev = Lg[0];
+                if (lane == 63) lnext = Rg[IPL - 1];
+#pragma unroll
+                for (int u = 0; u < IPL; ++u) {
+                    const float o = ((u > 0 ? Rg[u - 1] : rprev) + Mg[u]) + (u + 1 < IPL ? Lg[u + 1] : lnext);
+                    accA[ci][u] = fmaf(wa, o, accA[ci][u]);
+                    accB[ci][u] = fmaf(wb, o, accB[ci][u]);
+                }
+            }
+        }
+        __syncthreads();   // the next row overwrites v, lse and the one-hot sums
+    }
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci) {
+        const int c = wave + 4 * ci;
+        if (c < C) {
+#pragma unroll
+            for (int u = 0; u < IPL; ++u) {
+                if (k >= 0) P[(((size_t)b * C + c) * Hl + k) * Wl + g0 + u] = accA[ci][u];
+                if (k + 1 < Hl) P[half + (((size_t)b * C + c) * Hl + k + 1) * Wl + g0 + u] = accB[ci][u];
+            }
+        }
+    }
+}
+
+// dlow[i] = P1[i] + P0[i]: the contribution of the band above a source row, then of the band below (ascending output rows)
+__global__ __launch_bounds__(256) void ohem_up_bwd_comb_kernel(OhemBwdHeads hd, int NH, size_t half4, float* __restrict__ dlow) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= half4 * NH) return;
+    const int head = (int)(i / half4);
+    const size_t j = i - (size_t)head * half4;
+    const f32x4* P = reinterpret_cast<const f32x4*>(hd.T[head]);
+    const f32x4 p0 = P[j], p1 = P[half4 + j];
+    reinterpret_cast<f32x4*>(dlow)[i] = f32x4{p1[0] + p0[0], p1[1] + p0[1], p1[2] + p0[2], p1[3] + p0[3]};
+}
+
 // dlow[b][c][ys][xs] = sum_oy wy(oy, ys) * T[b][c][oy][xs]
 __global__ __launch_bounds__(256) void ohem_up_bwd_y_kernel(const float* __restrict__ T, int planes, int Hl, int Wl, int H,
                                                              float rh, int fastR, float* __restrict__ dlow) {
@@ -773,6 +960,33 @@ hipError_t ohem_up_bwd_run(int nh, const float* const* low, const long long* lab
     for (int i = 0; i < nh; ++i)
         aligned = aligned && ((reinterpret_cast<uintptr_t>(low[i]) | reinterpret_cast<uintptr_t>(loss_px[i]) |
                                reinterpret_cast<uintptr_t>(hd.T[i])) & 15) == 0;
+    // round 5: bands of eight output rows, no T (see ohem_up_bwd_x8band_kernel) -- measured and NOT the default: 76 + 6 us against
+    // 58 + 13 us for the row kernel + y pass at config 3 (profiles/r05_ohem_band_ab.txt).  The band kernel moves 134 MB less, but a
+    // band is eight rows walked one after the other behind three barriers each, in an eighth of the workgroups: the backward is
+    // bound by the latency of its dependent phases (label / loss loads -> lse -> exp chain), and 16384 row workgroups hide that
+    // better than 2064 band workgroups.  CABINET_OHEM_BAND=1 selects it (A/B timing, test_band_kernel_equals_row_kernel_plus_y_pass).
+    const size_t lds_band = ((size_t)6 * C * Wl + (size_t)W) * sizeof(float);
+    static const auto band_enabled = [] { const char* e = getenv("CABINET_OHEM_BAND"); return e && e[0] == '1'; };
+    if ((ipl == 1 || ipl == 2 || ipl == 4) && aligned && lds_band <= 64 * 1024 && H == 8 * Hl && C <= 32 && os_row_kernel_enabled() &&
+        band_enabled() && (reinterpret_cast<uintptr_t>(dlow) & 15) == 0) {
+        const int bgrid = 8 * nh * ceil_div((Hl + 1) * B, 8);
+        static lds_attr_mask b1{0}, b2{0}, b4{0};
+#define OHEM_BAND(I, M)                                                                                                  \
+        do {                                                                                                             \
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(ohem_up_bwd_x8band_kernel<I>), 64 * 1024, M); \
+                e != hipSuccess)                                                                                         \
+                return e;                                                                                                \
+            hipLaunchKernelGGL((ohem_up_bwd_x8band_kernel<I>), dim3(bgrid), dim3(256), lds_band, stream, hd, labels, nh, B, C, Hl, \
+                               H, (float)Hl / (float)H, thresh, ignore_lb, coef);                                        \
+        } while (0)
+        if (ipl == 1) OHEM_BAND(1, b1);
+        else if (ipl == 2) OHEM_BAND(2, b2);
+        else OHEM_BAND(4, b4);
+#undef OHEM_BAND
+        const size_t half4 = (size_t)B * C * Hl * Wl / 4;
+        hipLaunchKernelGGL(ohem_up_bwd_comb_kernel, dim3((unsigned)((half4 * nh + 255) / 256)), dim3(256), 0, stream, hd, nh, half4, dlow);
+        return hipGetLastError();
+    }
     if ((ipl == 1 || ipl == 2 || ipl == 4) && aligned && lds_row <= 64 * 1024 && os_row_kernel_enabled()) {
         const int rgrid = 8 * nh * ceil_div(H * B, 8);
         static lds_attr_mask m1{0}, m2{0}, m4{0};

@@ -120,6 +120,38 @@ def test_row_kernel_equals_segment_kernel():
         assert torch.equal(new, Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37))  # bit-reproducible
 
 
+def test_band_kernel_equals_row_kernel_plus_y_pass():
+    """Round 5: the backward WITHOUT the intermediate T (bands of eight output rows keep the y adjoint in registers, two addends per
+    source row; opt-in through CABINET_OHEM_BAND=1 -- it measured slower, see ohem.hip) against the default row kernel + y pass: pair and single head, ignored pixels,
+    the three lane widths, Hl = 1 (both edge bands touch the only source row), the config-3 and config-5 head grids; the two
+    summation orders differ in the last bit, nothing more; bit-reproducible."""
+    import os
+
+    from cabinet_amd import functional as Fn
+
+    for B, C, Hl, Wl in [(2, 8, 8, 128), (1, 19, 4, 64), (1, 3, 2, 256), (2, 8, 1, 64), (8, 8, 128, 128), (2, 19, 256, 128)]:
+        H, W = 8 * Hl, 8 * Wl
+        g = torch.Generator().manual_seed(C + Wl + Hl)
+        la = (torch.randn(B, C, Hl, Wl, generator=g) * 2).cuda()
+        lb_ = (torch.randn(B, C, Hl, Wl, generator=g) * 2).cuda()
+        lab = torch.randint(0, C, (B, H, W), generator=g)
+        lab[torch.rand(B, H, W, generator=g) < 0.1] = 255
+        lab = lab.cuda()
+        loss_px, _ = Fn.ohem_up_pair_fwd_hip(la, lb_, lab, (H, W), 0.7, 255)
+        old = Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37)   # default: row kernel + y pass
+        os.environ["CABINET_OHEM_BAND"] = "1"
+        try:
+            new = Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37)
+            again = Fn.ohem_up_pair_bwd_hip(la, lb_, lab, loss_px, (H, W), 0.7, 255, 0.37)
+            single = Fn.ohem_up_bwd_hip(la, lab, loss_px[0], (H, W), 0.7, 255, 0.37)
+        finally:
+            del os.environ["CABINET_OHEM_BAND"]
+        torch.cuda.synchronize()
+        assert_close(new, old, 1e-6, f"dlow {B}x{C}x{Hl}x{Wl}", atol=1e-9)
+        assert torch.equal(new, again)            # bit-reproducible
+        assert torch.equal(single, new[0])        # one head: the same bits
+
+
 def test_fused_ohem_is_deterministic_and_scales_with_upstream_grad():
     from cabinet_amd.loss import OhemCELoss
 
