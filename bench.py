@@ -633,6 +633,12 @@ def main():
                                                                               "algorithmic_gflop", "algorithmic_mbytes")},
                                   longest_kernel_group=dom["kernel"], longest_kernel_frac=dom["frac"],
                                   longest_kernel_scope=dom["scope"])
+        # round 5: where the forward needs no key split the model's CAB runs K1 with the output projection in its epilogue; that
+        # instantiation's own entry (its FLOPs include the projection's 2 B n Vc Co) travels next to the plain kernel's
+        kp = [r for r in ks if r["kernel"].startswith("cab_attn_proj_fwd")]
+        if kp:
+            result["roofline"]["as_run_in_the_step"] = {k: kp[0][k] for k in ("kernel", "ms_per_launch", "bound", "achieved", "peak",
+                                                                             "unit", "frac", "traffic", "algorithmic_gflop")}
     if ddp:
         torch.distributed.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
