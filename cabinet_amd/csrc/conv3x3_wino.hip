@@ -132,6 +132,13 @@ __device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_byt
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
 }
 
+// PAIR (W even): the 4x4 patch of a lane is assembled from ONE 8-byte load per row (columns 2 tx, 2 tx + 1: the tile's own two
+// columns) and its neighbours' registers -- column 2 tx - 1 is the left neighbour's second value, column 2 tx + 2 the right
+// neighbour's first (DPP row_shr:1 / row_shl:1: a DPP row of 16 lanes IS one tile row of the block and one channel) -- plus one
+// dword per row that only the row's first and last lane use (the halo columns 32 bx - 1 and 32 bx + 32; every other lane's offset
+// is out of range: no memory request).  8 vector-memory instructions per chunk and thread instead of 16 dword gathers; zero padding
+// still costs nothing (a tile right of the image loads zeros, and that is exactly what its left neighbour needs in column W).
+template <bool PAIR>
 __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -153,27 +160,66 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     // (>= every image tensor, which conv3x3_shape_ok keeps below 1 GB) instead of a clamped address and a select behind the load
     // (round 5's first version: 16 v_cndmask per chunk and thread).
     const int ty = 2 * by + (li >> 4), tx = 16 * bx + (li & 15);
-    int poff[16];
+    int poff[PAIR ? 5 : 16];   // PAIR: [row] pair offset, [4] halo offset
+    if constexpr (PAIR) {
+        // ONE halo load per chunk: lane t = 0..3 of a tile row fetches the LEFT halo (column 32 bx - 1) of patch row t, lane 12 + t the
+        // RIGHT halo (column 32 bx + 32) of patch row t; a quad broadcast (DPP quad_perm [t,t,t,t]) then hands row t's halo to the
+        // row's first lane (from its own quad) and to its last lane (from the last quad) in one move
+        const int t = li & 15, hr = t & 3, r = 2 * ty - 1 + hr;
+        const int hc = t < 4 ? 32 * bx - 1 : (t >= 12 ? 32 * bx + 32 : -1);
+        poff[4] = ((unsigned)r < (unsigned)a.H && (unsigned)hc < (unsigned)a.W) ? ((2 * wave + h) * HW + r * a.W + hc) * 4 : WN_OOB;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 2 * ty - 1 + i;
+        if constexpr (PAIR) {
+            const bool rin = (unsigned)r < (unsigned)a.H;
+            const int base = ((2 * wave + h) * HW + r * a.W) * 4;
+            poff[i] = (rin && 2 * tx < a.W) ? base + 2 * tx * 4 : WN_OOB;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 2 * tx - 1 + j;
-            poff[4 * i + j] = ((unsigned)r < (unsigned)a.H && (unsigned)c < (unsigned)a.W) ? ((2 * wave + h) * HW + r * a.W + c) * 4 : WN_OOB;
+            for (int j = 0; j < 4; ++j) {
+                const int c = 2 * tx - 1 + j;
+                poff[4 * i + j] = ((unsigned)r < (unsigned)a.H && (unsigned)c < (unsigned)a.W) ? ((2 * wave + h) * HW + r * a.W + c) * 4 : WN_OOB;
+            }
         }
     }
     const buf_rsrc rx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)((size_t)a.C0 * HW * 4));
     const buf_rsrc rx1 = make_rsrc(a.x1 ? a.x1 + (size_t)b * a.C1 * HW : a.x0, (unsigned)((size_t)(a.x1 ? a.C1 : a.C0) * HW * 4));
-    float pd[16];
+    float pd[16];   // PAIR: pd[4 i + 1], pd[4 i + 2] = the pair of row i, pd[0] = this lane's halo value; the rest is filled by patch_ready()
     auto load_patch = [&](int n) {   // chunk n -> pd, zero padding included
         const bool first = n < nch0;   // wave-uniform
         const int soff = (first ? n : n - nch0) * WN_CC * HW * 4;
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) pd[e] = bload(first ? rx0 : rx1, poff[e], soff);
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 pr = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(first ? rx0 : rx1, poff[i], soff, 0));
+                pd[4 * i + 1] = pr[0], pd[4 * i + 2] = pr[1];
+            }
+            pd[0] = bload(first ? rx0 : rx1, poff[4], soff);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pd[e] = bload(first ? rx0 : rx1, poff[e], soff);
+        }
+    };
+    // PAIR: columns 2 tx - 1 and 2 tx + 2 from the neighbours (the row's first / last lane keeps its halo value: bound_ctrl off)
+    auto patch_ready = [&]() {
+        if constexpr (PAIR) {
+            const int hv = __builtin_bit_cast(int, pd[0]);
+            const int hq[4] = {__builtin_amdgcn_update_dpp(0, hv, 0x00, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0x55, 0xF, 0xF, true),
+                               __builtin_amdgcn_update_dpp(0, hv, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0xFF, 0xF, 0xF, true)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int halo = hq[i];   // quad_perm [i,i,i,i]: row i's halo, in the row's first quad the left one, in its last the right one
+                const int left = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, pd[4 * i + 2]), 0x111, 0xF, 0xF, false);   // row_shr:1
+                const int right = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, pd[4 * i + 1]), 0x101, 0xF, 0xF, false);  // row_shl:1
+                pd[4 * i] = __builtin_bit_cast(float, left), pd[4 * i + 3] = __builtin_bit_cast(float, right);
+            }
+        }
     };
     auto transform_store = [&](int buf) {
         float v[16];
+        patch_ready();
         wino_bt_d_b(pd, v);
         float* dst = smem + buf * WN_VBUF + (2 * wave + h) * WN_TB + li;
 #pragma unroll
@@ -268,10 +314,11 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         WN_T(1);
         // ---- Q1
+        patch_ready();
         wino_bt_d_b(pd, vout);
         load_patch(n2);
         mfma_quarter(ucur, bva, 0, 2);
-        WN_PIN(8, 0x002, 4)    // 32 additions
+        WN_PIN(8, 0x002, PAIR ? 6 : 4)    // 32 additions (+ 12 DPP moves)
         __builtin_amdgcn_sched_barrier(0);
         WN_T(2);
         // ---- Q2
@@ -457,21 +504,41 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     f32x2 pg[2];
     // zero padding and masked tiles through the buffer range check (see wino_conv_kernel): a tap outside the image -- row term in the
     // scalar offset, column term in the per-lane offset -- is WN_OOB away and loads as 0; no clamps, no selects
+    // EVEN_W: the x patch as one 8-byte load per row (the tile's own two columns) + one halo dword that only the first / last tile of
+    // the 8-tile chunk uses; columns 2 tx - 1 and 2 tx + 2 come from the neighbour lanes (patch_ready: DPP row_shr:1 / row_shl:1, the
+    // halo selected at the chunk's ends -- a DPP row holds two channels' tile groups) -- see wino_conv_kernel<PAIR>
     auto load_chunk = [&](const Pos& p) {
         const int tx = 8 * p.cx + tt;
         const buf_rsrc rx = make_rsrc(xsrc + (size_t)p.b * Cx * HW, (unsigned)((size_t)Cx * HW * 4));
-        int cof[4];
+        if constexpr (EVEN_W) {
+            const int cpair = 2 * tx < a.W ? (2 * tx + (cfirst + ch) * HW) * 4 : WN_OOB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = 2 * tx - 1 + j;
-            cof[j] = (unsigned)c < (unsigned)a.W ? (c + (cfirst + ch) * HW) * 4 : WN_OOB;
-        }
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * p.ty - 1 + i;
+                const int so = (unsigned)r < (unsigned)a.H ? r * a.W * 4 : WN_OOB;
+                const f32x2 pr = bload2(rx, cpair, so);
+                px[4 * i + 1] = pr[0], px[4 * i + 2] = pr[1];
+            }
+            {   // ONE halo load: tile lane tt = 0..3 fetches the LEFT halo (column 16 cx - 1) of patch row tt, lane 4 + t the RIGHT halo
+                // (column 16 cx + 16) of row t; quad broadcasts hand them to the chunk's first / last tile (see wino_conv_kernel<PAIR>)
+                const int hr = tt & 3, r = 2 * p.ty - 1 + hr, hc = tt < 4 ? 16 * p.cx - 1 : 16 * p.cx + 16;
+                const int off = ((unsigned)r < (unsigned)a.H && (unsigned)hc < (unsigned)a.W) ? (hc + (cfirst + ch) * HW + r * a.W) * 4 : WN_OOB;
+                px[0] = bload(rx, off, 0);
+            }
+        } else {
+            int cof[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 2 * p.ty - 1 + i;
-            const int so = (unsigned)r < (unsigned)a.H ? r * a.W * 4 : WN_OOB;
+            for (int j = 0; j < 4; ++j) {
+                const int c = 2 * tx - 1 + j;
+                cof[j] = (unsigned)c < (unsigned)a.W ? (c + (cfirst + ch) * HW) * 4 : WN_OOB;
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) px[4 * i + j] = bload(rx, cof[j], so);
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * p.ty - 1 + i;
+                const int so = (unsigned)r < (unsigned)a.H ? r * a.W * 4 : WN_OOB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) px[4 * i + j] = bload(rx, cof[j], so);
+            }
         }
         // dy tile: rows 2 ty, 2 ty + 1, columns 2 tx, 2 tx + 1
         const buf_rsrc rg = make_rsrc(a.dy + (size_t)p.b * a.K * HW, (unsigned)((size_t)a.K * HW * 4));
@@ -505,6 +572,19 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
         }
     };
     auto stage_a = [&]() {
+        if constexpr (EVEN_W) {   // patch columns 2 tx - 1 and 2 tx + 2 from the neighbours (the halo at the chunk's ends)
+            const int hv = __builtin_bit_cast(int, px[0]);
+            const int hq[4] = {__builtin_amdgcn_update_dpp(0, hv, 0x00, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0x55, 0xF, 0xF, true),
+                               __builtin_amdgcn_update_dpp(0, hv, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0xFF, 0xF, 0xF, true)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int halo = hq[i];   // quad_perm [i,i,i,i]: in the chunk's first quad the left halo of row i, in its second the right one
+                const int left = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, px[4 * i + 2]), 0x111, 0xF, 0xF, false);   // row_shr:1
+                const int right = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, px[4 * i + 1]), 0x101, 0xF, 0xF, false);  // row_shl:1
+                px[4 * i] = __builtin_bit_cast(float, tt == 0 ? halo : left);
+                px[4 * i + 3] = __builtin_bit_cast(float, tt == 7 ? halo : right);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             tsel[j] = px[j] - px[8 + j], tsel[4 + j] = px[4 + j] + px[8 + j];
@@ -595,7 +675,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
         load_chunk(p_ld);
         mfma_step(o1);
         WG_PIN(4, 0x100, 1)
-        WG_PIN(4, 0x002, 6)
+        WG_PIN(4, 0x002, EVEN_W ? 11 : 6)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q2
         read_ops(o1, buf, 3);
@@ -698,9 +778,17 @@ static hipError_t wino_conv_run(const float* x0, const float* x1, const float* u
     a.nby = (wn_th(H) + 1) / 2, a.nbx = (wn_th(W) + 15) / 16, a.ntb = B * a.nby * a.nbx, a.nkb = K / WN_KB;
     a.accumulate = accumulate;
     const size_t lds = (size_t)16 * WN_KB * WN_TB * sizeof(float);   // 128 KB (the epilogue's planes; the V ring needs 64 KB)
-    static lds_attr_mask mask{0};
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel), 160 * 1024, mask); e != hipSuccess) return e;
-    hipLaunchKernelGGL(wino_conv_kernel, dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);
+    static lds_attr_mask mask{0}, mask_pair{0};
+    // CABINET_WINO_PAIR=0: the round-5a patch loads (16 dword gathers) also for even W (A/B timing)
+    static const bool pair_on = [] { const char* e = getenv("CABINET_WINO_PAIR"); return !(e && e[0] == '0'); }();
+    const bool aligned8 = ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 7) == 0;
+    if (pair_on && (W & 1) == 0 && aligned8) {
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel<true>), 160 * 1024, mask_pair); e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);
+        return hipGetLastError();
+    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel<false>), 160 * 1024, mask); e != hipSuccess) return e;
+    hipLaunchKernelGGL(wino_conv_kernel<false>, dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 
