@@ -138,8 +138,12 @@ __device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_byt
 // dword per row that only the row's first and last lane use (the halo columns 32 bx - 1 and 32 bx + 32; every other lane's offset
 // is out of range: no memory request).  8 vector-memory instructions per chunk and thread instead of 16 dword gathers; zero padding
 // still costs nothing (a tile right of the image loads zeros, and that is exactly what its left neighbour needs in column W).
-template <bool PAIR>
+// NKB: 32-channel blocks of output channels per workgroup.  2 (64 channels) is the default; 1 is for grids that would not fill the
+// chip (config 5's conva / b1 forward: 2 images x 16 tile blocks x 4 channel blocks = 128 workgroups for 256 CUs): twice the
+// workgroups with half the MFMAs per chunk each -- the patch transform is done twice as often, but on CUs that were idle.
+template <bool PAIR, int NKB>
 __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
+    constexpr int KBW = 32 * NKB;   // output channels of this workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar, or every load offset built from it becomes a waterfall loop
@@ -229,24 +233,24 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     // ---- A operand: U rows of the wave's two xi, two 32-channel blocks; one 16-byte load = four k-steps -------------------
     const int ng = C >> 3, nrb = a.K >> 5;
     const buf_rsrc ru = make_rsrc(a.u, (unsigned)((size_t)16 * a.K * C * 4));
-    f32x4 ua[2][2][2], ub[2][2][2];   // [xi][channel block][half chunk]
-    auto load_u = [&](f32x4 (&dst)[2][2][2], int n) {
+    f32x4 ua[2][NKB][2], ub[2][NKB][2];   // [xi][channel block][half chunk]
+    auto load_u = [&](f32x4 (&dst)[2][NKB][2], int n) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int hc = 0; hc < 2; ++hc) {
-                    const int soff = ((((2 * wave + x) * nrb + 2 * kblk + kb) * ng + 2 * n + hc) * 64) * 16;
+                    const int soff = ((((2 * wave + x) * nrb + NKB * kblk + kb) * ng + 2 * n + hc) * 64) * 16;
                     dst[x][kb][hc] = bload4(ru, lane * 16, soff);
                 }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NKB];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][kb][r] = 0.f;
 
@@ -286,13 +290,13 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) dst[x][s] = vb[x * WN_CC * WN_TB + (2 * (4 * hc + s)) * WN_TB];
     };
-    auto mfma_quarter = [&](const f32x4 (&uu)[2][2][2], const float (&bv)[2][4], int hc, int s0) {
+    auto mfma_quarter = [&](const f32x4 (&uu)[2][NKB][2], const float (&bv)[2][4], int hc, int s0) {
 #pragma unroll
         for (int s = s0; s < s0 + 2; ++s)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) acc[x][kb] = mfma32(uu[x][kb][hc][s], bv[x][s], acc[x][kb]);
+                for (int kb = 0; kb < NKB; ++kb) acc[x][kb] = mfma32(uu[x][kb][hc][s], bv[x][s], acc[x][kb]);
     };
     // group-barrier recipes: `per` instructions of class `mask` behind each of `n` MFMAs (0x002 VALU, 0x020 VMEM read, 0x100 DS read,
     // 0x200 DS write)
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
         __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                    \
     }
-    auto body = [&](const f32x4 (&ucur)[2][2][2], f32x4 (&unext)[2][2][2], int n, int buf) {
+    auto body = [&](const f32x4 (&ucur)[2][NKB][2], f32x4 (&unext)[2][NKB][2], int n, int buf) {
         const int n1 = min(n + 1, nch - 1), n2 = min(n + 2, nch - 1);
         // ---- Q0
         __builtin_amdgcn_sched_barrier(0);
@@ -309,8 +313,8 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         load_u(unext, n1);
         read_v(bvb, buf, 1);
         mfma_quarter(ucur, bva, 0, 0);
-        WN_PIN(4, 0x020, 2)    // 8 filter loads
-        WN_PIN(4, 0x100, 2)    // LDS operand reads (ds_read2: 4 instructions; the recipe tolerates fewer)
+        WN_PIN(2 * NKB, 0x020, 2)    // 4 NKB filter loads
+        WN_PIN(2 * NKB, 0x100, 4 / NKB)    // LDS operand reads (ds_read2: 4 instructions; the recipe tolerates fewer)
         __builtin_amdgcn_sched_barrier(0);
         WN_T(1);
         // ---- Q1
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
         wino_bt_d_b(pd, vout);
         load_patch(n2);
         mfma_quarter(ucur, bva, 0, 2);
-        WN_PIN(8, 0x002, PAIR ? 6 : 4)    // 32 additions (+ 12 DPP moves)
+        WN_PIN(4 * NKB, 0x002, (PAIR ? 12 : 8) / NKB)    // 32 additions (+ 12 DPP moves)
         __builtin_amdgcn_sched_barrier(0);
         WN_T(2);
         // ---- Q2
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
             for (int xi = 0; xi < 16; ++xi) dst[xi * WN_CC * WN_TB] = vout[xi];
         }
         mfma_quarter(ucur, bvb, 1, 0);
-        WN_PIN(8, 0x200, 1)    // 8 LDS stores (ds_write2)
+        WN_PIN(4 * NKB, 0x200, 2 / NKB)    // 8 LDS stores (ds_write2)
         __builtin_amdgcn_sched_barrier(0);
         WN_T(3);
         __syncthreads();
@@ -360,12 +364,12 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                smem[((2 * wave + x) * WN_KB + 32 * kb + acc_row(r) + 4 * h) * WN_TB + li] = acc[x][kb][r];
+                smem[((2 * wave + x) * KBW + 32 * kb + acc_row(r) + 4 * h) * WN_TB + li] = acc[x][kb][r];
     __syncthreads();
-    const int k0 = kblk * WN_KB;
+    const int k0 = kblk * KBW;
     float* ybase;
     int krow0, kimg;   // first channel of the block inside its output tensor, channels of that tensor
     if (k0 < a.K0) ybase = a.y0, krow0 = k0, kimg = a.K0;
@@ -374,11 +378,11 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     const int oy = 2 * oty, ox = 2 * otx;
     const bool even_w = (a.W & 1) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * NKB; ++i) {
         const int kk = (tid >> 5) + 16 * i;   // channel of the block
         float m[16];
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) m[xi] = smem[(xi * WN_KB + kk) * WN_TB + t];
+        for (int xi = 0; xi < 16; ++xi) m[xi] = smem[(xi * KBW + kk) * WN_TB + t];
         float s0[4], s1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -777,18 +781,27 @@ static hipError_t wino_conv_run(const float* x0, const float* x1, const float* u
     a.C0 = C0, a.C1 = C1, a.K = K, a.K0 = K0, a.B = B, a.H = H, a.W = W;
     a.nby = (wn_th(H) + 1) / 2, a.nbx = (wn_th(W) + 15) / 16, a.ntb = B * a.nby * a.nbx, a.nkb = K / WN_KB;
     a.accumulate = accumulate;
-    const size_t lds = (size_t)16 * WN_KB * WN_TB * sizeof(float);   // 128 KB (the epilogue's planes; the V ring needs 64 KB)
-    static lds_attr_mask mask{0}, mask_pair{0};
+    // 32-channel blocks where 64-channel ones leave CUs idle (fewer than ~0.8 of one round of workgroups); CABINET_WINO_NKB=2 keeps 64
+    static const int nkb_env = [] { const char* e = getenv("CABINET_WINO_NKB"); return e ? atoi(e) : 0; }();   // 1 / 2: force (A/B timing)
+    const bool small = nkb_env == 1 || (nkb_env != 2 && a.ntb * a.nkb <= 200);
+    if (small) a.nkb = K / 32;
+    const size_t lds = (size_t)16 * (small ? 32 : WN_KB) * WN_TB * sizeof(float);   // the epilogue's planes (128 KB / 64 KB); the V ring needs 64 KB
+    static lds_attr_mask mask[4] = {{0}, {0}, {0}, {0}};
     // CABINET_WINO_PAIR=0: the round-5a patch loads (16 dword gathers) also for even W (A/B timing)
     static const bool pair_on = [] { const char* e = getenv("CABINET_WINO_PAIR"); return !(e && e[0] == '0'); }();
     const bool aligned8 = ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 7) == 0;
-    if (pair_on && (W & 1) == 0 && aligned8) {
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel<true>), 160 * 1024, mask_pair); e != hipSuccess) return e;
-        hipLaunchKernelGGL(wino_conv_kernel<true>, dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);
-        return hipGetLastError();
-    }
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel<false>), 160 * 1024, mask); e != hipSuccess) return e;
-    hipLaunchKernelGGL(wino_conv_kernel<false>, dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);
+    const bool pair = pair_on && (W & 1) == 0 && aligned8;
+#define WN_LAUNCH(P, N, M)                                                                                                       \
+    do {                                                                                                                         \
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv_kernel<P, N>), 160 * 1024, mask[M]); e != hipSuccess) \
+            return e;                                                                                                            \
+        hipLaunchKernelGGL((wino_conv_kernel<P, N>), dim3(a.ntb * a.nkb), dim3(512), lds, stream, a);                            \
+    } while (0)
+    if (pair && small) WN_LAUNCH(true, 1, 0);
+    else if (pair) WN_LAUNCH(true, 2, 1);
+    else if (small) WN_LAUNCH(false, 1, 2);
+    else WN_LAUNCH(false, 2, 3);
+#undef WN_LAUNCH
     return hipGetLastError();
 }
 
