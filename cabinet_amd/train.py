@@ -16,6 +16,7 @@ Python never travels to the GPU box), so the step recipe is restated:
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 
@@ -561,16 +562,26 @@ class GraphedDDPStep:
             # compute stream (profiles/r04_ddp_overlap_world1.md: every RCCL kernel with no compute kernel beside it, the next
             # compute kernel 10-98 us later).  Same buckets, same order on every rank.
             cur = torch.cuda.current_stream()
+            # tools/ddp_gap_probe.py (profiles/r05_ddp_gap_probe.txt): event records between the graph launches are free and so is a
+            # stream waiting for the event behind B1, but ANY stream waiting for the event behind B2 costs the compute stream
+            # ~0.3-0.4 ms (the B2 | B3 boundary then drains instead of overlapping).  CABINET_DDP_ONE_EVENT=1 drops that event and
+            # issues the backbone's buckets behind B3 on the compute stream instead (12.6 MB exposed instead of overlapped with the
+            # spatial branch's backward): which one wins at 8 GPUs is for a node that has them to measure.
+            one_event = os.environ.get("CABINET_DDP_ONE_EVENT") == "1"
             gB1.replay()
             self._ev[0].record(cur)
             gB2.replay()
-            self._ev[1].record(cur)
+            if not one_event:
+                self._ev[1].record(cur)
             gB3.replay()
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._ev[0])
                 works = self._reduce(0)   # the decoder's buckets travel under the backbone's and the spatial branch's backward
-                self._side.wait_event(self._ev[1])
-                works += self._reduce(1)  # the backbone's under the spatial branch's
+                if not one_event:
+                    self._side.wait_event(self._ev[1])
+                    works += self._reduce(1)  # the backbone's under the spatial branch's
+            if one_event:
+                works += self._reduce(1)
             works += self._reduce(2)      # < 0.5 MB behind graph B3: the only exposed communication
         else:
             gB1.replay()
