@@ -437,6 +437,238 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
     }
 }
 
+// ---- round 6: 128 output channels per workgroup at ONE wave per SIMD ---------------------------------------
+// The 64-channel kernel above stops at 0.66-0.72 of the fp32 MFMA peak because, per chunk, every wave issues ~70 other instructions
+// (patch loads, B^T d B, LDS stores / operand reads, filter loads) for 32 MFMAs, and on gfx950 those add up serially with the fp32
+// MFMAs (see the loop comment there).  With 256 threads a wave may hold 512 registers: 4 xi x 4 channel blocks = 16 accumulator
+// tiles (256 registers, in the AGPR half) per wave, i.e. a workgroup owns 128 output channels x 32 tiles for all 16 xi.  Per chunk
+// and wave: 128 MFMAs beside 2 patches (10 loads, 88 VALU, 16 LDS stores), 32 filter loads and 16 LDS operand reads -- the
+// transform, V traffic and x traffic per MFMA halve (x is fetched once per 128-channel block: 2x instead of 4x for K = 256).  There
+// is no partner wave to cover a wait, so everything a block of 32 MFMAs needs is requested one block ahead:
+//   block x (xi = 4 wave + x) of chunk n:   filter loads of block x+1, LDS operand reads of block x+1, 32 MFMAs, and
+//     x = 0: B^T d B of patch A of chunk n+1 and its 16 LDS stores      x = 1: the same for patch B
+//     x = 2: the loads of patch A of chunk n+2, then the chunk's one barrier (V[n+1] complete, every read of V[n] done)
+//     x = 3: the loads of patch B of chunk n+2; its operand reads are the first of chunk n+1
+// Used for grids of at least two rounds of workgroups (conv_out at configs 3 and 5); the attention branch's convolutions (64 or
+// 128 tile blocks) keep the 64- / 32-channel kernel.  W even and 8-byte aligned inputs only (the paired patch loads).
+constexpr int WN_KB2 = 128;
+
+__global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32], twice
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3, a scalar
+    const int tau = xcd_chunked_tile(blockIdx.x, a.ntb * a.nkb);  // a.nkb = K / 128
+    const int kblk = tau / a.ntb, tb = tau - kblk * a.ntb;
+    const int per_img = a.nby * a.nbx, b = tb / per_img, rem = tb - b * per_img, by = rem / a.nbx, bx = rem - by * a.nbx;
+    const int HW = a.H * a.W, C = a.C0 + a.C1, nch = C / WN_CC, nch0 = a.C0 / WN_CC;
+
+    // ---- the thread's two patches per chunk: tile li, channels cw = 2 wave + h (patch A) and cw + 8 (patch B: scalar offset) ----
+    const int ty = 2 * by + (li >> 4), tx = 16 * bx + (li & 15), cw = 2 * wave + h;
+    int poff[5];
+    {
+        const int t = li & 15, hr = t & 3, r = 2 * ty - 1 + hr;
+        const int hc = t < 4 ? 32 * bx - 1 : (t >= 12 ? 32 * bx + 32 : -1);
+        poff[4] = ((unsigned)r < (unsigned)a.H && (unsigned)hc < (unsigned)a.W) ? (cw * HW + r * a.W + hc) * 4 : WN_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = 2 * ty - 1 + i;
+            poff[i] = ((unsigned)rr < (unsigned)a.H && 2 * tx < a.W) ? (cw * HW + rr * a.W + 2 * tx) * 4 : WN_OOB;
+        }
+    }
+    const buf_rsrc rx0 = make_rsrc(a.x0 + (size_t)b * a.C0 * HW, (unsigned)((size_t)a.C0 * HW * 4));
+    const buf_rsrc rx1 = make_rsrc(a.x1 ? a.x1 + (size_t)b * a.C1 * HW : a.x0, (unsigned)((size_t)(a.x1 ? a.C1 : a.C0) * HW * 4));
+    float pdA[16], pdB[16];   // pd[4 i + 1], pd[4 i + 2] = the pair of row i, pd[0] = this lane's halo value; patch_ready() fills the rest
+    auto load_patch = [&](float (&pd)[16], int n, int which) {
+        const bool first = n < nch0;   // wave-uniform
+        const int soff = ((first ? n : n - nch0) * WN_CC + 8 * which) * HW * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 pr = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(first ? rx0 : rx1, poff[i], soff, 0));
+            pd[4 * i + 1] = pr[0], pd[4 * i + 2] = pr[1];
+        }
+        pd[0] = bload(first ? rx0 : rx1, poff[4], soff);
+    };
+    auto patch_ready = [&](float (&pd)[16]) {   // see wino_conv_kernel<PAIR>
+        const int hv = __builtin_bit_cast(int, pd[0]);
+        const int hq[4] = {__builtin_amdgcn_update_dpp(0, hv, 0x00, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0x55, 0xF, 0xF, true),
+                           __builtin_amdgcn_update_dpp(0, hv, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0xFF, 0xF, 0xF, true)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int halo = hq[i];
+            const int left = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, pd[4 * i + 2]), 0x111, 0xF, 0xF, false);   // row_shr:1
+            const int right = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, pd[4 * i + 1]), 0x101, 0xF, 0xF, false);  // row_shl:1
+            pd[4 * i] = __builtin_bit_cast(float, left), pd[4 * i + 3] = __builtin_bit_cast(float, right);
+        }
+    };
+    auto transform_store = [&](float (&pd)[16], int buf, int which) {
+        float v[16];
+        patch_ready(pd);
+        wino_bt_d_b(pd, v);
+        float* dst = smem + buf * WN_VBUF + (cw + 8 * which) * WN_TB + li;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) dst[xi * WN_CC * WN_TB] = v[xi];
+    };
+
+    // ---- A operand: U rows of block x (xi = 4 wave + x), four 32-channel blocks, two half chunks; one 16-byte load = four k-steps
+    const int ng = C >> 3, nrb = a.K >> 5;
+    const buf_rsrc ru = make_rsrc(a.u, (unsigned)((size_t)16 * a.K * C * 4));
+    auto load_u = [&](f32x4 (&dst)[4][2], int x, int n) {
+        const int base = (((4 * wave + x) * nrb + 4 * kblk) * ng + 2 * n) * 1024;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int hc = 0; hc < 2; ++hc) dst[kb][hc] = bload4(ru, lane * 16, base + (kb * ng + hc) * 1024);
+    };
+    auto read_v = [&](float (&dst)[8], int buf, int x) {
+        const float* vb = smem + buf * WN_VBUF + (4 * wave + x) * WN_CC * WN_TB + h * WN_TB + li;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dst[s] = vb[2 * s * WN_TB];
+    };
+    f32x16 acc[4][4];   // [x][channel block]
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][kb][r] = 0.f;
+    f32x4 u0[4][2], u1[4][2];
+    float v0[8], v1[8];
+#define WN_MFMA_BLOCK(X, UU, VV)                                                                                       \
+    _Pragma("unroll") for (int hc = 0; hc < 2; ++hc) _Pragma("unroll") for (int s = 0; s < 4; ++s)                     \
+        _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) acc[X][kb] = mfma32(UU[kb][hc][s], VV[4 * hc + s], acc[X][kb]);
+#define WN_PIN(n, mask, per)                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+        __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                        \
+    }
+    auto chunk = [&](int n, int buf) {
+        const int n1 = min(n + 1, nch - 1), n2 = min(n + 2, nch - 1);
+        // ---- block 0: U / V of block 1 requested; patch A of chunk n+1 transformed and stored
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(u1, 1, n);
+        read_v(v1, buf, 1);
+        transform_store(pdA, buf ^ 1, 0);
+        WN_MFMA_BLOCK(0, u0, v0)
+        WN_PIN(8, 0x020, 1)     // 8 filter loads
+        WN_PIN(4, 0x100, 2)     // 8 LDS operand reads (ds_read2st64: 4)
+        WN_PIN(16, 0x002, 3)    // 12 DPP moves + 32 additions
+        WN_PIN(4, 0x200, 4)     // 16 LDS stores (ds_write2st64: 8)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- block 1: the same for patch B
+        load_u(u0, 2, n);
+        read_v(v0, buf, 2);
+        transform_store(pdB, buf ^ 1, 1);
+        WN_MFMA_BLOCK(1, u1, v1)
+        WN_PIN(8, 0x020, 1)
+        WN_PIN(4, 0x100, 2)
+        WN_PIN(16, 0x002, 3)
+        WN_PIN(4, 0x200, 4)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- block 2: patch A of chunk n+2 requested (two blocks ahead of the wait that covers it); the chunk's barrier
+        load_u(u1, 3, n);
+        read_v(v1, buf, 3);
+        load_patch(pdA, n2, 0);
+        WN_MFMA_BLOCK(2, u0, v0)
+        WN_PIN(13, 0x020, 1)
+        WN_PIN(4, 0x100, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // V[n+1] is complete; every read of V[n] has returned
+        // ---- block 3: first operands of chunk n+1, patch B of chunk n+2 requested
+        load_u(u0, 0, n1);
+        read_v(v0, buf ^ 1, 0);
+        load_patch(pdB, n2, 1);
+        WN_MFMA_BLOCK(3, u1, v1)
+        WN_PIN(13, 0x020, 1)
+        WN_PIN(4, 0x100, 2)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- prologue
+    load_patch(pdA, 0, 0);
+    load_patch(pdB, 0, 1);
+    load_u(u0, 0, 0);
+    transform_store(pdA, 0, 0);
+    transform_store(pdB, 0, 1);
+    load_patch(pdA, min(1, nch - 1), 0);
+    load_patch(pdB, min(1, nch - 1), 1);
+    __syncthreads();
+    read_v(v0, 0, 0);
+    // ONE chunk per iteration, the V buffer chosen by a scalar: a second, conditional copy of the body (`if (n + 1 < nch)`) puts 256
+    // accumulator registers through a phi at its merge point, and with all 256 AGPRs taken the copies go through scratch
+    // (181 spilled registers; this form: none)
+    for (int n = 0; n < nch; ++n) chunk(n, n & 1);
+#undef WN_PIN
+#undef WN_MFMA_BLOCK
+
+    // ---- epilogue: two halves of 64 channels through LDS (16 planes x 64 x 32 = 128 KB each), Y = A^T M A ------------------------
+    const int t = tid & 31, oty = 2 * by + (t >> 4), otx = 16 * bx + (t & 15);
+    const int oy = 2 * oty, ox = 2 * otx;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();   // half 0: every wave is past its last V read; half 1: the first half's planes have been read
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    smem[((4 * wave + x) * 64 + 32 * kq + acc_row(r) + 4 * h) * WN_TB + li] = acc[x][2 * half + kq][r];
+        __syncthreads();
+        const int k0 = kblk * WN_KB2 + 64 * half;
+        float* ybase;
+        int krow0, kimg;
+        if (k0 < a.K0) ybase = a.y0, krow0 = k0, kimg = a.K0;
+        else ybase = a.y1, krow0 = k0 - a.K0, kimg = a.K - a.K0;
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int kk = (tid >> 5) + 8 * i;   // channel of the half block
+            float m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = smem[(xi * 64 + kk) * WN_TB + t];
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = (m[j] + m[4 + j]) + m[8 + j];
+                s1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+            }
+            float o[2][2];
+            o[0][0] = (s0[0] + s0[1]) + s0[2], o[0][1] = (s0[1] - s0[2]) - s0[3];
+            o[1][0] = (s1[0] + s1[1]) + s1[2], o[1][1] = (s1[1] - s1[2]) - s1[3];
+            float* yp = ybase + ((size_t)b * kimg + krow0 + kk) * HW;
+            const bool vx = ox < a.W;   // W is even: both columns of the tile are inside, or none
+            float cnt = 0.f, sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool vy = oy + r < a.H;
+                if (vy && vx) {
+                    float* p = yp + (size_t)(oy + r) * a.W + ox;
+                    f32x2 val = {o[r][0], o[r][1]};
+                    if (a.accumulate) {
+                        const f32x2 old = *reinterpret_cast<const f32x2*>(p);
+                        val[0] += old[0], val[1] += old[1], o[r][0] = val[0], o[r][1] = val[1];
+                    }
+                    *reinterpret_cast<f32x2*>(p) = val;
+                    cnt += 2.f, sum += o[r][0], sum += o[r][1];
+                }
+            }
+            if (a.stat_part) {   // (mean, M2) of the block's valid outputs of channel kk (as wino_conv_kernel: same order, same bits)
+                const float n_blk = half_sum(cnt), mean = half_sum(sum) / fmaxf(n_blk, 1.f);
+                float m2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (oy + r < a.H && vx) {
+                        m2 += (o[r][0] - mean) * (o[r][0] - mean);
+                        m2 += (o[r][1] - mean) * (o[r][1] - mean);
+                    }
+                m2 = half_sum(m2);
+                if (t == 0) {
+                    a.stat_part[(size_t)(k0 + kk) * a.ntb + tb] = mean;
+                    a.stat_part[((size_t)a.K + k0 + kk) * a.ntb + tb] = m2;
+                }
+            }
+        }
+    }
+}
+
 // ---- weight gradient: dU_xi (K x C) = sum over tiles of dM_xi (K x tiles) . V_xi^T (tiles x C), dw = G^T dU G ---------------------
 // dM = A dY A^T (the 2x2 output-gradient tile spread to 4x4), V = B^T d B as in forward: F(3x3, 2x2), the exact adjoint of the
 // forward's bilinear form, 16 instead of 36 multiplications per (k, c, tile).  The contraction runs over tiles, so BOTH operands are
@@ -781,6 +1013,23 @@ static hipError_t wino_conv_run(const float* x0, const float* x1, const float* u
     a.C0 = C0, a.C1 = C1, a.K = K, a.K0 = K0, a.B = B, a.H = H, a.W = W;
     a.nby = (wn_th(H) + 1) / 2, a.nbx = (wn_th(W) + 15) / 16, a.ntb = B * a.nby * a.nbx, a.nkb = K / WN_KB;
     a.accumulate = accumulate;
+    // round 6: 128-channel blocks at one wave per SIMD where the grid still fills at least two rounds of workgroups
+    // (CABINET_WINO_128=0: off, =1: wherever the shape allows -- A/B timing)
+    const char* k128_s = getenv("CABINET_WINO_128");   // read per call: the tests flip it in-process
+    const int k128_env = k128_s ? atoi(k128_s) : -1;
+    {
+        const bool aligned8 = ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 7) == 0;
+        const bool can = (W & 1) == 0 && aligned8 && (K % WN_KB2) == 0 && (K0 % 64) == 0;
+        const int wgs = a.ntb * (K / WN_KB2);
+        if (can && k128_env != 0 && (k128_env == 1 || wgs >= 512)) {
+            a.nkb = K / WN_KB2;
+            static lds_attr_mask mask128{0};
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv128_kernel), 160 * 1024, mask128); e != hipSuccess)
+                return e;
+            hipLaunchKernelGGL(wino_conv128_kernel, dim3(wgs), dim3(256), (size_t)16 * 64 * WN_TB * sizeof(float), stream, a);
+            return hipGetLastError();
+        }
+    }
     // 32-channel blocks where 64-channel ones leave CUs idle (fewer than ~0.8 of one round of workgroups); CABINET_WINO_NKB=2 keeps 64
     static const int nkb_env = [] { const char* e = getenv("CABINET_WINO_NKB"); return e ? atoi(e) : 0; }();   // 1 / 2: force (A/B timing)
     const bool small = nkb_env == 1 || (nkb_env != 2 && a.ntb * a.nkb <= 200);

@@ -656,6 +656,19 @@ void bn_finalize(const double* stat_part, int ntiles, int C, int nch, long long 
 // pooled[b][c] = mean_p relu(bn(z[b][c][p]))        one workgroup per (b,c) row.
 // The BatchNorm finalize is folded in: every row reduces its channel's B double partials itself (2 B scalar loads), the
 // image-0 row also writes save_mean / save_invstd and updates the running buffers -- it was a 5 us launch of its own.
+//
+// Round 6 -- ReLU decisions of borderline units in double.  tools/diag_ffm_flips.py on the model's own
+// tensors at configs 3 and 5 (profiles/r06_ffm_flips_config{3,5}.json): every gradient of the FFM equals the fp64 replay with the
+// kernels' OWN ReLU mask to 2e-7, and ALL of the in-situ distance from the fp64 oracle (dfsp 7.2e-4 / 4.4e-4) is 4 of 33.5 M (3 of
+// 16.8 M) units whose pre-activation lies within the fp32 product's rounding error (1.9e-7 abs on |z| ~ 0.8) of zero and lands on
+// the other side -- the fp32 CPU reference flips 3 (1) others.  A unit that close to the boundary is decided by rounding noise in
+// ANY fp32 implementation, and each one toggles a whole gradient column; so this pass, the first that knows the batch mean,
+// re-decides exactly those units: where |pre| < 2^-17 (|gamma| + |beta|) (about 200 of 33.5 M elements at config 3) the wave
+// recomputes z = W [fsp; U(low)] for that one unit in double from the operator's inputs (24 loads per lane, a wave sum), takes
+// the decision from (z64 - mean64) invstd64 gamma + beta in double, and stores the fp32 z nearest to z64 for which the kernels'
+// own expression fmaf((z - mean) invstd, gamma, beta) > 0 -- the one every FFM kernel, forward and backward, evaluates -- gives
+// that decision (at most a few ulps from z64; the BatchNorm sums were taken over the uncorrected z: a 1e-14 relative change).
+// At most FFM_EXACT_CAP units per row are re-decided (degenerate inputs -- a constant plane -- would flag every element).
 struct BnFin {
     const double* stat_part;  // [2][C][B] sums and sums of squares per (channel, image); unused in eval mode
     int B, training;
@@ -663,14 +676,69 @@ struct BnFin {
     float momentum, eps;
     float *run_mean, *run_var, *save_mean, *save_invstd;
 };
-__global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__ z, BnFin fin,
+struct FfmExact {      // the operator's inputs, for the double-precision re-decision; fsp == nullptr: off
+    const float* fsp;  // (B, Cs, H, W)
+    const float* xc;   // plain form: fcp (B, Cc, H, W); fused-upsample form: low (B, Cc, Hl, Wl)
+    const float* w;    // (Co, Cs + Cc) as stored
+    int Cs, Cc, H, W, Hl, Wl;   // Hl == 0: plain form
+};
+constexpr int FFM_EXACT_CAP = 16;
+
+// z[b][co][p] in double, by one whole wave (every lane returns the sum)
+__device__ double ffm_exact_z(const FfmExact& e, int b, int co, int p, int lane) {
+    const int P = e.H * e.W, Cin = e.Cs + e.Cc;
+    const float* wr = e.w + (size_t)co * Cin;
+    double acc = 0.0;
+    for (int c = lane; c < e.Cs; c += 64) acc += (double)wr[c] * (double)e.fsp[((size_t)b * e.Cs + c) * P + p];
+    if (e.Hl == 0) {
+        for (int c = lane; c < e.Cc; c += 64) acc += (double)wr[e.Cs + c] * (double)e.xc[((size_t)b * e.Cc + c) * P + p];
+    } else {
+        // F.interpolate(mode="bilinear", align_corners=False) as ATen evaluates it for a double tensor (cabinet.py:228-230):
+        // src = (dst + 0.5) in / out - 0.5 clamped at 0, i1 = min(i0 + 1, in - 1)
+        const int oy = p / e.W, ox = p - oy * e.W, Pl = e.Hl * e.Wl;
+        auto taps = [](int d, int in, int out, int& i0, int& i1, double& l) {
+            double src = ((double)d + 0.5) * ((double)in / (double)out) - 0.5;
+            if (src < 0.0) src = 0.0;
+            i0 = min((int)src, in - 1), i1 = min(i0 + 1, in - 1), l = src - (double)i0;
+        };
+        int y0, y1, x0, x1;
+        double ly, lx;
+        taps(oy, e.Hl, e.H, y0, y1, ly);
+        taps(ox, e.Wl, e.W, x0, x1, lx);
+        for (int c = lane; c < e.Cc; c += 64) {
+            const float* lp = e.xc + ((size_t)b * e.Cc + c) * Pl;
+            const double v = (1.0 - ly) * ((1.0 - lx) * (double)lp[y0 * e.Wl + x0] + lx * (double)lp[y0 * e.Wl + x1]) +
+                             ly * ((1.0 - lx) * (double)lp[y1 * e.Wl + x0] + lx * (double)lp[y1 * e.Wl + x1]);
+            acc += (double)wr[e.Cs + c] * v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    return acc;
+}
+
+// the fp32 z nearest to z64 whose fp32 pre-activation has the sign of the double one
+__device__ float ffm_decided_z(double z64, double mean64, double inv64, float mu, float inv, float gw, float gb) {
+    const bool want = (z64 - mean64) * inv64 * (double)gw + (double)gb > 0.0;
+    float zc = (float)z64;
+    const bool up = (gw > 0.f) == want;   // which way z has to move to change the fp32 decision towards `want`
+    for (int it = 0; it < 16; ++it) {
+        if ((fmaf((zc - mu) * inv, gw, gb) > 0.f) == want) break;
+        zc = nextafterf(zc, up ? INFINITY : -INFINITY);
+    }
+    return zc;
+}
+
+__global__ __launch_bounds__(256) void ffm_pool_kernel(float* __restrict__ z, BnFin fin, FfmExact ex,
                                                         const float* __restrict__ bn_w, const float* __restrict__ bn_b,
                                                         float* __restrict__ pooled, int C, int P) {
     __shared__ float s_red[4];
-    const int row = blockIdx.x, c = row % C, b = row / C;
+    const int row = blockIdx.x, c = row % C, b = row / C, lane = threadIdx.x & 63;
     float mu, inv;
+    double mean64, inv64;
     if (!fin.training) {
         mu = fin.run_mean[c], inv = 1.0f / sqrtf(fin.run_var[c] + fin.eps);
+        mean64 = (double)mu, inv64 = 1.0 / sqrt((double)fin.run_var[c] + (double)fin.eps);
         if (b == 0 && threadIdx.x == 0) fin.save_mean[c] = mu, fin.save_invstd[c] = inv;
     } else {
         double s1 = 0.0, s2 = 0.0;
@@ -700,7 +768,8 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__
         const double mean = s1 / (double)fin.count;
         double var = s2 / (double)fin.count - mean * mean;
         if (var < 0.0) var = 0.0;
-        mu = (float)mean, inv = (float)(1.0 / sqrt(var + (double)fin.eps));
+        mean64 = mean, inv64 = 1.0 / sqrt(var + (double)fin.eps);
+        mu = (float)mean, inv = (float)inv64;
         if (b == 0 && threadIdx.x == 0) {
             fin.save_mean[c] = mu, fin.save_invstd[c] = inv;
             const double unbiased = fin.count > 1 ? var * ((double)fin.count / (double)(fin.count - 1)) : var;
@@ -708,17 +777,67 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(const float* __restrict__
             fin.run_var[c] = (float)((1.0 - (double)fin.momentum) * (double)fin.run_var[c] + (double)fin.momentum * unbiased);
         }
     }
-    const float sc = bn_w[c] * inv, sh = bn_b[c] - mu * sc;
-    const float* zr = z + (size_t)row * P;
+    // relu(bn(z)) as EVERY FFM kernel evaluates it (ffm_gate_kernel, the backward's reduction, adjoint and product kernels):
+    // pre = fmaf((z - mean) invstd, gamma, beta) -- no cancellation against a folded shift, and one expression for one mask
+    const float gw = bn_w[c], gb = bn_b[c];
+    const float thr = ex.fsp ? 0x1p-17f * (fabsf(gw) + fabsf(gb)) : -1.f;
+    float* zr = z + (size_t)row * P;
     float acc = 0.f;
+    int budget = FFM_EXACT_CAP;   // per wave: wave-uniform
+    // a borderline element of lane `src` (wave-uniform branch: every lane takes part in the double-precision product)
+    auto redecide = [&](int src, int p) {
+        const double z64 = ffm_exact_z(ex, b, c, p, lane);
+        const float zc = ffm_decided_z(z64, mean64, inv64, mu, inv, gw, gb);
+        if (lane == src) zr[p] = zc;
+        return zc;
+    };
     if ((P & 3) == 0) {
-        for (int p = threadIdx.x * 4; p < P; p += 1024) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(zr + p);
+        for (int p0 = 0; p0 < P; p0 += 1024) {   // wave-uniform trip count
+            const int p = p0 + threadIdx.x * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < P) v = *reinterpret_cast<const f32x4*>(zr + p);
+            float y[4];
+            bool flag = false;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc += fmaxf(fmaf(v[e], sc, sh), 0.f);
+            for (int e = 0; e < 4; ++e) {
+                y[e] = fmaf((v[e] - mu) * inv, gw, gb);
+                flag |= fabsf(y[e]) < thr;
+            }
+            unsigned long long m = __ballot(flag && p < P);
+            while (m && budget > 0) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int ps = __shfl(p, src, 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ye = __shfl(y[e], src, 64);
+                    if (fabsf(ye) < thr && budget > 0) {   // wave-uniform
+                        const float zc = redecide(src, ps + e);
+                        if (lane == src) y[e] = fmaf((zc - mu) * inv, gw, gb);
+                        --budget;
+                    }
+                }
+            }
+            if (p < P) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += fmaxf(y[e], 0.f);
+            }
         }
     } else {
-        for (int p = threadIdx.x; p < P; p += 256) acc += fmaxf(fmaf(zr[p], sc, sh), 0.f);
+        for (int p0 = 0; p0 < P; p0 += 256) {
+            const int p = p0 + threadIdx.x;
+            const bool in = p < P;
+            float y = in ? fmaf((zr[p] - mu) * inv, gw, gb) : 1.f;
+            unsigned long long m = __ballot(in && fabsf(y) < thr);
+            while (m && budget > 0) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float zc = redecide(src, __shfl(p, src, 64));
+                if (lane == src) y = fmaf((zc - mu) * inv, gw, gb);
+                --budget;
+            }
+            if (in) acc += fmaxf(y, 0.f);
+        }
     }
     acc = block_sum_256(acc, s_red);
     if (threadIdx.x == 0) pooled[row] = acc / (float)P;
@@ -789,7 +908,7 @@ __global__ __launch_bounds__(256) void ffm_gate_kernel(const float* __restrict__
                                                         const float* __restrict__ gate, float* __restrict__ out, int C,
                                                         int P, int chunks_per_row) {
     const int row = blockIdx.x / chunks_per_row, chunk = blockIdx.x % chunks_per_row, c = row % C;
-    const float sc = bn_w[c] * invstd[c], sh = bn_b[c] - mean[c] * sc, ga = 1.f + gate[row];
+    const float mu = mean[c], is = invstd[c], gw = bn_w[c], gb = bn_b[c], ga = 1.f + gate[row];   // the mask expression of ffm_pool_kernel
     const float* zr = z + (size_t)row * P;
     float* orow = out + (size_t)row * P;
     const int lo = chunk * 4096, hi = min(lo + 4096, P);
@@ -797,11 +916,11 @@ __global__ __launch_bounds__(256) void ffm_gate_kernel(const float* __restrict__
         for (int p = lo + threadIdx.x * 4; p < hi; p += 1024) {
             f32x4 v = *reinterpret_cast<const f32x4*>(zr + p);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], sc, sh), 0.f) * ga;
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf((v[e] - mu) * is, gw, gb), 0.f) * ga;
             *reinterpret_cast<f32x4*>(orow + p) = v;
         }
     } else {
-        for (int p = lo + threadIdx.x; p < hi; p += 256) orow[p] = fmaxf(fmaf(zr[p], sc, sh), 0.f) * ga;
+        for (int p = lo + threadIdx.x; p < hi; p += 256) orow[p] = fmaxf(fmaf((zr[p] - mu) * is, gw, gb), 0.f) * ga;
     }
 }
 
@@ -1051,17 +1170,22 @@ size_t ffm_up_fwd_workspace(const FfmShape& s, int Hl, int Wl) {
 }
 
 // everything after z exists: BN statistics, pooling, SE gate, gated output
+static bool ffm_exact_mask_enabled() {   // CABINET_FFM_EXACT_MASK=0: fp32 decisions everywhere (A/B: tools/diag_ffm_flips.py)
+    static const bool on = [] { const char* e = getenv("CABINET_FFM_EXACT_MASK"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static void ffm_fwd_tail(const FfmShape& s, double* stat_part, const float* bn_w, const float* bn_b,
                          float* run_mean, float* run_var, const float* w1, const float* w2, int training,
-                         float momentum, float eps, float* out, const float* z, float* save_mean,
-                         float* save_invstd, float* pooled, float* gate, hipStream_t stream, int nparts = 0) {
+                         float momentum, float eps, float* out, float* z, float* save_mean,
+                         float* save_invstd, float* pooled, float* gate, hipStream_t stream, FfmExact ex, int nparts = 0) {
     // nparts > 0: the producer of z already left nparts (sum, sum of squares) pairs per channel in stat_part (fused forward)
     const int P = s.H * s.W;
     if (training && nparts == 0)
         hipLaunchKernelGGL(bn_rowstats_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, stat_part, s.B, s.Co, P);
     const BnFin fin{stat_part, nparts > 0 ? nparts : s.B, training, (long long)s.B * P, momentum, eps, run_mean, run_var,
                     save_mean, save_invstd};
-    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, fin, bn_w, bn_b, pooled, s.Co, P);
+    if (!ffm_exact_mask_enabled()) ex.fsp = nullptr;
+    hipLaunchKernelGGL(ffm_pool_kernel, dim3(s.B * s.Co), dim3(256), 0, stream, z, fin, ex, bn_w, bn_b, pooled, s.Co, P);
     hipLaunchKernelGGL(ffm_se_kernel, dim3(s.B), dim3(SE_T), (size_t)(s.Co + s.Cm) * sizeof(float), stream, pooled, w1,
                        w2, gate, s.Co, s.Cm);
     const int cpr = ceil_div(P, 4096);
@@ -1087,7 +1211,7 @@ hipError_t ffm_fwd_run(const FfmShape& s, const float* fsp, const float* fcp, co
     a.P = P;
     if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
-                 save_invstd, pooled, gate, stream);
+                 save_invstd, pooled, gate, stream, FfmExact{fsp, fcp, w_blk, s.Cs, s.Cc, s.H, s.W, 0, 0});
     return hipGetLastError();
 }
 
@@ -1102,6 +1226,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
     double* stat_part = reinterpret_cast<double*>(base + wt_bytes(s));
     float* ylow = reinterpret_cast<float*>(base + wt_bytes(s) + stat_bytes(s));
     void* wpack = base + wt_bytes(s) + stat_bytes(s) + low_bytes(s, Hl, Wl);
+    const FfmExact ex{fsp, low, w_blk, s.Cs, s.Cc, s.H, s.W, Hl, Wl};
     const bool small_low = small_grid(s.B, s.Co, Pl) && (Cin % 4) == 0 && (s.Cc % 4) == 0;
     // the persistent form of the big product (fp32; ffm_fwd_fused.hip) reads W as stored and leaves the BatchNorm partial sums
     const bool fused_z = precision == 0 && ffm_fwd_fused_enabled() && (Cin % 4) == 0 &&
@@ -1129,7 +1254,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
             e != hipSuccess)
             return e;
         ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
-                     save_invstd, pooled, gate, stream, ffm_fwd_fused_nwg(s.B, P));
+                     save_invstd, pooled, gate, stream, ex, ffm_fwd_fused_nwg(s.B, P));
         return hipGetLastError();
     }
     if (precision != 0 && gemm_bf16_supported(s.Co, s.Cs, P, s.W, Wl, true)) {
@@ -1149,7 +1274,7 @@ hipError_t ffm_up_fwd_run(const FfmShape& s, int Hl, int Wl, const float* fsp, c
         if (hipError_t ge = gemm_kmajor(a, s.B, stream); ge != hipSuccess) return ge;
     }
     ffm_fwd_tail(s, stat_part, bn_w, bn_b, run_mean, run_var, w1, w2, training, momentum, eps, out, z, save_mean,
-                 save_invstd, pooled, gate, stream);
+                 save_invstd, pooled, gate, stream, ex);
     return hipGetLastError();
 }
 

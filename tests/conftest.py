@@ -39,6 +39,15 @@ def pytest_collection_modifyitems(config, items):
     import torch
 
     if torch.cuda.is_available():
+        # Round 6: the GPU parity session pins MIOpen to its deterministic solvers.  tools/diag_step_determinism.py
+        # (profiles/r06_step_determinism.txt): with the default solver choice the FORWARD of the spatial branch is not reproducible
+        # run to run (six repeats of one step from one state_dict: six different digests of the final logits, the attention
+        # branch's logits identical) -- a split-K convolution solver with atomics --, so which ReLU units flip, and with them every
+        # gradient upstream (216 of 221 tensors move; gamma.grad lands up to 1.9e-3 from the reference's value), depends on the
+        # run.  With torch.backends.cudnn.deterministic (MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC on every descriptor) six repeats are
+        # bit-identical in every logit and every gradient: the verdict of the parity suite no longer depends on box history.
+        # (bench.py keeps MIOpen's default choice: the timed step is what a user runs.)
+        torch.backends.cudnn.deterministic = True
         return
     skip = pytest.mark.skip(reason="no GPU in this process")
     for it in items:

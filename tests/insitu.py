@@ -11,12 +11,18 @@ Reference spans replayed: src/models/cab.py:131-162,182-184,213-216; src/models/
 src/utils/loss.py:38-80 with cabinet.py:240-245.
 """
 import torch
+import torch.nn.functional as F
 
 from oracle import model_ref
 
 
 def instrument(net):
     cap = {}
+    # one live capture per process: a registry entry of an earlier model (keyed by id(weight): ids are reused after garbage
+    # collection) must not route a later model's tensors into a stale dict (ADVICE r05)
+    _K11_REGISTRY.clear()
+    _K12_REGISTRY.clear()
+    _FFM_REGISTRY.clear()
 
     def keep(name, t):
         cap[name] = t.detach().clone()
@@ -69,7 +75,31 @@ def instrument(net):
     # their meaning (own-mask replay = the operator's arithmetic; fp64-mask replay = arithmetic + flipped units).
     _K12_REGISTRY.update({id(net.ab.b4.weight): (cap, "ab"), id(net.conv_out.conv_out.weight): (cap, "conv_out")})
     _install_k12_spy()
+    # the FFM's pre-BatchNorm product and saved statistics (round 6): what its kernels decide their ReLU mask on
+    _FFM_REGISTRY[id(net.ffm.convblk.conv.weight)] = cap
+    _install_ffm_spy()
     return cap
+
+
+_FFM_REGISTRY = {}
+
+
+def _install_ffm_spy():
+    import cabinet_amd.functional as Fn
+
+    if getattr(Fn.ffm_up_fwd_hip, "_insitu_spy", False):
+        return
+    orig = Fn.ffm_up_fwd_hip
+
+    def ffm_up_fwd_spy(fsp, low, w_blk, bn_w, *rest):
+        res = orig(fsp, low, w_blk, bn_w, *rest)
+        for cap in _FFM_REGISTRY.values():   # one live capture at a time (instrument() clears the registries)
+            if cap.get("ffm.fsp") is not None and cap["ffm.fsp"].shape == fsp.shape and "ffm.z" not in cap:
+                cap["ffm.z"], cap["ffm.bn_mean"], cap["ffm.bn_invstd"] = (t.detach().clone() for t in res[1:4])
+        return res
+
+    ffm_up_fwd_spy._insitu_spy = True
+    Fn.ffm_up_fwd_hip = ffm_up_fwd_spy
 
 
 _K11_REGISTRY = {}
@@ -198,6 +228,30 @@ def replay_ffm(sd, fsp, low, g, dtype, training=True):
     return y.detach(), fo.grad, lo.grad, w.grads()
 
 
+def replay_ffm_masked(sd, fsp, low, g, mask, training=True, eps=1e-5):
+    """The FFM (cabinet.py:142-153 behind the x4 resize of :228-230) in fp64 with the ReLU replaced by a GIVEN 0/1 mask (the
+    kernels' own): what separates the model's gradients from this replay is the kernels' arithmetic alone, what separates this
+    replay from replay_ffm's is the flipped units.  -> dfsp, dlow, {param: grad}, mask of the fp64 forward"""
+    dt = torch.float64
+    p = {k: sd["ffm." + k].detach().cpu().to(dt).requires_grad_(True) for k in
+         ("convblk.conv.weight", "convblk.bn.weight", "convblk.bn.bias", "conv1.weight", "conv2.weight")}
+    fo = fsp.detach().cpu().to(dt).requires_grad_(True)
+    lo = low.detach().cpu().to(dt).requires_grad_(True)
+    z = F.conv2d(torch.cat([fo, model_ref._bilinear(lo, fo.shape[2:])], 1), p["convblk.conv.weight"])
+    if training:
+        mean, var = z.mean(dim=(0, 2, 3), keepdim=True), z.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    else:
+        mean = sd["ffm.convblk.bn.running_mean"].to(dt).view(1, -1, 1, 1)
+        var = sd["ffm.convblk.bn.running_var"].to(dt).view(1, -1, 1, 1)
+    pre = (z - mean) * (var + eps).rsqrt() * p["convblk.bn.weight"].view(1, -1, 1, 1) + p["convblk.bn.bias"].view(1, -1, 1, 1)
+    mask64 = pre.detach() > 0
+    feat = pre * mask.detach().cpu().to(dt)
+    a = feat.mean(dim=(2, 3), keepdim=True)
+    a = torch.sigmoid(F.conv2d(F.relu(F.conv2d(a, p["conv1.weight"])), p["conv2.weight"]))
+    (feat * a + feat).backward(g.detach().cpu().to(dt))
+    return fo.grad, lo.grad, {k: v.grad for k, v in p.items()}, mask64
+
+
 def replay_head(low, labels, size, n_min, dtype, thresh=0.7):
     """One loss head: OHEM-CE of the x8 bilinear upsample of the low-resolution logits: -> loss, dlow."""
     lo = low.detach().cpu().to(dtype).requires_grad_(True)
@@ -242,6 +296,10 @@ def replay_b2(sd, z, r_gpu, d_r, training=True, eps=1e-5, prefix="ab.b2"):
 
 
 B2_OWN_MASK_TOL = 1e-5  # K7's backward against the fp64 replay with K7's own ReLU mask
+OWN_MASK_ROWS = ("ab.b2.dx_own_mask", "conv_out.bn.dx_own_mask", "ffm.dfsp_own_mask", "ffm.dlow_own_mask",
+                 "ffm.convblk.conv.weight_own_mask", "ffm.convblk.bn.bias_own_mask")
+FFM_VS_CPU32 = 1.5   # an FFM row may be at most this multiple of the fp32 CPU oracle's distance from fp64 (same tensors) ...
+FP32_LEVEL = 1e-6    # ... unless it sits at the fp32 rounding level anyway
 
 
 def cab_table(net, sd, cap, training=True):
@@ -287,6 +345,19 @@ def operator_table(net, sd, cap, labels, size, n_min, with_fp32=True, training=T
     for k, v in g64.items():
         put("ffm." + k, grads["ffm." + k], v, g32.get(k))
     del res
+    if "ffm.z" in cap:
+        # round 6: the same gradients against the fp64 replay under the kernels' OWN ReLU mask (= their arithmetic alone), and the
+        # number of units whose decision differs from the fp64 forward's (ffm.hip re-decides borderline units in double)
+        sdg = {k: (v.to(cap["ffm.z"].device) if torch.is_tensor(v) else v) for k, v in sd.items() if k.startswith("ffm.convblk.bn.")}
+        own = own_relu_output(cap["ffm.z"], cap["ffm.bn_mean"], cap["ffm.bn_invstd"], sdg["ffm.convblk.bn.weight"],
+                              sdg["ffm.convblk.bn.bias"]) > 0
+        df, dl, gp, mask64 = replay_ffm_masked(sd, cap["ffm.fsp"], cap["ffm.low"], cap["d.ffm.y"], own, training)
+        put("ffm.dfsp_own_mask", cap["d.ffm.fsp"], df)
+        put("ffm.dlow_own_mask", cap["d.ffm.low"], dl)
+        put("ffm.convblk.conv.weight_own_mask", grads["ffm.convblk.conv.weight"], gp["convblk.conv.weight"])
+        put("ffm.convblk.bn.bias_own_mask", grads["ffm.convblk.bn.bias"], gp["convblk.bn.bias"])
+        rows["ffm.dfsp_own_mask"].update(flipped_units_vs_f64_mask=int((own.cpu() != mask64).sum()), units=mask64.numel())
+        del own, df, dl, gp, mask64
     # ---- K11: the decoder's three plain 3x3 convolutions (conva, the two-pointer fusion head b1, conv_out.conv), when they ran
     # through K11 (captured at the conv3x3 call, each input through a view of its own: the gradients are this use's alone)
     for name, wkey in (("ab.conva", "ab.conva.0.weight"), ("ab.b1", "ab.b1.weight"), ("conv_out.conv", "conv_out.conv.conv.weight")):
@@ -355,6 +426,11 @@ def judge_operator_table(rows, tol, training=True):
             r["analytic_zero"] = True
             if not (r["norm"] < 1e-3 * scale_ref and r["gpu_vs_f64"] * r["norm"] < 1e-3 * scale_ref):
                 bad[k] = r
-        elif not r["gpu_vs_f64"] <= (B2_OWN_MASK_TOL if k in ("ab.b2.dx_own_mask", "conv_out.bn.dx_own_mask") else tol):
+        elif not r["gpu_vs_f64"] <= (B2_OWN_MASK_TOL if k in OWN_MASK_ROWS else tol):
+            bad[k] = r
+        elif k.startswith("ffm.") and "cpu32_vs_f64" in r and not r["gpu_vs_f64"] <= max(FFM_VS_CPU32 * r["cpu32_vs_f64"], FP32_LEVEL):
+            # no FFM row may creep back to a multiple of the fp32 CPU oracle's own distance from fp64 on the
+            # very same tensors (rows at the fp32 rounding level -- both sides ~2e-7 -- are exempt from the ratio)
+            r["ratio_to_cpu32"] = r["gpu_vs_f64"] / r["cpu32_vs_f64"]
             bad[k] = r
     return bad

@@ -70,6 +70,45 @@ def test_conv3x3_fwd_bwd_vs_fp64_oracle(shape):
     assert max(errs.values()) < 1e-5, errs   # what fp32 Winograd delivers here; a regression shows long before 1e-3
 
 
+K128_SHAPES = [
+    (1, 32, 0, 128, 256, 256),    # 512 workgroups of 128 channels: the one-wave-per-SIMD kernel by its own rule, two chunks
+    (2, 64, 64, 256, 130, 132),   # two inputs, two channel blocks, ragged tile blocks (33 x 5 per image, last ones partial)
+    (1, 48, 0, 128, 6, 64),       # forced onto a small grid: an odd number of chunks, one tile-block row
+]
+
+
+@pytest.mark.parametrize("shape", K128_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_conv3x3_128_channel_kernel_vs_fp64_oracle_and_equals_64_channel_kernel(shape, monkeypatch):
+    """Round 6: wino_conv128_kernel (128 output channels per workgroup, one wave per SIMD, 16 accumulator tiles per wave) serves the
+    forward and the data gradient of grids with at least two rounds of workgroups (conv_out, cabinet.py:160).  It contracts the
+    channels in the order of the 64-channel kernel -- chunk by chunk, k-step by k-step on one fma chain per output -- so outputs,
+    gradients and the BatchNorm partials of its epilogue must equal that kernel's BIT FOR BIT, and the fp64 oracle to 1e-5."""
+    from cabinet_amd import _lib
+    from cabinet_amd.functional import conv3x3_bwd_hip, conv3x3_fwd_hip
+
+    B, C0, C1, K, H, W = shape
+    x0, x1, w, dy = _case(*shape, seed=23)
+    y_ref, dx_ref, dw_ref = _oracle(x0, x1, w, dy)
+    d = lambda t: t.cuda() if t is not None else None  # noqa: E731
+    nblk = _lib.load().cabinet_conv3x3_tile_blocks(B, H, W)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CABINET_WINO_128", flag)
+        part = torch.full((2, K, nblk), float("nan"), device="cuda")
+        y = conv3x3_fwd_hip(d(x0), d(x1), d(w), bn_part=part)
+        res[flag] = (y, part) + tuple(conv3x3_bwd_hip(d(dy), d(x0), d(x1), d(w)))
+    torch.cuda.synchronize()
+    y, part, dx0, dx1, dw = res["1"]
+    errs = {"y": rel(y, y_ref), "dx0": rel(dx0, dx_ref[:, :C0]), "dw": rel(dw, dw_ref)}
+    if C1:
+        errs["dx1"] = rel(dx1, dx_ref[:, C0:])
+    assert max(errs.values()) < 1e-5, errs
+    assert torch.isfinite(part).all()
+    for a, b, name in zip(res["1"], res["0"], ("y", "bn_part", "dx0", "dx1", "dw")):
+        if a is not None:
+            assert torch.equal(a, b), f"{name}: the 128-channel kernel's bits differ from the 64-channel kernel's (rel {rel(a, b):.2e})"
+
+
 def test_conv3x3_autograd_function_matches_stock_module_and_skips_unneeded_grads():
     """The autograd wrapper the model uses, against nn.Conv2d's own autograd in fp64 on the host; weight-only and input-only
     gradient requests run only their half."""

@@ -57,7 +57,10 @@ def _insitu(mode, batch, height, width, ncls, tag):
     assert not bad, {k: {n: (f"{v:.2e}" if isinstance(v, float) else v) for n, v in r.items()} for k, r in bad.items()}
     # 2 + 20 CAB, 3 + 5 FFM, 4 fusion-head BatchNorm, 2 loss heads, 10 K11 (conva: out dw dx; b1: out dw dx dx1; conv_out.conv: out dw dx),
     # 8 K12 (ab.b4: out weight bias; conv_out.conv_out: out weight; conv_out's BatchNorm with the operator's own mask: dx weight bias)
-    assert len(rows) == 2 + 20 + 3 + 5 + 4 + 2 + 10 + 8, sorted(rows)
+    # + 4 FFM rows under the kernels' own ReLU mask (round 6)
+    assert len(rows) == 2 + 20 + 3 + 5 + 4 + 4 + 2 + 10 + 8, sorted(rows)
+    # the FFM re-decides borderline ReLU units in double (ffm.hip): its mask is the fp64 forward's
+    assert rows["ffm.dfsp_own_mask"]["flipped_units_vs_f64_mask"] <= 1, rows["ffm.dfsp_own_mask"]
 
 
 @pytest.mark.timeout(1800)

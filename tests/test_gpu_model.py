@@ -89,6 +89,43 @@ def test_model_known_answers_from_reference(mode):
     assert abs(total - t["global_grad_norm"]) < TOL * t["global_grad_norm"]
 
 
+@pytest.mark.parametrize("mode", ["small", "large"])
+def test_step_is_bit_reproducible_in_the_parity_session(mode):
+    """The step behind test_model_known_answers_from_reference (KAT3 recipe, reference train.py:429-441), three times from one
+    state_dict: every logit and every gradient bit-identical.  The hand-written kernels sum in fixed orders (asserted per
+    operator); what made the WHOLE step -- and with it the verdict of every model-level parity test -- depend on the run was a
+    stock convolution solver with atomics in the spatial branch's forward (tools/diag_step_determinism.py,
+    profiles/r06_step_determinism.txt); tests/conftest.py pins MIOpen to its deterministic solvers for this session."""
+    from cabinet_amd.train import TrainStep, build_model, make_criteria
+
+    assert torch.backends.cudnn.deterministic, "tests/conftest.py pins the deterministic solvers for GPU sessions"
+    kat = json.load(open(os.path.join(GOLDEN, "kat_model.json")))[mode]
+    t = kat["train"]
+    net = build_model(mode, n_classes=8, seed=kat["model_seed"], freeze_unused=False, device="cuda")
+    with torch.no_grad():
+        net.ab.a2block.gamma.fill_(t["gamma"])
+    net.train()
+    sd0 = copy.deepcopy(net.state_dict())
+    torch.manual_seed(t["data_seed"])
+    x = torch.randn(*t["shape"]).cuda()
+    lb = torch.randint(0, 8, (t["shape"][0], t["shape"][2], t["shape"][3])).cuda()
+    runs = []
+    for _ in range(3):
+        net.load_state_dict(sd0)
+        low, low16 = net.forward_lowres(x)
+        net.load_state_dict(sd0)
+        step = TrainStep(net, make_criteria(t["shape"][0], t["shape"][2], t["shape"][3], "cuda"))
+        loss = step(x, lb)
+        torch.cuda.synchronize()
+        runs.append((low.detach().clone(), low16.detach().clone(), float(loss),
+                     {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
+    for r in runs[1:]:
+        assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]), "forward logits differ between repeats"
+        assert r[2] == runs[0][2]
+        moved = [k for k, g in r[3].items() if not torch.equal(g, runs[0][3][k])]
+        assert not moved, f"{len(moved)} of {len(r[3])} gradient tensors differ between repeats: {moved[:6]}"
+
+
 @pytest.mark.parametrize("mode,batch,size,ncls", [("small", 4, 512, 8),      # BASELINE config 2
                                                  ("large", 2, 512, 19)])
 def test_model_vs_oracle_logits_and_grads(mode, batch, size, ncls):
