@@ -93,6 +93,10 @@ def parse():
                     "(plain FFM without the fused upsample, single-head OHEM)")
     ap.add_argument("--no-graph", action="store_true", help="single GPU: enqueue every step eagerly instead of replaying "
                     "the step's two captured hipGraphs")
+    ap.add_argument("--eval", action="store_true", help="time the forward-only path evaluate.py consumes (.eval(), no_grad, BatchNorm on "
+                    "running statistics, full-resolution logits) instead of the training step; one JSON line of its own")
+    ap.add_argument("--no-eval-forward", action="store_true", help="skip the forward-only measurement that the training line carries "
+                    "as `eval_forward`")
     args = ap.parse_args()
     args.height = args.height or args.size
     args.width = args.width or args.size
@@ -253,6 +257,11 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
     # round 4: no statistics pass), read z (pool), read z + write out (gate); low resolution: read low, write + read y_low
     by_f = 4.0 * B * (P * (Cs + 4 * Co) + Pl * (Cc + 2 * Co))
     yield ("ffm_up_fwd (K3': resize fused, conv commuted to low res)", upf, fl_f, by_f, "hbm")
+    # the same operator as evaluate.py runs it (BatchNorm on running statistics, SURVEY 8(d) "eval-mode fwd"): this build keeps the
+    # training pass structure (z written, pooled, gated), so the bytes are the training forward's; SURVEY's floor for a BN-folded
+    # forward is read fsp + write feat + read feat + write out = 4 B P (Cs + 3 Co) (603 MB at config 3 with the materialised fcp)
+    upe = lambda: Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, False, 0.1, 1e-5)  # noqa: E731
+    yield ("ffm_up_fwd_eval (K3' in eval mode: BatchNorm on running statistics; the path evaluate.py:77 consumes)", upe, fl_f, by_f, "hbm")
     for code, name in ((Fh.PREC_BF16X6, "bf16x6"), (Fh.PREC_BF16X3, "bf16x3")):
         yield (f"ffm_up_fwd_{name} (K3' with z = W_s fsp + U(W_c low) on the bf16 matrix pipe, operands split while staged)",
                lambda c=code: Fh.ffm_up_fwd_hip(fsp, low, wb, bw, bb, rm, rv, w1, w2, True, 0.1, 1e-5, c), fl_f, by_f, "hbm")
@@ -497,6 +506,85 @@ def kernel_rooflines(batch, height, width, classes, iters, extra=False):
     return out
 
 
+def time_eval_forward(net, im, steps, warmup):
+    """The path the reference's evaluator consumes (evaluate.py:77 `model(crop)[0]`; ema.py:44 `deepcopy(model).eval()`): forward only,
+    `.eval()` (BatchNorm on running statistics), `torch.no_grad()`, full-resolution logits.  -> dict with the eager time (what the
+    unmodified script pays, host dispatch included) and the time of the same forward replayed from ONE hipGraph."""
+    import copy
+
+    net_e = copy.deepcopy(net).eval()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    res = {}
+    with torch.no_grad():
+        for _ in range(max(2, warmup)):
+            out = net_e(im)[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = net_e(im)[0]
+        torch.cuda.synchronize()
+        res["eager_ms"] = (time.perf_counter() - t0) / steps * 1e3
+        try:
+            s_im = im.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                s_out = net_e(s_im)[0]
+            graph.replay()
+            torch.cuda.synchronize()
+            start.record()
+            for _ in range(steps):
+                graph.replay()
+            stop.record()
+            torch.cuda.synchronize()
+            res["graph_ms"] = start.elapsed_time(stop) / steps
+            # not bitwise: bench.py leaves MIOpen its default solvers, and some of the backbone's convolutions sum with atomics
+            res["graph_vs_eager_rel"] = float((s_out.double() - out.double()).norm() / out.double().norm().clamp_min(1e-30))
+            del graph
+        except Exception as e:  # noqa: BLE001
+            res["graph_ms"] = None
+            res["graph_error"] = f"{type(e).__name__}: {e}"
+    res["finite"] = bool(torch.isfinite(out).all())
+    res["out_shape"] = list(out.shape)
+    return res
+
+
+def eval_line(args, net, im, dev):
+    """`--eval`: one JSON line for the forward-only path (the `no_grad` / `.eval()` path evaluate.py:77 uses)."""
+    H, W = args.height, args.width
+    net.train()
+    with torch.no_grad():   # running statistics of a freshly initialised model describe nothing: let BatchNorm see this input first
+        for _ in range(12):
+            net.forward_lowres(im)
+    torch.cuda.synchronize()
+    r = time_eval_forward(net, im, args.steps, args.warmup)
+    ms = r["graph_ms"] if r.get("graph_ms") else r["eager_ms"]
+    ks = kernel_rooflines(args.batch, H, W, args.classes, args.kernel_iters, False) if not args.no_kernel_roofline else []
+    fe = [k for k in ks if k["kernel"].startswith("ffm_up_fwd_eval")]
+    k1 = [k for k in ks if k["kernel"].startswith("cab_attn_fwd ")]
+    out = {
+        "metric": f"{H}x{W} images/sec forward only, eval mode (CABiNet-MobileNetV3-{args.mode.capitalize()})",
+        "value": round(args.batch / (ms * 1e-3), 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": (f"CABiNet-MobileNetV3-{args.mode.capitalize()}, {args.batch}x3x{H}x{W} synthetic, {args.classes} classes, "
+                                "forward only: .eval() + torch.no_grad(), BatchNorm on running statistics (populated by 12 training-mode "
+                                "forwards of this input), full-resolution logits model(x)[0] as evaluate.py:77 consumes them"),
+                   "host_path": "one captured hipGraph per forward" if r.get("graph_ms") else "eager enqueue"},
+        "eager": {"ms_per_step": round(r["eager_ms"], 3), "value": round(args.batch / (r["eager_ms"] * 1e-3), 3),
+                  "what": "the same forward enqueued eagerly (what the reference's unmodified evaluate.py pays: host dispatch included)"},
+        "forward": r,
+        "context_only": {"reference_published_inference_fps": {"76 FPS": "Cityscapes, RTX 2080 Ti", "8 FPS": "Jetson Xavier NX",
+                                                               "15 FPS": "UAVid, hardware not stated"},
+                         "source": "reference .github/CHANGELOG.md:61-63 (other hardware, other input sizes: not a baseline for this line)"},
+    }
+    if fe:
+        out["roofline"] = {k: fe[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_mfma", "frac_hbm") if k in fe[0]}
+        out["roofline"].update(kernel=fe[0]["kernel"], ms_per_launch=fe[0]["ms_per_launch"], algorithmic_mbytes=fe[0]["algorithmic_mbytes"])
+    if k1:
+        out["cab_attn_fwd"] = {k: k1[0][k] for k in ("kernel", "ms_per_launch", "bound", "achieved", "peak", "unit", "frac")}
+    return out
+
+
 def main():
     args = parse()
     t_start = time.perf_counter()
@@ -510,6 +598,20 @@ def main():
     # is answered from the kernel driver's device node
     if not os.path.exists("/dev/kfd"):
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # the library that gets timed must be the one the sources in this tree describe (and the one the PMC profiles were digest-checked
+    # against): cabinet_amd/build.py stamps the library with the digest of csrc/ + include/ at build time (VERDICT r05 hygiene)
+    from cabinet_amd import build as _build
+    if not _build.is_fresh():
+        # never time a stale library: local rank 0 rebuilds it from the sources in this tree, the other ranks wait for its stamp
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            print("[bench] libcabinet_hip.so is stale or missing: rebuilding it from the sources in this tree", file=sys.stderr, flush=True)
+            _build.build(verbose=False)   # raises when hipcc is missing or a source does not compile
+        else:
+            t_wait = time.perf_counter()
+            while not _build.is_fresh():
+                if time.perf_counter() - t_wait > 1200:
+                    raise SystemExit("bench.py: cabinet_amd/libcabinet_hip.so is stale and local rank 0 did not rebuild it")
+                time.sleep(2.0)
     if args.kernels_only:
         for r in kernel_rooflines(args.batch, args.height, args.width, args.classes, args.kernel_iters, args.all_kernels):
             print(f"{r['kernel'][:52]:52s} {r['ms_per_launch'] * 1e3:9.1f} us  {r['tflops']:7.2f} TF/s  "
@@ -540,6 +642,11 @@ def main():
         reducer = BucketedGradReducer(net, always_reduce=True) if ddp else None
         step = TrainStep(net, crit, reducer=reducer, optimizer=opt)
     im, lb = synthetic_batch(args.batch, args.height, args.width, args.classes, dev, seed=1 + rank)
+    if args.eval:
+        if world != 1:
+            raise SystemExit("--eval times one GPU")
+        print(json.dumps(eval_line(args, net, im, dev)), flush=True)
+        return
 
     def sync():
         if ddp:
@@ -563,10 +670,14 @@ def main():
         loss = step(im, lb)
     sync()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if ddp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+        # every rank's own wall time of the K steps (the line's `value` uses the maximum): what a reader needs to see a straggler
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank_ms = [float(x) / args.steps * 1e3 for x in every]
+        dt = max(float(x) for x in every)
     final_loss = float(loss)
     log(f"timed region {dt:.3f}s -> {world * args.batch * args.steps / dt:.2f} images/s")
     # SURVEY.md section 8(d) words the metric as forward + 2x OHEM-CE + backward; `value` above also contains the gradient
@@ -616,14 +727,32 @@ def main():
                               else "two captured hipGraphs per step around the one OHEM read-back (GraphedTrainStep)"
                               if graphed else "eager enqueue (TrainStep)"),
                 "dist_backend": torch.distributed.get_backend() if ddp else None,
+                "ranks_in_process_group": torch.distributed.get_world_size() if ddp else None,
+                "per_rank_ms_per_step": ({"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3),
+                                          "all": [round(x, 3) for x in per_rank_ms]} if per_rank_ms else None),
+                "ddp_schedule": getattr(step, "schedule", None) if ddp else None,
                 "cpu_affinity": ddp_mod.AFFINITY if world > 1 else None,
             },
+            "library": {"source_digest": _build.source_digest()[:16], "fresh": _build.is_fresh(),
+                        "what": "sha256 of cabinet_amd/csrc/* + include/cabinet_hip.h; the loaded libcabinet_hip.so carries this stamp"},
             "final_loss": round(final_loss, 5),
             "fwd_loss_bwd_only": {"value": round(images / dt_nopt, 3), "unit": "images/s",
                                   "ms_per_step": round(dt_nopt / args.steps * 1e3, 3),
                                   "what": "the same K steps without the SGD step (forward + 2x OHEM-CE + backward"
                                           + (" + gradient all-reduce)" if ddp else ")")},
         }
+    if rank == 0 and world == 1 and not args.no_eval_forward:
+        # the forward-only path of evaluate.py:77 on the model that was just timed (its BatchNorm running statistics have seen
+        # warmup + steps batches): .eval() + no_grad, full-resolution logits; `python bench.py --eval` prints
+        # this as a line of its own
+        r = time_eval_forward(net, im, max(5, args.steps // 2), 2)
+        ms = r["graph_ms"] if r.get("graph_ms") else r["eager_ms"]
+        result["eval_forward"] = {"value": round(args.batch / (ms * 1e-3), 3), "unit": "images/s", "ms_per_step": round(ms, 3),
+                                  "eager_ms_per_step": round(r["eager_ms"], 3), "graph_vs_eager_rel": r.get("graph_vs_eager_rel"),
+                                  "what": "forward only, .eval() + torch.no_grad(), BatchNorm on running statistics, model(x)[0] at "
+                                          "full resolution (evaluate.py:77), one hipGraph per forward; eager_ms_per_step = the "
+                                          "same forward through the Python dispatch"}
+        log(f"eval forward: {ms:.2f} ms/batch graphed, {r['eager_ms']:.2f} eager")
     # ---- per-kernel rooflines and CPU baseline: rank 0, outside the timed region -----------------
     if rank == 0 and not args.no_kernel_roofline:
         del step, opt
@@ -631,11 +760,26 @@ def main():
         ks = kernel_rooflines(args.batch, args.height, args.width, args.classes, args.kernel_iters, args.all_kernels)
         log("kernel rooflines measured")
         result["kernels"] = ks
+        # what the SURVEY section 8 path costs inside the step: the groups the step launches (not the plain K1 where the fused-projection
+        # form runs, not the split-bf16 variants, not --all-kernels extras), once each -- next to ms_per_step, so that `value` is not
+        # read as a statement about these kernels alone (section 8 is ~18 % of the step; the backbone / spatial branch on
+        # stock PyTorch-ROCm operators and K7-K10 are the rest)
+        in_step = [r for r in ks if r["scope"] == "SURVEY section 8" and "_bf16x" not in r["kernel"].split(" ")[0]
+                   and not r["kernel"].startswith(("ffm_fwd ", "ffm_bwd ", "ohem_up_fwd ", "ohem_up_bwd ", "ffm_up_fwd_eval"))]
+        if any(r["kernel"].startswith("cab_attn_proj_fwd") for r in in_step):
+            in_step = [r for r in in_step if not r["kernel"].startswith("cab_attn_fwd ")]
+        hot = sum(r["ms_per_launch"] for r in in_step)
+        result["hot_path_ms_per_step"] = {"value": round(hot, 3), "share_of_step": round(hot / result["ms_per_step"], 3),
+                                          "groups": [r["kernel"].split(" ")[0] for r in in_step],
+                                          "what": "sum of the SURVEY section 8 kernel groups the step launches (standalone graph-replay "
+                                                  "timings, once each); the rest of ms_per_step is the MobileNetV3 backbone and the "
+                                                  "spatial branch, which north_star leaves on PyTorch-ROCm"}
         # `roofline` = the CAB affinity+aggregate kernel the north_star sets its MFMA target on; next to it the
         # longest-running hand-written group INSIDE SURVEY section 8 (the hot path's dominant cost) and, for context, the
         # longest group overall (an out-of-scope backbone operator)
         k1 = ks[0]
-        s8 = [r for r in ks if r["scope"] == "SURVEY section 8" and "_bf16x" not in r["kernel"].split(" ")[0]]
+        s8 = [r for r in ks if r["scope"] == "SURVEY section 8" and "_bf16x" not in r["kernel"].split(" ")[0]
+              and not r["kernel"].startswith("ffm_up_fwd_eval")]
         dom8 = max(s8, key=lambda r: r["ms_per_launch"])
         dom = max(ks, key=lambda r: r["ms_per_launch"])
         result["roofline"] = {k: k1[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}

@@ -440,19 +440,274 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
 // ---- round 6: 128 output channels per workgroup at ONE wave per SIMD ---------------------------------------
 // The 64-channel kernel above stops at 0.66-0.72 of the fp32 MFMA peak because, per chunk, every wave issues ~70 other instructions
 // (patch loads, B^T d B, LDS stores / operand reads, filter loads) for 32 MFMAs, and on gfx950 those add up serially with the fp32
-// MFMAs (see the loop comment there).  With 256 threads a wave may hold 512 registers: 4 xi x 4 channel blocks = 16 accumulator
-// tiles (256 registers, in the AGPR half) per wave, i.e. a workgroup owns 128 output channels x 32 tiles for all 16 xi.  Per chunk
-// and wave: 128 MFMAs beside 2 patches (10 loads, 88 VALU, 16 LDS stores), 32 filter loads and 16 LDS operand reads -- the
-// transform, V traffic and x traffic per MFMA halve (x is fetched once per 128-channel block: 2x instead of 4x for K = 256).  There
-// is no partner wave to cover a wait, so everything a block of 32 MFMAs needs is requested one block ahead:
-//   block x (xi = 4 wave + x) of chunk n:   filter loads of block x+1, LDS operand reads of block x+1, 32 MFMAs, and
-//     x = 0: B^T d B of patch A of chunk n+1 and its 16 LDS stores      x = 1: the same for patch B
-//     x = 2: the loads of patch A of chunk n+2, then the chunk's one barrier (V[n+1] complete, every read of V[n] done)
-//     x = 3: the loads of patch B of chunk n+2; its operand reads are the first of chunk n+1
+// MFMAs (see the loop comment there).  With 256 threads a wave may hold 512 registers: 16 accumulator tiles (256 registers, the
+// AGPR half) per wave, so a workgroup owns 128 output channels x 32 tiles for all 16 xi and, per chunk and wave, issues 128 MFMAs
+// beside 2 patches (10 loads, 88 VALU, 8 LDS stores), 32 filter loads and 32 LDS operand reads: transform, V traffic and x traffic
+// per MFMA halve (x is fetched once per 128-channel block: 2x instead of 4x for K = 256).
+//   * A wave owns 32 CHANNELS for ALL 16 xi (not 4 xi for all channels): a lane then holds, for its tile and 16 channel rows, every
+//     xi of the product -- the output transform Y = A^T M A runs in registers, the epilogue needs no LDS and no barrier, and the V
+//     ring survives it.  V is staged as [channel][tile][16 xi] (pitch 20 floats: the 8-lane groups of a 16-byte LDS access cover
+//     all 32 banks once): a thread stores its patch's 16 values as four ds_write_b128, a wave reads the four xi of a group and one
+//     k-step as ONE ds_read_b128.
+//   * Persistent over tile blocks: a workgroup walks a contiguous range of the (channel block, tile block) list, and the software
+//     pipeline runs THROUGH the tile boundary -- the last chunk of a tile transforms and stores the first patches of the next
+//     tile, requests its second chunk and its first filters -- so only the first tile of a workgroup pays the load latency of a
+//     prologue (one wave per SIMD: there is no partner to cover it).
+//   * per chunk, four groups of 4 xi (32 MFMAs each); everything a group needs is requested one group ahead:
+//       group g:  filter loads of group g+1, LDS operand reads of group g+1, 32 MFMAs, and
+//       g = 0: B^T d B of patch A of the next chunk + its 4 LDS stores     g = 1: the same for patch B
+//       g = 2: the loads of patch A two chunks ahead, then the chunk's one barrier (V of the next chunk complete)
+//       g = 3: the loads of patch B two chunks ahead; its operand reads are the first of the next chunk
+// Contracts the channels in the order of the 64-channel kernel (one fma chain per output, chunk by chunk, k-step by k-step) and
+// evaluates the same output-transform expressions: outputs and BatchNorm partials are bit-identical to that kernel's (tested).
 // Used for grids of at least two rounds of workgroups (conv_out at configs 3 and 5); the attention branch's convolutions (64 or
 // 128 tile blocks) keep the 64- / 32-channel kernel.  W even and 8-byte aligned inputs only (the paired patch loads).
 constexpr int WN_KB2 = 128;
+constexpr int WN_VP = 20;                              // floats per (channel, tile) of the staged V: 16 xi + 4 of padding
+constexpr int WN_VBUF2 = WN_CC * WN_TB * WN_VP;        // one staged chunk: 40 KB
 
+__global__ __launch_bounds__(256) void wino_conv128p_kernel(WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // V ring: [2][16 ch][32 tiles][20]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3, a scalar
+    const int HW = a.H * a.W, C = a.C0 + a.C1, nch = C / WN_CC, nch0 = a.C0 / WN_CC;
+    const int per_img = a.nby * a.nbx, total = a.ntb * a.nkb;   // a.nkb = K / 128
+    const int wg = xcd_chunked_tile(blockIdx.x, gridDim.x);
+    const int t_lo = (int)((long long)wg * total / gridDim.x), t_hi = (int)((long long)(wg + 1) * total / gridDim.x);
+    if (t_lo >= t_hi) return;
+    const int cw = 2 * wave + h;   // channel of patch A inside a chunk; patch B = cw + 8 (scalar offset)
+
+    // ---- a tile of the list: the channel block is the slow index (an XCD works on one slice of U at a time) ----------------------
+    struct Tile {
+        int kblk, tb, b, by, bx;
+        int poff[5];   // per-lane byte offsets of the paired patch loads (rows 0..3, halo), zero padding = WN_OOB
+    };
+    auto make_tile = [&](int tau) {
+        Tile t;
+        t.kblk = tau / a.ntb, t.tb = tau - t.kblk * a.ntb;
+        t.b = t.tb / per_img;
+        const int rem = t.tb - t.b * per_img;
+        t.by = rem / a.nbx, t.bx = rem - t.by * a.nbx;
+        const int ty = 2 * t.by + (li >> 4), tx = 16 * t.bx + (li & 15);
+        const int tt = li & 15, hr = tt & 3, r = 2 * ty - 1 + hr;
+        const int hc = tt < 4 ? 32 * t.bx - 1 : (tt >= 12 ? 32 * t.bx + 32 : -1);
+        t.poff[4] = ((unsigned)r < (unsigned)a.H && (unsigned)hc < (unsigned)a.W) ? (cw * HW + r * a.W + hc) * 4 : WN_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = 2 * ty - 1 + i;
+            t.poff[i] = ((unsigned)rr < (unsigned)a.H && 2 * tx < a.W) ? (cw * HW + rr * a.W + 2 * tx) * 4 : WN_OOB;
+        }
+        return t;
+    };
+    Tile tc = make_tile(t_lo), tn = make_tile(min(t_lo + 1, t_hi - 1));   // this tile, the next one (the last tile prefetches itself)
+
+    float pdA[16], pdB[16];   // pd[4 i + 1], pd[4 i + 2] = the pair of row i, pd[0] = this lane's halo value; patch_ready() fills the rest
+    // chunk n of tile t (n in [0, nch)): 16 channels of x0 or x1 of image t.b
+    auto load_patch = [&](float (&pd)[16], const Tile& t, int n, int which) {
+        const bool first = n < nch0;   // wave-uniform
+        const float* base = first ? a.x0 + (size_t)t.b * a.C0 * HW : a.x1 + (size_t)t.b * a.C1 * HW;
+        const buf_rsrc rx = make_rsrc(base, (unsigned)((size_t)(first ? a.C0 : a.C1) * HW * 4));
+        const int soff = ((first ? n : n - nch0) * WN_CC + 8 * which) * HW * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 pr = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rx, t.poff[i], soff, 0));
+            pd[4 * i + 1] = pr[0], pd[4 * i + 2] = pr[1];
+        }
+        pd[0] = bload(rx, t.poff[4], soff);
+    };
+    auto patch_ready = [&](float (&pd)[16]) {   // see wino_conv_kernel<PAIR>
+        const int hv = __builtin_bit_cast(int, pd[0]);
+        const int hq[4] = {__builtin_amdgcn_update_dpp(0, hv, 0x00, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0x55, 0xF, 0xF, true),
+                           __builtin_amdgcn_update_dpp(0, hv, 0xAA, 0xF, 0xF, true), __builtin_amdgcn_update_dpp(0, hv, 0xFF, 0xF, 0xF, true)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int halo = hq[i];
+            const int left = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, pd[4 * i + 2]), 0x111, 0xF, 0xF, false);   // row_shr:1
+            const int right = __builtin_amdgcn_update_dpp(halo, __builtin_bit_cast(int, pd[4 * i + 1]), 0x101, 0xF, 0xF, false);  // row_shl:1
+            pd[4 * i] = __builtin_bit_cast(float, left), pd[4 * i + 3] = __builtin_bit_cast(float, right);
+        }
+    };
+    auto transform_store = [&](float (&pd)[16], int buf, int which) {
+        float v[16];
+        patch_ready(pd);
+        wino_bt_d_b(pd, v);
+        float* dst = smem + buf * WN_VBUF2 + ((cw + 8 * which) * WN_TB + li) * WN_VP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    };
+
+    // ---- A operand: U rows of the wave's 32 channels, the 4 xi of group g, two half chunks; one 16-byte load = four k-steps -------
+    const int ng = C >> 3, nrb = a.K >> 5;
+    const buf_rsrc ru = make_rsrc(a.u, (unsigned)((size_t)16 * a.K * C * 4));
+    auto load_u = [&](f32x4 (&dst)[4][2], int kblk, int g, int n) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int base = (((4 * g + x) * nrb + 4 * kblk + wave) * ng + 2 * n) * 1024;
+#pragma unroll
+            for (int hc = 0; hc < 2; ++hc) dst[x][hc] = bload4(ru, lane * 16, base + hc * 1024);
+        }
+    };
+    // B operand of group g: k-step s contracts channels 2 s + h; one 16-byte read = the group's four xi
+    auto read_v = [&](f32x4 (&dst)[8], int buf, int g) {
+        const float* vb = smem + buf * WN_VBUF2 + (h * WN_TB + li) * WN_VP + 4 * g;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dst[s] = *reinterpret_cast<const f32x4*>(vb + 2 * s * WN_TB * WN_VP);
+    };
+    f32x16 acc[16];   // [xi]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    };
+    zero_acc();
+    f32x4 u0[4][2], u1[4][2], v0[8], v1[8];
+#define WN_MFMA_GROUP(G, UU, VV)                                                                                       \
+    _Pragma("unroll") for (int hc = 0; hc < 2; ++hc) _Pragma("unroll") for (int s = 0; s < 4; ++s)                     \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) acc[4 * (G) + x] = mfma32(UU[x][hc][s], VV[4 * hc + s][x], acc[4 * (G) + x]);
+#define WN_PIN(n, mask, per)                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+        __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                        \
+    }
+    // chunk n of the current tile; positions past its last chunk continue in the next tile (selects, no branches: one basic block)
+    auto chunk = [&](int n, int buf) {
+        const bool w1 = n + 1 >= nch, w2 = n + 2 >= nch;   // scalars
+        const int n1 = w1 ? 0 : n + 1, n2 = w2 ? n + 2 - nch : n + 2;
+        const int kb1 = w1 ? tn.kblk : tc.kblk;
+        Tile t2;   // the tile of the patches requested in this chunk
+        t2.b = w2 ? tn.b : tc.b;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) t2.poff[i] = w2 ? tn.poff[i] : tc.poff[i];
+        // ---- group 0
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(u1, tc.kblk, 1, n);
+        read_v(v1, buf, 1);
+        transform_store(pdA, buf ^ 1, 0);
+        WN_MFMA_GROUP(0, u0, v0)
+        WN_PIN(8, 0x020, 1)     // 8 filter loads
+        WN_PIN(8, 0x100, 1)     // 8 LDS operand reads
+        WN_PIN(12, 0x002, 4)    // 12 DPP moves + 32 additions
+        WN_PIN(4, 0x200, 1)     // 4 LDS stores
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- group 1
+        load_u(u0, tc.kblk, 2, n);
+        read_v(v0, buf, 2);
+        transform_store(pdB, buf ^ 1, 1);
+        WN_MFMA_GROUP(1, u1, v1)
+        WN_PIN(8, 0x020, 1)
+        WN_PIN(8, 0x100, 1)
+        WN_PIN(12, 0x002, 4)
+        WN_PIN(4, 0x200, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- group 2: patch A two chunks ahead; the chunk's barrier
+        load_u(u1, tc.kblk, 3, n);
+        read_v(v1, buf, 3);
+        load_patch(pdA, t2, n2, 0);
+        WN_MFMA_GROUP(2, u0, v0)
+        WN_PIN(13, 0x020, 1)
+        WN_PIN(8, 0x100, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // V of the next chunk is complete; every read of this chunk's V has returned
+        // ---- group 3: first operands of the next chunk, patch B two chunks ahead
+        load_u(u0, kb1, 0, n1);
+        read_v(v0, buf ^ 1, 0);
+        load_patch(pdB, t2, n2, 1);
+        WN_MFMA_GROUP(3, u1, v1)
+        WN_PIN(13, 0x020, 1)
+        WN_PIN(8, 0x100, 1)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- prologue of the workgroup's first tile
+    load_patch(pdA, tc, 0, 0);
+    load_patch(pdB, tc, 0, 1);
+    load_u(u0, tc.kblk, 0, 0);
+    transform_store(pdA, 0, 0);
+    transform_store(pdB, 0, 1);
+    load_patch(pdA, tc, 1, 0);   // nch >= 4 (C % 64 == 0)
+    load_patch(pdB, tc, 1, 1);
+    __syncthreads();
+    read_v(v0, 0, 0);
+
+    const int t = li, oty_in = li >> 4, otx_in = li & 15;
+    (void)t;
+    for (int tau = t_lo; tau < t_hi; ++tau) {
+        // ONE chunk per iteration, the V buffer chosen by a scalar (nch is a multiple of 4: the parity restarts with every tile): a
+        // second, conditional copy of the body puts 256 accumulator registers through a phi, and with all 256 AGPRs taken the copies
+        // go through scratch (181 spilled registers; this form: none)
+        for (int n = 0; n < nch; ++n) chunk(n, n & 1);
+        // ---- epilogue in registers: Y = A^T M A for this lane's tile and its 16 channel rows ------------------------------------
+        {
+            const int k0 = tc.kblk * WN_KB2 + 32 * wave;   // first channel of the wave's rows
+            float* ybase;
+            int krow0, kimg;
+            if (k0 < a.K0) ybase = a.y0, krow0 = k0, kimg = a.K0;   // K0 % 64 == 0: a wave's 32 channels lie on one side
+            else ybase = a.y1, krow0 = k0 - a.K0, kimg = a.K - a.K0;
+            const int oy = 2 * (2 * tc.by + oty_in), ox = 2 * (16 * tc.bx + otx_in);
+            const bool vx = ox < a.W;   // W is even: both columns of the tile are inside, or none
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = acc_row(r) + 4 * h;   // channel row of the wave's block
+                float m[16];
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) m[xi] = acc[xi][r];
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = (m[j] + m[4 + j]) + m[8 + j];
+                    s1[j] = (m[4 + j] - m[8 + j]) - m[12 + j];
+                }
+                float o[2][2];
+                o[0][0] = (s0[0] + s0[1]) + s0[2], o[0][1] = (s0[1] - s0[2]) - s0[3];
+                o[1][0] = (s1[0] + s1[1]) + s1[2], o[1][1] = (s1[1] - s1[2]) - s1[3];
+                float* yp = ybase + ((size_t)tc.b * kimg + krow0 + kk) * HW;
+                float cnt = 0.f, sum = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    if (oy + rr < a.H && vx) {
+                        float* p = yp + (size_t)(oy + rr) * a.W + ox;
+                        f32x2 val = {o[rr][0], o[rr][1]};
+                        if (a.accumulate) {
+                            const f32x2 old = *reinterpret_cast<const f32x2*>(p);
+                            val[0] += old[0], val[1] += old[1], o[rr][0] = val[0], o[rr][1] = val[1];
+                        }
+                        *reinterpret_cast<f32x2*>(p) = val;
+                        cnt += 1.f, sum += o[rr][0];
+                        cnt += 1.f, sum += o[rr][1];
+                    }
+                }
+                if (a.stat_part) {   // (mean, M2) of the block's valid outputs of this channel: the 64-channel kernel's order, same bits
+                    const float n_blk = half_sum(cnt), mean = half_sum(sum) / fmaxf(n_blk, 1.f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+                        if (oy + rr < a.H && vx) {
+                            m2 += (o[rr][0] - mean) * (o[rr][0] - mean);
+                            m2 += (o[rr][1] - mean) * (o[rr][1] - mean);
+                        }
+                    m2 = half_sum(m2);
+                    if (li == 0) {
+                        a.stat_part[(size_t)(k0 + kk) * a.ntb + tc.tb] = mean;
+                        a.stat_part[((size_t)a.K + k0 + kk) * a.ntb + tc.tb] = m2;
+                    }
+                }
+            }
+        }
+        zero_acc();
+        tc = tn;
+        tn = make_tile(min(tau + 2, t_hi - 1));
+    }
+#undef WN_PIN
+#undef WN_MFMA_GROUP
+}
+
+// ---- the form that ships (round 6): 128 channels per workgroup, one wave per SIMD, wave w owns xi = 4 w .. 4 w + 3 for all four
+// 32-channel blocks; V staged as in the 64-channel kernel ([xi][channel][tile]); one tile block per workgroup; the epilogue meets in
+// LDS in two halves of 64 channels.  Measured on one box, conv_out of config 3 (tools/time_conv3x3.py): 581 / 579 us forward / data
+// gradient (0.752 / 0.755 of the fp32 MFMA peak) against 607 / 596 us for the 64-channel kernel; the persistent all-xi-per-wave form
+// above (wino_conv128p_kernel: register epilogue, pipeline through the tile boundary): 629 / 621 us -- every wave reads the WHOLE
+// staged V there (4x the LDS read volume) and the register epilogue of 16 channel rows per lane runs with no other wave beside
+// it; kept behind CABINET_WINO_128=2 with its bit-equality test.
 __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // V: [2][16 xi][16 ch][32 tiles]; epilogue: M [16][64][32], twice
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
@@ -541,9 +796,12 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
         __builtin_amdgcn_sched_group_barrier((mask), (per), 0);                                                        \
     }
+    // per chunk, four blocks of 32 MFMAs (block x: xi = 4 wave + x); everything a block needs is requested one block ahead:
+    //   block 0: U / V of block 1, B^T d B of patch A of chunk n+1 and its 16 LDS stores     block 1: the same for patch B
+    //   block 2: the loads of patch A of chunk n+2, then the chunk's one barrier (V[n+1] complete, every read of V[n] done)
+    //   block 3: the loads of patch B of chunk n+2; its operand reads are the first of chunk n+1
     auto chunk = [&](int n, int buf) {
         const int n1 = min(n + 1, nch - 1), n2 = min(n + 2, nch - 1);
-        // ---- block 0: U / V of block 1 requested; patch A of chunk n+1 transformed and stored
         __builtin_amdgcn_sched_barrier(0);
         load_u(u1, 1, n);
         read_v(v1, buf, 1);
@@ -554,7 +812,6 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
         WN_PIN(16, 0x002, 3)    // 12 DPP moves + 32 additions
         WN_PIN(4, 0x200, 4)     // 16 LDS stores (ds_write2st64: 8)
         __builtin_amdgcn_sched_barrier(0);
-        // ---- block 1: the same for patch B
         load_u(u0, 2, n);
         read_v(v0, buf, 2);
         transform_store(pdB, buf ^ 1, 1);
@@ -564,7 +821,6 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
         WN_PIN(16, 0x002, 3)
         WN_PIN(4, 0x200, 4)
         __builtin_amdgcn_sched_barrier(0);
-        // ---- block 2: patch A of chunk n+2 requested (two blocks ahead of the wait that covers it); the chunk's barrier
         load_u(u1, 3, n);
         read_v(v1, buf, 3);
         load_patch(pdA, n2, 0);
@@ -573,7 +829,6 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
         WN_PIN(4, 0x100, 2)
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // V[n+1] is complete; every read of V[n] has returned
-        // ---- block 3: first operands of chunk n+1, patch B of chunk n+2 requested
         load_u(u0, 0, n1);
         read_v(v0, buf ^ 1, 0);
         load_patch(pdB, n2, 1);
@@ -582,7 +837,6 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
         WN_PIN(4, 0x100, 2)
         __builtin_amdgcn_sched_barrier(0);
     };
-    // ---- prologue
     load_patch(pdA, 0, 0);
     load_patch(pdB, 0, 1);
     load_u(u0, 0, 0);
@@ -647,7 +901,8 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
                         val[0] += old[0], val[1] += old[1], o[r][0] = val[0], o[r][1] = val[1];
                     }
                     *reinterpret_cast<f32x2*>(p) = val;
-                    cnt += 2.f, sum += o[r][0], sum += o[r][1];
+                    cnt += 1.f, sum += o[r][0];
+                    cnt += 1.f, sum += o[r][1];
                 }
             }
             if (a.stat_part) {   // (mean, M2) of the block's valid outputs of channel kk (as wino_conv_kernel: same order, same bits)
@@ -1021,8 +1276,22 @@ static hipError_t wino_conv_run(const float* x0, const float* x1, const float* u
         const bool aligned8 = ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(x1)) & 7) == 0;
         const bool can = (W & 1) == 0 && aligned8 && (K % WN_KB2) == 0 && (K0 % 64) == 0;
         const int wgs = a.ntb * (K / WN_KB2);
-        if (can && k128_env != 0 && (k128_env == 1 || wgs >= 512)) {
+        if (can && k128_env != 0 && (k128_env == 1 || k128_env == 2 || wgs >= 512)) {
             a.nkb = K / WN_KB2;
+            if (k128_env == 2) {   // the persistent all-xi-per-wave form (measured slower; kept for A/B and its test)
+                static lds_attr_mask mask128p{0};
+                if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv128p_kernel), 160 * 1024, mask128p); e != hipSuccess)
+                    return e;
+                int cus = 256;
+                {
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                        cus = prop.multiProcessorCount;
+                }
+                hipLaunchKernelGGL(wino_conv128p_kernel, dim3(wgs < cus ? wgs : cus), dim3(256), (size_t)2 * WN_VBUF2 * sizeof(float), stream, a);
+                return hipGetLastError();
+            }
             static lds_attr_mask mask128{0};
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(wino_conv128_kernel), 160 * 1024, mask128); e != hipSuccess)
                 return e;

@@ -663,7 +663,7 @@ void bn_finalize(const double* stat_part, int ntiles, int C, int nch, long long 
 // 16.8 M) units whose pre-activation lies within the fp32 product's rounding error (1.9e-7 abs on |z| ~ 0.8) of zero and lands on
 // the other side -- the fp32 CPU reference flips 3 (1) others.  A unit that close to the boundary is decided by rounding noise in
 // ANY fp32 implementation, and each one toggles a whole gradient column; so this pass, the first that knows the batch mean,
-// re-decides exactly those units: where |pre| < 2^-17 (|gamma| + |beta|) (about 200 of 33.5 M elements at config 3) the wave
+// re-decides exactly those units: where |pre| < 2^-17 ((|mean| invstd + 1) |gamma| + |beta|) (about 200 of 33.5 M elements at config 3) the wave
 // recomputes z = W [fsp; U(low)] for that one unit in double from the operator's inputs (24 loads per lane, a wave sum), takes
 // the decision from (z64 - mean64) invstd64 gamma + beta in double, and stores the fp32 z nearest to z64 for which the kernels'
 // own expression fmaf((z - mean) invstd, gamma, beta) > 0 -- the one every FFM kernel, forward and backward, evaluates -- gives
@@ -780,7 +780,10 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(float* __restrict__ z, Bn
     // relu(bn(z)) as EVERY FFM kernel evaluates it (ffm_gate_kernel, the backward's reduction, adjoint and product kernels):
     // pre = fmaf((z - mean) invstd, gamma, beta) -- no cancellation against a folded shift, and one expression for one mask
     const float gw = bn_w[c], gb = bn_b[c];
-    const float thr = ex.fsp ? 0x1p-17f * (fabsf(gw) + fabsf(gb)) : -1.f;
+    // the band in which a unit counts as borderline, in units of the pre-activation: the fp32 product's error is relative to |z|, i.e.
+    // to |mean| + a few sigma, while the decision is taken in sigma units -- a channel whose mean is many sigma wide of zero needs a
+    // band that much wider (round 6: Large 2x512^2 flipped a unit of such a channel at 1e-5 sigma with a band of 7.6e-6 sigma)
+    const float thr = ex.fsp ? 0x1p-17f * ((fabsf(mu) * inv + 1.f) * fabsf(gw) + fabsf(gb)) : -1.f;
     float* zr = z + (size_t)row * P;
     float acc = 0.f;
     int budget = FFM_EXACT_CAP;   // per wave: wave-uniform

@@ -237,6 +237,176 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(const SgJobs jobs) {
     }
 }
 
+// ---- round 6: the FAST form with a quarter / half of the LDS operand reads ------------------------------------
+// sg_gemm_kernel<MB, true> above reads TWO dwords from LDS per MFMA (one per operand and k-step: 32 ds_read_b32 for the 16 MFMAs of
+// a chunk at MB = 1), and on gfx950 those issue slots add up with the fp32 MFMAs of the three or four waves that share a SIMD
+// (20.8 us for the 1.6 GFLOP of the q / k / v projections: 0.49 of the matrix peak; five launches of this kernel per step).
+// Which two k an MFMA step contracts is free as long as A and B agree, so step s takes k = s from lanes 0-31 and k = 16 + s from
+// lanes 32-63: the 16 values a lane needs of an operand are then
+//   * 16 CONSECUTIVE floats of its row when the operand is stored with the contracted index contiguous (a weight as PyTorch
+//     stores it: M-major A): image [row][32 k], pitch 36 (8-lane groups of a ds_read_b128 / ds_write_b128
+//     cover all 32 banks once) -- four 16-byte reads per chunk, written with 16-byte stores exactly as loaded (the old form
+//     transposed such an operand with scalar stores);
+//   * 16 rows 64 (or 128) floats apart when the operand is stored k-major (an activation (K, P), a weight used transposed):
+//     image [k][row], pitch = the tile width, read in pairs by ds_read2st64_b32 -- eight reads per chunk.
+// 8 .. 16 LDS reads per chunk and operand pair instead of 32; same loaders, same epilogues, same tile -> workgroup mapping.
+constexpr int SG_KP = 36;
+
+template <int MB>
+__global__ __launch_bounds__(256) void sg_gemm_fast_kernel(const SgJobs jobs) {
+    constexpr int MT = SG_T * MB;
+    constexpr int A_FLOATS = MT * SG_KP, B_FLOATS = SG_BK * SG_T;   // SG_KP >= SG_BK: either A image fits
+    __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].tile_base) ++ji;
+    const SgJob& J = jobs.j[ji];
+    int t = blockIdx.x - J.tile_base;
+    const int nt = t % J.tiles_n;
+    t /= J.tiles_n;
+    const int mt = t % J.tiles_m, b = t / J.tiles_m;
+    const int m0 = mt * MT, p0 = nt * SG_T, M = J.M, lda = J.lda, ldp = J.ldp;
+    const bool am = J.a_mmajor != 0;   // workgroup-uniform (B is k-major here: sg_gemm keeps position-major B jobs on the round-3 kernel)
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    f32x4 ra[2 * MB], rb[2];
+    int offA[2 * MB], offB[2];
+    float biasv[2 * MB];
+    const float* apc = nullptr;
+    const float* bpc = nullptr;
+    int seg_cur = 0, seg_left = 0;
+    const int stepA = am ? SG_BK : SG_BK * lda, stepB = SG_BK * ldp;
+    auto open_segment = [&](int sgi) {
+        seg_cur = sgi, seg_left = J.nck[sgi];
+        apc = J.seg[sgi].a + (size_t)b * J.a_img_stride;
+        bpc = J.seg[sgi].b + (size_t)b * J.seg[sgi].b_rows * ldp;
+    };
+#pragma unroll
+    for (int i = 0; i < 2 * MB; ++i) {
+        const int idx = tid + i * 256;
+        offA[i] = am ? (m0 + (idx >> 3)) * lda + (idx & 7) * 4 : (idx / (MT / 4)) * lda + m0 + (idx % (MT / 4)) * 4;
+        biasv[i] = (am && J.a_bias) ? J.a_bias[(size_t)b * M + m0 + (idx >> 3)] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256;
+        offB[i] = (idx >> 4) * ldp + p0 + (idx & 15) * 4;
+    }
+    open_segment(0);
+    auto load_next = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2 * MB; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4*>(apc + offA[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[i][e] -= biasv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bpc + offB[i]);
+        apc += stepA, bpc += stepB;
+        if (--seg_left == 0 && seg_cur + 1 < J.nseg) open_segment(seg_cur + 1);
+    };
+    auto store_chunk = [&](int buf) {   // every operand is written as it was loaded: 16-byte stores, no transposition
+#pragma unroll
+        for (int i = 0; i < 2 * MB; ++i) {
+            const int idx = tid + i * 256;
+            float* d = am ? &As[buf][(idx >> 3) * SG_KP + (idx & 7) * 4] : &As[buf][(idx / (MT / 4)) * MT + (idx % (MT / 4)) * 4];
+            *reinterpret_cast<f32x4*>(d) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;
+            float* d = &Bs[buf][(idx >> 4) * SG_T + (idx & 15) * 4];
+            *reinterpret_cast<f32x4*>(d) = rb[i];
+        }
+    };
+    const int nchunks = J.nck[0] + J.nck[1] + J.nck[2];
+    load_next();
+    store_chunk(0);
+    __syncthreads();
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int buf = ci & 1;
+        if (ci + 1 < nchunks) load_next();
+        float av[MB][16], bv[16];
+        if (am) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const float* r = &As[buf][(mb * 64 + wm * 32 + li) * SG_KP + 16 * h];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(r + 4 * q);
+                    av[mb][4 * q] = v[0], av[mb][4 * q + 1] = v[1], av[mb][4 * q + 2] = v[2], av[mb][4 * q + 3] = v[3];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const float* r = &As[buf][16 * h * MT + mb * 64 + wm * 32 + li];
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) av[mb][s2] = r[s2 * MT];
+            }
+        }
+        {
+            const float* r = &Bs[buf][16 * h * SG_T + wn * 32 + li];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) bv[s2] = r[s2 * SG_T];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = mfma32(av[mb][s2], bv[s2], acc[mb]);
+        if (ci + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* dst = J.dst + (size_t)b * J.dst_rows * ldp;
+    const int p = p0 + wn * 32 + li;
+    const float alpha = J.alpha != 0.f ? J.alpha : 1.f;
+    const float* ob = J.out_bias;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mb * 64 + wm * 32 + acc_row(r) + 4 * h;
+            dst[(size_t)m * ldp + p] = ob ? fmaf(acc[mb][r], alpha, ob[m]) : acc[mb][r] * alpha;
+        }
+    // statistics epilogue: as sg_gemm_kernel<MB, true> (the operand ring is dead behind the loop's last barrier)
+    if (J.stat != nullptr) {
+        constexpr int TP = 65;
+        float* T = &As[0][0];
+        static_assert(2 * A_FLOATS >= MT * TP, "the tile must fit the A ring");
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                T[(mb * 64 + wm * 32 + acc_row(r) + 4 * h) * TP + wn * 32 + li] = acc[mb][r] * alpha;
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int row = mb * 64 + (tid >> 2), seg = tid & 3;
+            const float* tr = T + row * TP;
+            const float pivot = tr[0];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float d = tr[seg * 16 + j] - pivot;
+                s1 += d, s2 = fmaf(d, d, s2);
+            }
+            s1 += __shfl_xor(s1, 1, 64), s2 += __shfl_xor(s2, 1, 64);
+            s1 += __shfl_xor(s1, 2, 64), s2 += __shfl_xor(s2, 2, 64);
+            if (seg == 0) {
+                const float mean_d = s1 * (1.f / 64.f);
+                f32x2 o = {pivot + mean_d, fmaxf(s2 - s1 * mean_d, 0.f)};
+                *reinterpret_cast<f32x2*>(J.stat + (((size_t)(m0 + row) * jobs.B + b) * J.tiles_n + nt) * 2) = o;
+            }
+        }
+    }
+}
+
 const char* sg_gemm_unsupported(const SgJob& j) {
     if (j.lda & 3) return "lda % 4 == 0";
     for (int s = 0; s < j.nseg; ++s)
@@ -267,16 +437,23 @@ bool sg_gemm(SgJobs& jobs, int B, hipStream_t stream, int mb) {
         if (j.a_img_stride & 3) f = false;
         fast = fast && f;
     }
-    auto kernel = mb == 2 ? (fast ? sg_gemm_kernel<2, true> : sg_gemm_kernel<2, false>)
-                          : (fast ? sg_gemm_kernel<1, true> : sg_gemm_kernel<1, false>);
+    // CABINET_SG_KCONTIG=0: the round-3 FAST kernel (two LDS dwords per MFMA) for A/B timing
+    static const bool kc_env = [] { const char* e = getenv("CABINET_SG_KCONTIG"); return !(e && e[0] == '0'); }();
+    bool kcontig = kc_env;
+    for (int i = 0; i < jobs.n; ++i) kcontig = kcontig && !jobs.j[i].b_pmajor;   // no caller stages a position-major B today
+    auto kernel = mb == 2 ? (fast ? (kcontig ? sg_gemm_fast_kernel<2> : sg_gemm_kernel<2, true>) : sg_gemm_kernel<2, false>)
+                          : (fast ? (kcontig ? sg_gemm_fast_kernel<1> : sg_gemm_kernel<1, true>) : sg_gemm_kernel<1, false>);
     hipLaunchKernelGGL(kernel, dim3(base), dim3(256), 0, stream, jobs);
     return fast;
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradients
 __global__ __launch_bounds__(256) void sd_dw_kernel(const SdJobs jobs, float* __restrict__ part, int B) {
-    __shared__ float Az[2][SG_T * SD_STR];
-    __shared__ float Bx[2][SG_T * SD_STR];
+    // round 6: both operands have the contracted index (the position) contiguous, so both images are [row][32 p] at pitch SG_KP,
+    // written with the 16-byte pieces as loaded and read as four ds_read_b128 per operand and chunk (step s contracts p = s in
+    // lanes 0-31 and p = 16 + s in lanes 32-63; see sg_gemm_fast_kernel): 8 LDS reads per 16 MFMAs where stride-33 images took 32
+    __shared__ __attribute__((aligned(16))) float Az[2][SG_T * SG_KP];
+    __shared__ __attribute__((aligned(16))) float Bx[2][SG_T * SG_KP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     int ji = 0;
@@ -323,11 +500,8 @@ __global__ __launch_bounds__(256) void sd_dw_kernel(const SdJobs jobs, float* __
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * 256, row = idx >> 3, col = (idx & 7) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Az[buf][row * SD_STR + col + e] = rz[i][e];
-                Bx[buf][row * SD_STR + col + e] = rx[i][e];
-            }
+            *reinterpret_cast<f32x4*>(&Az[buf][row * SG_KP + col]) = rz[i];
+            *reinterpret_cast<f32x4*>(&Bx[buf][row * SG_KP + col]) = rx[i];
         }
     };
     if (chunk_lo < chunk_hi) {
@@ -338,10 +512,15 @@ __global__ __launch_bounds__(256) void sd_dw_kernel(const SdJobs jobs, float* __
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         const int buf = (chunk - chunk_lo) & 1;
         if (chunk + 1 < chunk_hi) load_chunk(chunk + 1);
-        const float* Ab = &Az[buf][(wm * 32 + li) * SD_STR + h];
-        const float* Bb = &Bx[buf][(wn * 32 + li) * SD_STR + h];
+        const float* Ab = &Az[buf][(wm * 32 + li) * SG_KP + 16 * h];
+        const float* Bb = &Bx[buf][(wn * 32 + li) * SG_KP + 16 * h];
+        f32x4 av[4], bv[4];
 #pragma unroll
-        for (int kk = 0; kk < SG_BK; kk += 2) acc = mfma32(Ab[kk], Bb[kk], acc);
+        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f32x4*>(Ab + 4 * q), bv[q] = *reinterpret_cast<const f32x4*>(Bb + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(av[q][e], bv[q][e], acc);
         if (chunk + 1 < chunk_hi) store_chunk(buf ^ 1);
         __syncthreads();
     }

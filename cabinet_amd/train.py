@@ -318,6 +318,39 @@ class GraphedTrainStep:
         return loss
 
 
+# ---- which replay schedule GraphedDDPStep takes (round 6) -----------------------------------------------------
+# Measured on one GPU (profiles/r05_ddp_gap_probe.txt): an event record between the backward graphs is free and a side stream that
+# waits for the event behind B1 (decoder) is free, but ANY stream that waits for the event between B2 (backbone) and B3 (spatial
+# branch) costs the compute stream 0.3-0.4 ms -- that boundary then drains instead of letting B3's first kernels start under B2's last.
+# Dropping that event exposes the backbone's buckets (12.6 MB) behind B3 instead of hiding them under the spatial branch's backward.
+# Which is cheaper depends on what those buckets cost on the wire, so the choice is taken from a model of the all-reduce and printed
+# (bench.py: config.ddp_schedule); CABINET_DDP_ONE_EVENT=1 / 0 overrides it for a node that can measure both.
+DDP_DRAIN_MS = 0.35            # measured cost of the second event's wait (one MI355X, config 3)
+XGMI_LINK_GBS_PER_DIR = 76.8   # 153.6 GB/s per link, both directions (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+RCCL_LINK_EFFICIENCY = 0.5     # share of the link rate a <= 8 MB bucket reaches (latency-bound messages); conservative
+RCCL_LAUNCH_MS = 0.02          # per collective
+
+
+def choose_ddp_schedule(world, exposed_bytes, n_buckets=2):
+    """-> dict(one_event, exposed_ms, drain_ms, ...): ring all-reduce of `exposed_bytes` over min(world - 1, 7) rings, one xGMI link
+    each (point-to-point fabric: a ring is bound by ONE link per hop), against the measured drain of the second event."""
+    forced = os.environ.get("CABINET_DDP_ONE_EVENT")
+    rings = max(1, min(world - 1, 7))
+    if world > 1:
+        wire = 2.0 * (world - 1) / world * (exposed_bytes / rings) / (RCCL_LINK_EFFICIENCY * XGMI_LINK_GBS_PER_DIR * 1e9) * 1e3
+    else:
+        wire = 0.0   # one-rank "collectives" are local copies
+    exposed = wire + n_buckets * RCCL_LAUNCH_MS
+    one = exposed < DDP_DRAIN_MS
+    why = "model"
+    if forced in ("0", "1"):
+        one, why = forced == "1", "CABINET_DDP_ONE_EVENT=" + forced
+    return dict(one_event=bool(one), decided_by=why, world=world, exposed_mbytes=round(exposed_bytes / 2 ** 20, 2), rings=rings,
+                exposed_ms_model=round(exposed, 3), drain_ms_measured=DDP_DRAIN_MS,
+                what=("backbone buckets behind B3 on the compute stream (exposed), decoder buckets on the side stream behind B1"
+                      if one else "decoder buckets behind B1 and backbone buckets behind B2, both on the side stream (two events)"))
+
+
 class GraphedDDPStep:
     """Data-parallel step for one node of MI355X: hipGraph segments with the gradient all-reduces issued BETWEEN them.
 
@@ -397,12 +430,12 @@ class GraphedDDPStep:
         self.fallbacks = self._calls = 0
         # side stream + events that order the collectives behind the graph segments (replay path, RCCL only);
         # CABINET_DDP_INLINE_REDUCE=1 keeps round 4's issue order (A/B timing)
-        import os as _os
-
         self._side, self._ev = None, None
-        if self.use_graphs and dev.type == "cuda" and _os.environ.get("CABINET_DDP_INLINE_REDUCE") != "1":
+        if self.use_graphs and dev.type == "cuda" and os.environ.get("CABINET_DDP_INLINE_REDUCE") != "1":
             self._side = torch.cuda.Stream(device=dev)
             self._ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self.schedule = choose_ddp_schedule(self.world, sum(f.numel() * 4 for f in self.segments[1]), len(self.segments[1]))
+        self.schedule["side_stream"] = self._side is not None and self.backend == "nccl"
 
     # ---- the pieces of one step (run eagerly, or recorded once and replayed) ----
     def _clear(self):
@@ -567,7 +600,7 @@ class GraphedDDPStep:
             # ~0.3-0.4 ms (the B2 | B3 boundary then drains instead of overlapping).  CABINET_DDP_ONE_EVENT=1 drops that event and
             # issues the backbone's buckets behind B3 on the compute stream instead (12.6 MB exposed instead of overlapped with the
             # spatial branch's backward): which one wins at 8 GPUs is for a node that has them to measure.
-            one_event = os.environ.get("CABINET_DDP_ONE_EVENT") == "1"
+            one_event = self.schedule["one_event"]
             gB1.replay()
             self._ev[0].record(cur)
             gB2.replay()

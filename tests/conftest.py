@@ -31,6 +31,16 @@ if os.path.isdir(_MIOPEN_DB) and "MIOPEN_USER_DB_PATH" not in os.environ:
         pass
 
 
+# Round 6: a convolution whose shape is NOT in that database (every test shape that is not a bench shape) made MIOpen's default find
+# mode time the applicable solvers on the spot and keep the fastest -- so which solver ran, and with it the bits of the spatial
+# branch's forward, depended on what the process (or the box) had done before: tools/diag_order_dependence.py gives exactly two
+# sets of digests for one step, {fresh process, after a Small step} and {after large allocations, after other FFM / K11 calls}, and
+# `test_model_vs_oracle_logits_and_grads[large-2-512-19]` passed in one test order and failed in another on the same box
+# (profiles/r06_order_dependence.txt).  FAST find mode takes a database hit when there is one and MIOpen's static heuristics when
+# there is none: no timing, no history.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

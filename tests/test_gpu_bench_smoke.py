@@ -75,6 +75,13 @@ def test_bench_main_with_eight_ranks_on_one_gpu():
     assert r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp8" and r["config"]["dist_backend"] == "gloo"
     assert "GraphedDDPStep" in r["config"]["host_path"] and len(r["config"]["grad_buckets_mb"]) >= 3
     assert r["value"] > 0 and math.isfinite(r["final_loss"])
+    # round 6: what a reader needs to trust an N > 1 line without a profiler -- ranks of the process group, every rank's own time
+    # (the line's value uses the maximum), the replay schedule GraphedDDPStep chose and why
+    c = r["config"]
+    assert c["ranks_in_process_group"] == 8 and len(c["per_rank_ms_per_step"]["all"]) == 8
+    assert abs(c["per_rank_ms_per_step"]["max"] - r["ms_per_step"]) < 1e-2 * r["ms_per_step"]
+    assert c["ddp_schedule"]["world"] == 8 and c["ddp_schedule"]["decided_by"] == "model" and c["ddp_schedule"]["one_event"] is True
+    assert r["library"]["fresh"] is True and len(r["library"]["source_digest"]) == 16
 
 
 @pytest.mark.timeout(1200)
@@ -100,3 +107,35 @@ def test_bench_main_with_two_ranks_on_one_gpu():
     assert "GraphedDDPStep" in r["config"]["host_path"]
     assert r["value"] > 0 and math.isfinite(r["final_loss"]) and r["ms_per_step"] > 0
     assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-2 * r["value"]  # whole-job images / max-over-ranks time
+    assert r["config"]["ranks_in_process_group"] == 2 and len(r["config"]["per_rank_ms_per_step"]["all"]) == 2
+    assert r["config"]["ddp_schedule"]["world"] == 2 and "exposed_ms_model" in r["config"]["ddp_schedule"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_eval_line_and_training_line_fields():
+    """`bench.py --eval` (round 6): the forward-only path evaluate.py:77 consumes -- .eval(), no_grad, BatchNorm on
+    running statistics, full-resolution logits -- as a JSON line of its own; and the training line's round-6 fields at a small size:
+    `eval_forward`, `hot_path_ms_per_step` (the section-8 groups the step launches, once each), `library` (digest of the sources the
+    loaded library was built from), both roofs per matrix group."""
+    env = dict(os.environ)
+    env.pop("MIOPEN_USER_DB_PATH", None)
+    env.pop("MIOPEN_CUSTOM_CACHE_DIR", None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "2", "--size", "256",
+            "--no-cpu-baseline", "--kernel-iters", "4"]
+    out = subprocess.run(base + ["--eval"], env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    e = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert "forward only" in e["metric"] and e["unit"] == "images/s" and e["value"] > 0 and e["n_gpus"] == 1
+    assert e["forward"]["finite"] and e["forward"]["out_shape"] == [2, 8, 256, 256]
+    assert e["forward"]["graph_ms"] is None or e["forward"]["graph_vs_eager_rel"] < 1e-4
+    assert e["roofline"]["kernel"].startswith("ffm_up_fwd_eval") and "evaluate.py:77" in e["config"]["workload"]
+    out = subprocess.run(base, env=env, capture_output=True, text=True, timeout=800, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert r["eval_forward"]["value"] > 0 and r["eval_forward"]["ms_per_step"] > 0
+    hp = r["hot_path_ms_per_step"]
+    assert 0 < hp["value"] and 0 < hp["share_of_step"] and "conv3x3_out_fwd" in hp["groups"] and "cab_attn_fwd_bf16x6" not in hp["groups"]
+    assert not any(g.startswith("ffm_up_fwd_eval") for g in hp["groups"])
+    assert r["library"]["fresh"] is True
+    ffm = [k for k in r["kernels"] if k["kernel"].startswith(("ffm_up_fwd ", "ffm_up_bwd "))]
+    assert len(ffm) == 2 and all("frac_mfma" in k and "frac_hbm" in k and k["frac"] == max(k["frac_mfma"], k["frac_hbm"]) for k in ffm)

@@ -71,9 +71,9 @@ def test_conv3x3_fwd_bwd_vs_fp64_oracle(shape):
 
 
 K128_SHAPES = [
-    (1, 32, 0, 128, 256, 256),    # 512 workgroups of 128 channels: the one-wave-per-SIMD kernel by its own rule, two chunks
+    (1, 64, 0, 128, 256, 256),    # 512 workgroups of 128 channels: the one-wave-per-SIMD kernel by its own rule
     (2, 64, 64, 256, 130, 132),   # two inputs, two channel blocks, ragged tile blocks (33 x 5 per image, last ones partial)
-    (1, 48, 0, 128, 6, 64),       # forced onto a small grid: an odd number of chunks, one tile-block row
+    (1, 192, 0, 128, 6, 64),      # forced onto a small grid: one tile-block row and a half, twelve chunks
 ]
 
 
@@ -92,7 +92,7 @@ def test_conv3x3_128_channel_kernel_vs_fp64_oracle_and_equals_64_channel_kernel(
     d = lambda t: t.cuda() if t is not None else None  # noqa: E731
     nblk = _lib.load().cabinet_conv3x3_tile_blocks(B, H, W)
     res = {}
-    for flag in ("1", "0"):
+    for flag in ("1", "2", "0"):   # 1: the 128-channel kernel; 2: its persistent all-xi-per-wave form (measured slower, kept); 0: 64 channels
         monkeypatch.setenv("CABINET_WINO_128", flag)
         part = torch.full((2, K, nblk), float("nan"), device="cuda")
         y = conv3x3_fwd_hip(d(x0), d(x1), d(w), bn_part=part)
@@ -104,9 +104,10 @@ def test_conv3x3_128_channel_kernel_vs_fp64_oracle_and_equals_64_channel_kernel(
         errs["dx1"] = rel(dx1, dx_ref[:, C0:])
     assert max(errs.values()) < 1e-5, errs
     assert torch.isfinite(part).all()
-    for a, b, name in zip(res["1"], res["0"], ("y", "bn_part", "dx0", "dx1", "dw")):
-        if a is not None:
-            assert torch.equal(a, b), f"{name}: the 128-channel kernel's bits differ from the 64-channel kernel's (rel {rel(a, b):.2e})"
+    for flag in ("1", "2"):
+        for a, b, name in zip(res[flag], res["0"], ("y", "bn_part", "dx0", "dx1", "dw")):
+            if a is not None:
+                assert torch.equal(a, b), f"{name}: CABINET_WINO_128={flag} differs from the 64-channel kernel's bits (rel {rel(a, b):.2e})"
 
 
 def test_conv3x3_autograd_function_matches_stock_module_and_skips_unneeded_grads():

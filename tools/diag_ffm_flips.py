@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     mode, batch, height, width, ncls = {3: ("large", 8, 1024, 1024, 8), 5: ("large", 2, 2048, 1024, 19),
-                                        2: ("small", 4, 512, 512, 8)}[a.config]
+                                        2: ("small", 4, 512, 512, 8), 6: ("large", 2, 512, 512, 19)}[a.config]
     from insitu import instrument, own_relu_output
     from cabinet_amd import functional as Fn
     from cabinet_amd.loss import ohem_upsampled_pair
@@ -105,6 +105,14 @@ def main():
     own = own_relu_output(z, mean, invstd, bw, bb) > 0
     m64 = r64["mask"]
     res["flips_own_mask"] = int((own != m64).sum())
+    # where the remaining flips sit: channel, |pre| of the fp64 forward, |mean| / sigma of the channel (the fp32 product's error is
+    # relative to |z| ~ |mean| + sigma, the decision band to sigma)
+    fl = (own != m64).nonzero()
+    res["flipped_units"] = [dict(b=int(i[0]), c=int(i[1]), y=int(i[2]), x=int(i[3]), pre64=float(r64["pre"][tuple(i)]),
+                                 z_gpu_minus_z64=float(z[tuple(i)].double() - r64["z"][tuple(i)]),
+                                 mean_over_sigma=float(r64["mean"][int(i[1])] * r64["invstd"][int(i[1])])) for i in fl[:16]]
+    ms = (r64["mean"] * r64["invstd"]).abs()
+    res["channels_mean_over_sigma"] = dict(max=float(ms.max()), median=float(ms.median()))
 
     def mask_of(zz):   # this z under fp64 statistics and fp64 arithmetic: what z's error alone flips
         pre = (zz.double() - r64["mean"].view(1, -1, 1, 1)) * r64["invstd"].view(1, -1, 1, 1) * bw.double().view(1, -1, 1, 1) \

@@ -46,6 +46,11 @@ def step(mode, batch, size, ncls, capture=True):
     im, lb = synthetic_batch(batch, size, size, ncls, "cpu", seed=1)
     net = net.cuda().train()
     cap = instrument(net) if capture else {}
+    if capture:   # the spatial branch layer by layer (stock convolutions behind K9 / K7): where does a difference start?
+        for name in ("conv1", "conv2", "conv3", "conv_out"):
+            blk = getattr(net.sb, name)
+            blk.conv.register_forward_hook(lambda m, a, o, n=name: cap.__setitem__("sb." + n + ".conv", o.detach().clone()))
+            blk.register_forward_hook(lambda m, a, o, n=name: cap.__setitem__("sb." + n, o.detach().clone()))
     crit = make_criteria(batch, size, size, "cuda")
     out, out16 = net(im.cuda())
     loss = crit[0](out, lb.cuda()) + crit[1](out16, lb.cuda())
