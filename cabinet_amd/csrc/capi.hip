@@ -1021,7 +1021,7 @@ static int check_conv3x3(const cabinet::WinoShape& s, const char* who) {
     if (!cabinet::conv3x3_shape_ok(s))
         return fail(CABINET_ERR_UNSUPPORTED,
                     "%s: C0=%d C1=%d Co=%d H=%d W=%d (C0, C1 multiples of 16; Co, C0+C1 multiples of 64; C0 %% 64 == 0 when C1 > 0; "
-                    "one image's tensors < 2 GB)", who, s.C0, s.C1, s.K, s.H, s.W);
+                    "one image's tensors < 1 GiB)", who, s.C0, s.C1, s.K, s.H, s.W);
     return CABINET_OK;
 }
 

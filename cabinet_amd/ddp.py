@@ -270,7 +270,8 @@ def _parse_cpulist(text):
 def gpu_local_cpus(local_rank, sysfs="/sys/class/drm", visible=None):
     """CPUs of the NUMA node the ``local_rank``-th visible AMD GPU hangs off, read from sysfs WITHOUT touching the HIP runtime
     (``<sysfs>/card*/device/{vendor, numa_node, local_cpulist}``; GPUs ordered by PCI address, ``HIP_VISIBLE_DEVICES`` /
-    ``ROCR_VISIBLE_DEVICES`` index lists honoured).  Returns (cpu set | None, numa node | None)."""
+    ``ROCR_VISIBLE_DEVICES`` index lists honoured).  Returns (cpu set | None, numa node | None); ``gpu_local_cpus.pci`` holds the
+    PCI address of the card the answer was read from (set_rank_affinity records it for the later cross-check)."""
     import os
 
     cards = {}
@@ -296,6 +297,8 @@ def gpu_local_cpus(local_rank, sysfs="/sys/class/drm", visible=None):
     lists = [visible] if visible is not None else [os.environ.get("ROCR_VISIBLE_DEVICES"),
                                                      os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES"))]
     for vis in lists:
+        if vis is not None and vis.strip() == "" and visible is None:
+            return None, None   # an EMPTY visibility variable means "no devices" to the runtime: nothing to pin to
         if vis:
             try:
                 devs = [devs[int(i)] for i in vis.split(",") if i.strip() != ""]
@@ -303,8 +306,7 @@ def gpu_local_cpus(local_rank, sysfs="/sys/class/drm", visible=None):
                 return None, None  # UUID lists etc.: do not guess
     if not 0 <= local_rank < len(devs):
         return None, None
-    global _AFFINITY_PCI
-    _AFFINITY_PCI = os.path.basename(os.path.realpath(devs[local_rank]))  # cross-checked against the runtime's answer later
+    gpu_local_cpus.pci = os.path.basename(os.path.realpath(devs[local_rank]))
     try:
         node = int(open(os.path.join(devs[local_rank], "numa_node")).read().strip())
         cpus = _parse_cpulist(open(os.path.join(devs[local_rank], "local_cpulist")).read())
@@ -324,9 +326,12 @@ def check_affinity_device(device_index):
     if not AFFINITY.get("set") or _AFFINITY_PCI is None:
         return AFFINITY
     try:
-        bus = torch.cuda.get_device_properties(device_index).pci_bus_id
-        want = int(_AFFINITY_PCI.split(":")[1], 16)
-        AFFINITY["pci_matches_runtime"] = bool(int(bus) == want)
+        props = torch.cuda.get_device_properties(device_index)
+        dom, bus = _AFFINITY_PCI.split(":")[:2]   # "dddd:bb:dd.f"
+        ok = int(props.pci_bus_id) == int(bus, 16)
+        if hasattr(props, "pci_domain_id"):        # several PCI domains on one node: the bus byte alone is ambiguous
+            ok = ok and int(props.pci_domain_id) == int(dom, 16)
+        AFFINITY["pci_matches_runtime"] = bool(ok)
     except Exception as e:  # noqa: BLE001  (a property this build lacks: say so)
         AFFINITY["pci_matches_runtime"] = f"unknown ({type(e).__name__})"
     return AFFINITY
@@ -344,7 +349,10 @@ def set_rank_affinity(local_rank, sysfs="/sys/class/drm"):
     if os.environ.get("CABINET_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
         AFFINITY = {"set": False, "why": "disabled"}
         return AFFINITY
+    global _AFFINITY_PCI
+    gpu_local_cpus.pci = None
     cpus, node = gpu_local_cpus(local_rank, sysfs)
+    _AFFINITY_PCI = gpu_local_cpus.pci   # only this caller records the card for check_affinity_device
     if not cpus:
         AFFINITY = {"set": False, "why": "no NUMA information for this GPU in sysfs"}
         return AFFINITY

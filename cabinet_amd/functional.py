@@ -904,9 +904,15 @@ def conv1x1_bias_supported(x, conv):
 CONV3X3_ENABLED = _os.environ.get("CABINET_CONV3X3", "1") != "0"
 
 
-def conv3x3_supported(C0, C1, Co):
-    """True when K11 takes ``nn.Conv2d(C0 + C1, Co, 3, padding=1, bias=False)`` over inputs of C0 (+ C1) channels."""
-    return bool(_lib.load().cabinet_conv3x3_supported(int(C0), int(C1), int(Co)))
+def conv3x3_supported(C0, C1, Co, H=None, W=None):
+    """True when K11 takes ``nn.Conv2d(C0 + C1, Co, 3, padding=1, bias=False)`` over inputs of C0 (+ C1) channels -- and, when the
+    spatial size is given, over images of H x W: zero padding rides on the buffer range check, which keeps one image's tensors below
+    1 GiB (conv3x3_wino.hip: WN_OOB).  A layer past that limit takes the stock convolution instead of raising."""
+    if not _lib.load().cabinet_conv3x3_supported(int(C0), int(C1), int(Co)):
+        return False
+    if H is None or W is None:
+        return True
+    return 4 * max(int(C0), int(C1), int(Co)) * int(H) * int(W) < (1 << 30)
 
 
 def conv3x3_fwd_hip(x0, x1, weight, bn_part=None):

@@ -50,7 +50,7 @@ def _conv3x3_bn_relu(conv: nn.Conv2d, bn: nn.BatchNorm2d, x: torch.Tensor, x1: O
     batch statistics come out of the convolution's epilogue (no statistics pass over its output) -- else the stock convolution;
     K7 (BatchNorm + ReLU in one streaming pass) either way."""
     c1 = 0 if x1 is None else x1.shape[1]
-    if _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels):
+    if _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels, x.shape[2], x.shape[3]):
         part = conv3x3_bn_part(x, conv.out_channels) if bn.training else None
         return bn_act(conv3x3(x, conv.weight, x1, part), bn, "relu", conv_part=part)
     return bn_act(conv(x if x1 is None else torch.cat([x, x1], dim=1)), bn, "relu")
@@ -62,7 +62,7 @@ def _conv3x3_bn_relu_cls(conv: nn.Conv2d, bn: nn.BatchNorm2d, cls: nn.Conv2d, x:
     1x1 classifier as one streaming operator that never writes the (B, 256, H', W') activation or, in backward, its gradient
     (reference cabinet.py:88-92 and :160-172); shapes outside K12's coverage take K7 + the stock 1x1 convolution."""
     c1 = 0 if x1 is None else x1.shape[1]
-    if _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels):
+    if _functional.CONV3X3_ENABLED and _is_plain_3x3(conv) and conv3x3_supported(x.shape[1], c1, conv.out_channels, x.shape[2], x.shape[3]):
         part = conv3x3_bn_part(x, conv.out_channels) if bn.training else None
         return bn_relu_cls(conv3x3(x, conv.weight, x1, part), bn, cls, conv_part=part)
     return bn_relu_cls(conv(x if x1 is None else torch.cat([x, x1], dim=1)), bn, cls)

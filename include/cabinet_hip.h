@@ -474,7 +474,7 @@ int cabinet_pwconv_bwd(const float* dy, const float* x, const float* w, int B, i
  *     weight gradient (skipped when NULL); both Winograd too (the weight gradient contracts over tiles: F(3x3,2x2));
  *     ordered slab sums, no atomics: deterministic.
  * Supported (cabinet_conv3x3_supported): C0, C1 multiples of 16, Co and C0+C1 multiples of 64, C0 a multiple of 64 when C1 > 0;
- * any B, H, W (odd sizes masked) with one image's tensors below 2 GB.
+ * any B, H, W (odd sizes masked) with one image's tensors below 1 GiB (zero padding rides on the buffer range check).
  * ------------------------------------------------------------------------- */
 int cabinet_conv3x3_supported(int C0, int C1, int Co);
 int cabinet_conv3x3_tile_blocks(int B, int H, int W);

@@ -49,8 +49,8 @@ def test_visibility_lists_compose_and_cuda_alias_is_honoured(tmp_path, monkeypat
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,3,0")
     assert ddp.gpu_local_cpus(0, sysfs) == (set(range(8, 12)), 1)
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,2")          # of (2, 3, 0): cards 3 and 0
-    assert ddp.gpu_local_cpus(0, sysfs) == (set(range(12, 16)), 1) and ddp._AFFINITY_PCI == "0000:c5:00.0"
-    assert ddp.gpu_local_cpus(1, sysfs) == (set(range(0, 4)), 0) and ddp._AFFINITY_PCI == "0000:05:00.0"
+    assert ddp.gpu_local_cpus(0, sysfs) == (set(range(12, 16)), 1) and ddp.gpu_local_cpus.pci == "0000:c5:00.0"
+    assert ddp.gpu_local_cpus(1, sysfs) == (set(range(0, 4)), 0) and ddp.gpu_local_cpus.pci == "0000:05:00.0"
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "1")           # HIP honours the CUDA spelling too
@@ -76,3 +76,17 @@ def test_set_rank_affinity_pins_and_never_fails(tmp_path, monkeypatch):
     assert ddp.set_rank_affinity(5, sysfs)["set"] is False and os.sched_getaffinity(0) == set(allowed)   # no such GPU
     monkeypatch.setenv("CABINET_NO_AFFINITY", "1")
     assert ddp.set_rank_affinity(0, sysfs) == {"set": False, "why": "disabled"}
+
+
+def test_only_set_rank_affinity_records_the_card_and_an_empty_visibility_list_means_no_devices(tmp_path, monkeypatch):
+    """gpu_local_cpus() is a pure lookup (the card address travels as an attribute of the function, the module global
+    that check_affinity_device reads is written by set_rank_affinity alone), and an EMPTY HIP_VISIBLE_DEVICES -- "no devices" to the
+    runtime -- is not treated as "unset"."""
+    sysfs = _fake_sysfs(str(tmp_path), [("0000:05:00.0", 0, "0-3"), ("0001:05:00.0", 1, "4-7")])
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    before = ddp._AFFINITY_PCI
+    assert ddp.gpu_local_cpus(1, sysfs) == (set(range(4, 8)), 1) and ddp.gpu_local_cpus.pci == "0001:05:00.0"
+    assert ddp._AFFINITY_PCI == before   # two PCI domains, same bus byte: the address keeps its domain for the cross-check
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert ddp.gpu_local_cpus(0, sysfs) == (None, None)
