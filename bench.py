@@ -75,8 +75,8 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)   # >= 50 timed steps behind >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 3: 8)")
     ap.add_argument("--size", type=int, default=1024, help="square image side (BASELINE config 3: 1024)")
     ap.add_argument("--height", type=int, default=None, help="image height when not square (BASELINE config 5: "
@@ -143,7 +143,7 @@ def time_kernel(fn, iters, warm=3, reps=5):
     return start.elapsed_time(stop) / iters
 
 
-TRAFFIC_PROFILES = ("r05_pmc_traffic.json", "r05_config5_pmc_traffic.json")  # under profiles/: one per workload shape
+TRAFFIC_PROFILES = ("r06_pmc_traffic.json", "r06_config5_pmc_traffic.json")  # under profiles/: one per workload shape
 
 
 def load_traffic(batch, height, width, classes):

@@ -6,7 +6,7 @@
 # per workload: the bench JSON line (roofline + cpu_baseline), rocprofv3 kernel stats of the eager run of the same bench,
 # PMC HBM traffic and PMC issue counters of the section-8 kernel groups; config 3 also host overhead and the world-1 RCCL timeline.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
 C5="--height 2048 --width 1024 --batch 2 --classes 19"
@@ -17,6 +17,10 @@ python bench.py $C5 > $O/${TAG}_config5_bench_n1.json 2> $O/${TAG}_config5_bench
 tail -c 300 $O/${TAG}_config5_bench_n1.json
 python bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.log
 tail -c 300 $O/${TAG}_bench_n1.json
+# the forward-only (eval) line of both workloads (round 6: VERDICT r05 item 7)
+python bench.py --eval --no-kernel-roofline $C5 > $O/${TAG}_config5_bench_eval.json 2> /dev/null
+python bench.py --eval > $O/${TAG}_bench_eval.json 2> $O/${TAG}_bench_eval.log
+tail -c 300 $O/${TAG}_bench_eval.json
 export CABINET_FORCE_DDP=1
 python tools/host_overhead.py 2>&1 | grep -v "Warn\|^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids\|socket.cpp" > $O/${TAG}_host_overhead.txt
 cat $O/${TAG}_host_overhead.txt
@@ -35,8 +39,8 @@ cd $GRAFT_REPO_ROOT
 python tools/summarize_rocprof.py /tmp/prof_bench gpurun_out/${TAG}_bench_n1 "config 3: rocprofv3 --kernel-trace --stats of: python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-roofline --no-graph (eager enqueue, so that every kernel is a separate dispatch)"
 python tools/summarize_rocprof.py /tmp/prof_bench5 gpurun_out/${TAG}_config5_bench_n1 "config 5: rocprofv3 --kernel-trace --stats of: python3 bench.py $C5 --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-roofline --no-graph"
 # ---- PMC passes: counters only, one rocprofv3 process per kernel group and counter set
-bash tools/pmc_traffic.sh $TAG
-bash tools/pmc_counters.sh $TAG
+bash tools/pmc_traffic.sh $TAG $S8_GROUPS ffm_up_fwd_eval
+bash tools/pmc_counters.sh $TAG $S8_GROUPS
 export CAB_B=2 CAB_H=2048 CAB_W=1024 CAB_CLASSES=19
 bash tools/pmc_traffic.sh ${TAG}_config5 $S8_GROUPS
 bash tools/pmc_counters.sh ${TAG}_config5 $S8_GROUPS

@@ -4,7 +4,7 @@
 # groups with different shapes (sg_gemm, gemm_kmajor ...) are not averaged across them.
 # usage (on the GPU box):  bash tools/pmc_counters.sh <tag> [group ...]   ->  gpurun_out/<tag>_pmc_counters.json
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 cd /tmp && export TMPDIR=/tmp
 GROUPS_ALL="cab_attn_fwd cab_attn_fwd_bf16x6 cab_attn_fwd_bf16x3 cab_attn_bwd ffm_up_fwd ffm_up_bwd ohem_up_pair_fwd ohem_up_pair_bwd cab_local_fwd cab_local_bwd cab_qkv_fwd cab_qkv_bwd conv3x3_conva_fwd conv3x3_conva_bwd conv3x3_b1_fwd conv3x3_b1_bwd conv3x3_out_fwd conv3x3_out_bwd"
 GROUPS_RUN=${*:-$GROUPS_ALL}

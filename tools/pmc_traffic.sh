@@ -4,7 +4,7 @@
 # usage (on the GPU box):  bash tools/pmc_traffic.sh <tag> [group ...]   ->  gpurun_out/<tag>_pmc_traffic.json
 # workload shape from the environment (tools/run_kernels.py): CAB_B CAB_H CAB_W CAB_CLASSES, default = BASELINE config 3
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 cd /tmp && export TMPDIR=/tmp
 GROUPS_ALL="cab_attn_fwd cab_attn_fwd_bf16x6 cab_attn_fwd_bf16x3 cab_attn_bwd ffm_up_fwd ffm_up_fwd_bf16x6 ffm_up_fwd_bf16x3 ffm_up_bwd bn_act_fwd bn_act_bwd bn_dwconv_fwd bn_dwconv_bwd stem_conv_fwd stem_conv_wrw pwconv_fwd pwconv_bwd ohem_up_pair_fwd ohem_up_pair_bwd cab_local_fwd cab_local_bwd cab_qkv_fwd cab_qkv_bwd conv3x3_conva_fwd conv3x3_conva_bwd conv3x3_b1_fwd conv3x3_b1_bwd conv3x3_out_fwd conv3x3_out_bwd cab_attn_proj_fwd bn_cls_out_fwd bn_cls_out_bwd bn_cls_head_fwd bn_cls_head_bwd"
 GROUPS_RUN=${*:-$GROUPS_ALL}
