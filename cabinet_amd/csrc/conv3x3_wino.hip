@@ -934,9 +934,15 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
 //     2 x 16 values: planes [xi][tile][channel], pitch 68 (a wave's 8 tiles x 8 channels land in 4 tile + channel: conflict-free; 72 was two-way);
 //   * every range writes its G^T dU G (9 values per (k, c), via LDS in two halves) to a slab; wino_wgrad_sum_kernel adds the slabs in
 //     a fixed order: no atomics, bit-reproducible.
-constexpr int WG_KB = 64, WG_CB = 64, WG_TT = 8, WG_PITCH = 68;
-constexpr int WG_PLANE = 576;                 // floats of one xi plane of one operand: 8 x 68 padded to 9 x 64 (ds_write2st64 pairs)
-constexpr int WG_OPBUF = 16 * WG_PLANE;      // one operand of one chunk: 36,864 B
+constexpr int WG_KB = 64, WG_CB = 64, WG_TT = 8;
+// Round 6: operand planes [xi][channel][8 tiles] (the TILE -- the contracted index -- fastest, no padding), the two 4-tile halves
+// of a row swapped where bit 2 of the channel is set.  Which two tiles an MFMA step contracts is free as long as both operands
+// agree, so step s takes tile s from lanes 0-31 and tile 4 + s from lanes 32-63: the four values a lane needs of one (xi, channel
+// block) are 16 consecutive bytes -- ONE ds_read_b128 per chunk where the [xi][tile][channel] planes of round 5 took four
+// ds_read_b32 (8 LDS reads per chunk and wave instead of 32; the swap makes the 8-lane groups of a 16-byte read cover all 32 banks
+// once).  A wave's stores are 64 consecutive floats per plane, permuted inside rows: two lanes per bank, as any 64-lane dword store.
+constexpr int WG_PLANE = 512;                 // floats of one xi plane of one operand: 64 channels x 8 tiles
+constexpr int WG_OPBUF = 16 * WG_PLANE;      // one operand of one chunk: 32 KB
 constexpr int WG_BUF = 2 * WG_OPBUF;         // dM + V of one chunk
 
 struct WinoWgArgs {
@@ -954,10 +960,11 @@ __device__ __forceinline__ f32x2 bload2(buf_rsrc r, int voff_bytes, int soff_byt
 
 template <bool EVEN_W>
 __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][dM | V][16 xi][8 tiles][68]; epilogue: [16][64][32]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][dM | V][16 xi][64 channels][8 tiles]; epilogue: [16][64][32]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: a scalar, or every load offset built from it becomes a waterfall loop
     const int tt = tid & 7, ch = tid >> 3;
+    const int wg_slot = ch * 8 + ((((tt >> 2) ^ (ch >> 2)) & 1) << 2) + (tt & 3);   // where (channel ch, tile tt) sits in a plane
     const int unit = xcd_chunked_tile(blockIdx.x, a.nsplit * a.nkb * a.ncb);
     const int per_split = a.nkb * a.ncb, split = unit / per_split, rem = unit - split * per_split;
     const int kblk = rem / a.ncb, cblk = rem - kblk * a.ncb;
@@ -1053,7 +1060,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
             rr[0][e] = pg[0][e], rr[1][e] = pg[0][e] + pg[1][e], rr[2][e] = pg[0][e] - pg[1][e], rr[3][e] = -pg[1][e];
-        float* dm = smem + buf * WG_BUF + tt * WG_PITCH + ch;
+        float* dm = smem + buf * WG_BUF + wg_slot;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dm[(4 * i + 0) * WG_PLANE] = rr[i][0];
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
         }
     };
     auto stage_b = [&](int buf) {
-        float* dv = smem + buf * WG_BUF + WG_OPBUF + tt * WG_PITCH + ch;
+        float* dv = smem + buf * WG_BUF + WG_OPBUF + wg_slot;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dv[(4 * i + 0) * WG_PLANE] = tsel[4 * i + 0] - tsel[4 * i + 2];
@@ -1102,27 +1109,27 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][kb][cb][r] = 0.f;
-    // operands of ONE k-step (two tiles): av[xi][k block], bv[xi][c block]
+    // operands of ONE chunk (four k-steps of two tiles): av[xi][k block], bv[xi][c block], component s = k-step s
     struct Ops {
-        float av[2][2], bv[2][2];
+        f32x4 av[2][2], bv[2][2];
     };
-    auto read_ops = [&](Ops& o, int buf, int s) {
-        const float* ab = smem + buf * WG_BUF + (2 * wave) * WG_PLANE + h * WG_PITCH + li;
+    auto read_ops = [&](Ops& o, int buf) {
+        const float* ab = smem + buf * WG_BUF + (2 * wave) * WG_PLANE + li * 8 + (((h ^ (li >> 2)) & 1) << 2);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                o.av[x][e] = ab[x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
-                o.bv[x][e] = ab[WG_OPBUF + x * WG_PLANE + 2 * s * WG_PITCH + 32 * e];
+                o.av[x][e] = *reinterpret_cast<const f32x4*>(ab + x * WG_PLANE + 32 * 8 * e);
+                o.bv[x][e] = *reinterpret_cast<const f32x4*>(ab + WG_OPBUF + x * WG_PLANE + 32 * 8 * e);
             }
     };
-    auto mfma_step = [&](const Ops& o) {
+    auto mfma_step = [&](const Ops& o, int s) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) acc[x][kb][cb] = mfma32(o.av[x][kb], o.bv[x][cb], acc[x][kb][cb]);
+                for (int cb = 0; cb < 2; ++cb) acc[x][kb][cb] = mfma32(o.av[x][kb][s], o.bv[x][cb][s], acc[x][kb][cb]);
     };
 #define WG_PIN(n, mask, per)                                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                                                           \
@@ -1131,10 +1138,11 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     }
 
     // Software pipeline, one basic block per chunk (see wino_conv_kernel): a chunk is four k-steps of 8 MFMAs; between them sit
-    //   Q0  operand reads of k-step 1, stage M of chunk q+1 (dM stored)
-    //   Q1  operand reads of k-step 2, stage A, then the loads of chunk q+2 (a whole chunk of MFMAs ahead of their use)
-    //   Q2  operand reads of k-step 3, stage B (V stored)                              -- barrier --
-    //   Q3  operand reads of k-step 0 of chunk q+1
+    //   Q0  stage M of chunk q+1 (dM stored)
+    //   Q1  stage A, then the loads of chunk q+2 (a whole chunk of MFMAs ahead of their use)
+    //   Q2  stage B (V stored)                                                          -- barrier --
+    //   Q3  the 8 operand reads (ds_read_b128) of chunk q+1 -- all four k-steps of both operands at once (round 6; round 5 read
+    //       8 dwords in every quarter)
     // (Measured and not kept: a second register set for the loaded patches, i.e. requests two chunks ahead of their use instead of
     // one: 820 vs 804, 233 vs 228, 281 vs 286 us -- latency is not what this loop waits for; see wino_conv_kernel on what it is.)
     // (every range holds at least one chunk: nsplit <= nchunks; a wave-uniform condition inside the loop body -- a clamp on the tile
@@ -1148,42 +1156,38 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WinoWgArgs a) {
     advance(p_ld, q_lo + 1 < q_hi);
     load_chunk(p_ld);
     __syncthreads();
-    Ops o0, o1;
-    read_ops(o0, 0, 0);
-    auto body = [&](int q, int buf) {
+    Ops oa, ob;
+    read_ops(oa, 0);
+    // Q0 stage M of chunk q+1 | Q1 stage A, the loads of chunk q+2 | Q2 stage B -- barrier -- | Q3 the 8 operand reads of chunk q+1
+    auto body = [&](int q, int buf, const Ops& oc, Ops& on) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q0
-        read_ops(o1, buf, 1);
         stage_m(buf ^ 1);
-        mfma_step(o0);
-        WG_PIN(4, 0x100, 1)
-        WG_PIN(4, 0x002, 3)
+        mfma_step(oc, 0);
+        WG_PIN(8, 0x002, 2)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q1
-        read_ops(o0, buf, 2);
         stage_a();
         advance(p_ld, q + 2 < q_hi);
         load_chunk(p_ld);
-        mfma_step(o1);
-        WG_PIN(4, 0x100, 1)
-        WG_PIN(4, 0x002, EVEN_W ? 11 : 6)
+        mfma_step(oc, 1);
+        WG_PIN(8, 0x002, EVEN_W ? 6 : 3)
         __builtin_amdgcn_sched_barrier(0);
         // ---- Q2
-        read_ops(o1, buf, 3);
         stage_b(buf ^ 1);
-        mfma_step(o0);
+        mfma_step(oc, 2);
         WG_PIN(8, 0x002, 2)
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- Q3
-        read_ops(o0, buf ^ 1, 0);
-        mfma_step(o1);
-        WG_PIN(4, 0x100, 1)
+        read_ops(on, buf ^ 1);
+        mfma_step(oc, 3);
+        WG_PIN(8, 0x100, 1)
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int q = q_lo; q < q_hi; q += 2) {
-        body(q, 0);
-        if (q + 1 < q_hi) body(q + 1, 1);
+        body(q, 0, oa, ob);
+        if (q + 1 < q_hi) body(q + 1, 1, ob, oa);
     }
     __syncthreads();   // every wave is past its last operand read: the epilogue's planes may overwrite the ring
 #undef WG_PIN
@@ -1364,7 +1368,7 @@ static hipError_t wino_wgrad_run(const WinoShape& s, const float* dy, const floa
     a.C0 = s.C0, a.C1 = s.C1, a.K = s.K, a.B = s.B, a.H = s.H, a.W = s.W;
     a.TH = wn_th(s.H), a.ncx = (wn_th(s.W) + WG_TT - 1) / WG_TT, a.nchunks = wino_wgrad_nchunks(s);
     a.nsplit = wino_wgrad_nsplit(s, a.nchunks), a.nkb = s.K / WG_KB, a.ncb = (s.C0 + s.C1) / WG_CB;
-    const size_t lds = (size_t)2 * WG_BUF * sizeof(float);   // 147,456 B (the epilogue's 128 KB of planes alias it)
+    const size_t lds = (size_t)2 * WG_BUF * sizeof(float);   // 131,072 B (the epilogue's 128 KB of planes alias it)
     static lds_attr_mask mask{0};
     static lds_attr_mask mask_odd{0};
     if ((s.W & 1) == 0) {

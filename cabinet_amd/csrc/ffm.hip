@@ -795,35 +795,46 @@ __global__ __launch_bounds__(256) void ffm_pool_kernel(float* __restrict__ z, Bn
         return zc;
     };
     if ((P & 3) == 0) {
-        for (int p0 = 0; p0 < P; p0 += 1024) {   // wave-uniform trip count
-            const int p = p0 + threadIdx.x * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p < P) v = *reinterpret_cast<const f32x4*>(zr + p);
-            float y[4];
-            bool flag = false;
+        // four iterations' 16-byte pieces are requested BEFORE the first is tested: the borderline test ends in a wave-uniform
+        // branch on loaded data, and behind such a branch the next load is only issued once this one has returned -- one memory
+        // latency per iteration (the first round-6 version: 23 -> 41 us in the step, profiles/r06_bench_n1_summary.md)
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int p0 = 0; p0 < P; p0 += 4096) {   // wave-uniform trip count; four 16-byte requests in flight per thread
+            f32x4 vv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = fmaf((v[e] - mu) * inv, gw, gb);
-                flag |= fabsf(y[e]) < thr;
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + 1024 * u + threadIdx.x * 4;
+                vv[u] = p < P ? *reinterpret_cast<const f32x4*>(zr + p) : zero4;
             }
-            unsigned long long m = __ballot(flag && p < P);
-            while (m && budget > 0) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int ps = __shfl(p, src, 64);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + 1024 * u + threadIdx.x * 4;
+                float y[4];
+                bool flag = false;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float ye = __shfl(y[e], src, 64);
-                    if (fabsf(ye) < thr && budget > 0) {   // wave-uniform
-                        const float zc = redecide(src, ps + e);
-                        if (lane == src) y[e] = fmaf((zc - mu) * inv, gw, gb);
-                        --budget;
+                    y[e] = fmaf((vv[u][e] - mu) * inv, gw, gb);
+                    flag |= fabsf(y[e]) < thr;
+                }
+                unsigned long long m = __ballot(flag && p < P);
+                while (m && budget > 0) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int ps = __shfl(p, src, 64);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float ye = __shfl(y[e], src, 64);
+                        if (fabsf(ye) < thr && budget > 0) {   // wave-uniform
+                            const float zc = redecide(src, ps + e);
+                            if (lane == src) y[e] = fmaf((zc - mu) * inv, gw, gb);
+                            --budget;
+                        }
                     }
                 }
-            }
-            if (p < P) {
+                if (p < P) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += fmaxf(y[e], 0.f);
+                    for (int e = 0; e < 4; ++e) acc += fmaxf(y[e], 0.f);
+                }
             }
         }
     } else {
