@@ -250,3 +250,53 @@ def test_ddp_schedule_model(monkeypatch):
     monkeypatch.setenv("CABINET_DDP_ONE_EVENT", "0")
     f = choose_ddp_schedule(8, mb)
     assert not f["one_event"] and f["decided_by"] == "CABINET_DDP_ONE_EVENT=0"
+
+
+def _seg8_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from cabinet_amd.ddp import init_distributed
+    from cabinet_amd.train import GraphedDDPStep, build_model, make_criteria, synthetic_batch
+
+    init_distributed("gloo")
+    net = build_model("small", n_classes=8, seed=rank, gamma=0.5).train()
+    step = GraphedDDPStep(net, make_criteria(2, 64, 64, "cpu"), optimizer=None, bucket_mb=8.0)
+    im, lb = synthetic_batch(2, 64, 64, 8, "cpu", seed=100 + rank)
+    loss = float(step(im, lb))
+    torch.save({"grads": {k: p.grad.clone() for k, p in net.named_parameters() if p.requires_grad and p.grad is not None},
+                "loss": loss, "schedule": step.schedule, "buckets": step.bucket_megabytes}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_segmented_step_has_the_rank_average_gradient(tmp_path):
+    """BASELINE config 4's rank count (8 ranks of one node) on CPU over gloo, reduced size: the segmented data-parallel step
+    (decoder | backbone | spatial branch buckets, all-reduce AVG) leaves the SAME gradient on all eight ranks and it is the mean of
+    the eight per-rank gradients that single-process steps produce from rank 0's weights (BatchNorm statistics and OHEM per rank,
+    as the reference has no SyncBN: SURVEY 8(e)); the schedule object every rank prints with the bench line says world = 8."""
+    world, port = 8, _free_port()
+    mp.spawn(_seg8_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"e{i}.pt", weights_only=False) for i in range(world)]
+    for i in range(1, world):
+        assert r[i]["grads"].keys() == r[0]["grads"].keys()
+        for k in r[0]["grads"]:
+            assert torch.equal(r[0]["grads"][k], r[i]["grads"][k]), (i, k)
+    assert r[0]["schedule"]["world"] == 8 and r[0]["schedule"]["rings"] == 7 and len(r[0]["buckets"]) >= 3
+    from cabinet_amd.train import build_model, make_criteria, synthetic_batch
+
+    torch.set_num_threads(8)
+    crit = make_criteria(2, 64, 64, "cpu")
+    total = None
+    for rank in range(world):
+        net = build_model("small", n_classes=8, seed=0, gamma=0.5).train()
+        im, lb = synthetic_batch(2, 64, 64, 8, "cpu", seed=100 + rank)
+        o, o16 = net(im)
+        (crit[0](o, lb) + crit[1](o16, lb)).backward()
+        g = {k: p.grad.double() for k, p in net.named_parameters() if p.requires_grad and p.grad is not None}
+        total = g if total is None else {k: total[k] + g[k] for k in g}
+    for k, s in total.items():
+        want, got = s / world, r[0]["grads"][k].double()
+        err, den = float((got - want).norm()), float(want.norm())
+        assert err <= 2e-3 * den + 1e-7, (k, err, den)
