@@ -331,11 +331,15 @@ def _kernel_cases(batch, height, width=None, classes=8, extra=False):
         dy = torch.randn(B, Co, hh, ww, generator=g).to(dev)
         fl = 2.0 * B * hh * ww * (C0 + C1) * Co * 9 / 2.25
         io = 4.0 * (B * hh * ww * (C0 + C1 + Co) + wt.numel())
-        yield (f"conv3x3_{tag}_fwd (K11: filter transform + fused Winograd forward, {C0}{'+' + str(C1) if C1 else ''} -> {Co})",
-               lambda: Fh.conv3x3_fwd_hip(x0, x1, wt), fl, io, "mfma")
+        # as the step runs it: the epilogue also leaves the per-block (mean, M2) partials for the training-mode BatchNorm behind each
+        # of the three convolutions (round 6: the replayed loop used to time the forward WITHOUT them -- tools/instep_cycles.sh found
+        # conv_out's forward a tenth slower inside the step than in this loop for exactly that reason)
+        part = Fh.conv3x3_bn_part(x0, Co)
+        yield (f"conv3x3_{tag}_fwd (K11: filter transform + fused Winograd forward with the BatchNorm partials in its epilogue, {C0}{'+' + str(C1) if C1 else ''} -> {Co})",
+               lambda: Fh.conv3x3_fwd_hip(x0, x1, wt, bn_part=part), fl, io, "mfma")
         yield (f"conv3x3_{tag}_bwd (K11: data gradient + weight gradient, both Winograd, ordered slab sum)",
                lambda: Fh.conv3x3_bwd_hip(dy, x0, x1, wt), 2.0 * fl, 2.0 * io, "mfma")
-        del x0, x1, wt, dy
+        del x0, x1, wt, dy, part
         torch.cuda.empty_cache()
 
     # ---- K12: BatchNorm -> ReLU -> 1x1 classifier as one streaming operator behind K11 (conv_out's tail,

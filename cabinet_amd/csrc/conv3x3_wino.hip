@@ -30,6 +30,8 @@
 // The data gradient is the same kernel on filters transformed with the spatial flip and the channel roles swapped
 // (dx = conv(dy, rot180(w)^T)); the weight gradient is its own kernel below (contraction over tiles).
 // Exact fp32 MFMA (v_mfma_f32_32x32x2_f32); Winograd's own rounding (+-1, 1/2 coefficients) stays at the 1e-6 level.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace cabinet {
@@ -130,6 +132,23 @@ __device__ __forceinline__ void wino_bt_d_b(const float (&d)[16], float (&v)[16]
 
 __device__ __forceinline__ f32x4 bload4(buf_rsrc r, int voff_bytes, int soff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+
+// Sum over the 32 lanes of this lane's half (= the 32 tiles of one channel in the epilogues below), result in every lane: four DPP
+// steps inside the 16-lane rows (quad swaps, half-row mirror, row mirror: VALU, ~8 cycles each) and ONE cross-row exchange.
+// Round 6: the statistics epilogue took three butterfly reductions of five ds_bpermute each per channel -- a dependent chain of
+// ~15 LDS-crossbar round trips, 16 channels per thread: tools/instep_cycles.sh counts 1.52-1.54 M cycles for conv_out's forward
+// inside the step (where the epilogue leaves the BatchNorm partials) against 1.38 M for the same kernel without them (the data
+// gradient; the replayed loop) -- a tenth of the kernel.  (The count of valid outputs needs no reduction at all: it is geometry.)
+__device__ __forceinline__ float wino_half_sum(float x) {
+    auto dpp = [](float v, auto ctrl_tag) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl_tag)::value, 0xF, 0xF, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});   // row_mirror
+    return x + __shfl_xor(x, 16, 64);                    // the other row of the half
 }
 
 // PAIR (W even): the 4x4 patch of a lane is assembled from ONE 8-byte load per row (columns 2 tx, 2 tx + 1: the tile's own two
@@ -420,7 +439,10 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
             if (vy && vx1) cnt += 1.f, sum += o[r][1];
         }
         if (a.stat_part) {   // (mean, M2) of the block's valid outputs of channel kk: two half-wave reductions, fixed order
-            const float n_blk = half_sum(cnt), mean = half_sum(sum) / fmaxf(n_blk, 1.f);
+            // valid outputs of the block: geometry (4 rows x 32 columns clipped at the image), the same for every channel
+            const float n_blk = (float)(max(0, min(4, a.H - 4 * by)) * max(0, min(32, a.W - 32 * bx)));
+            (void)cnt;
+            const float mean = wino_half_sum(sum) / fmaxf(n_blk, 1.f);
             float m2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -428,7 +450,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(WinoArgs a) {
                 if (vy && vx0) m2 += (o[r][0] - mean) * (o[r][0] - mean);
                 if (vy && vx1) m2 += (o[r][1] - mean) * (o[r][1] - mean);
             }
-            m2 = half_sum(m2);
+            m2 = wino_half_sum(m2);
             if (t == 0) {
                 a.stat_part[(size_t)(k0 + kk) * a.ntb + tb] = mean;
                 a.stat_part[((size_t)a.K + k0 + kk) * a.ntb + tb] = m2;
@@ -677,7 +699,9 @@ __global__ __launch_bounds__(256) void wino_conv128p_kernel(WinoArgs a) {
                     }
                 }
                 if (a.stat_part) {   // (mean, M2) of the block's valid outputs of this channel: the 64-channel kernel's order, same bits
-                    const float n_blk = half_sum(cnt), mean = half_sum(sum) / fmaxf(n_blk, 1.f);
+                    const float n_blk = (float)(max(0, min(4, a.H - 4 * tc.by)) * max(0, min(32, a.W - 32 * tc.bx)));
+                    (void)cnt;
+                    const float mean = wino_half_sum(sum) / fmaxf(n_blk, 1.f);
                     float m2 = 0.f;
 #pragma unroll
                     for (int rr = 0; rr < 2; ++rr)
@@ -685,7 +709,7 @@ __global__ __launch_bounds__(256) void wino_conv128p_kernel(WinoArgs a) {
                             m2 += (o[rr][0] - mean) * (o[rr][0] - mean);
                             m2 += (o[rr][1] - mean) * (o[rr][1] - mean);
                         }
-                    m2 = half_sum(m2);
+                    m2 = wino_half_sum(m2);
                     if (li == 0) {
                         a.stat_part[(size_t)(k0 + kk) * a.ntb + tc.tb] = mean;
                         a.stat_part[((size_t)a.K + k0 + kk) * a.ntb + tc.tb] = m2;
@@ -872,7 +896,7 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
         int krow0, kimg;
         if (k0 < a.K0) ybase = a.y0, krow0 = k0, kimg = a.K0;
         else ybase = a.y1, krow0 = k0 - a.K0, kimg = a.K - a.K0;
-#pragma unroll 2
+#pragma unroll 4
         for (int i = 0; i < 8; ++i) {
             const int kk = (tid >> 5) + 8 * i;   // channel of the half block
             float m[16];
@@ -906,7 +930,9 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
                 }
             }
             if (a.stat_part) {   // (mean, M2) of the block's valid outputs of channel kk (as wino_conv_kernel: same order, same bits)
-                const float n_blk = half_sum(cnt), mean = half_sum(sum) / fmaxf(n_blk, 1.f);
+                const float n_blk = (float)(max(0, min(4, a.H - 4 * by)) * max(0, min(32, a.W - 32 * bx)));
+                (void)cnt;
+                const float mean = wino_half_sum(sum) / fmaxf(n_blk, 1.f);
                 float m2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
@@ -914,7 +940,7 @@ __global__ __launch_bounds__(256) void wino_conv128_kernel(WinoArgs a) {
                         m2 += (o[r][0] - mean) * (o[r][0] - mean);
                         m2 += (o[r][1] - mean) * (o[r][1] - mean);
                     }
-                m2 = half_sum(m2);
+                m2 = wino_half_sum(m2);
                 if (t == 0) {
                     a.stat_part[(size_t)(k0 + kk) * a.ntb + tb] = mean;
                     a.stat_part[((size_t)a.K + k0 + kk) * a.ntb + tb] = m2;
