@@ -329,6 +329,7 @@ DDP_DRAIN_MS = 0.35            # measured cost of the second event's wait (one M
 XGMI_LINK_GBS_PER_DIR = 76.8   # 153.6 GB/s per link, both directions (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
 RCCL_LINK_EFFICIENCY = 0.5     # share of the link rate a <= 8 MB bucket reaches (latency-bound messages); conservative
 RCCL_LAUNCH_MS = 0.02          # per collective
+DDP_TWO_EVENT_MARGIN = 1.25    # the modelled exposure must exceed the measured drain by this factor before two events are chosen
 
 
 def choose_ddp_schedule(world, exposed_bytes, n_buckets=2):
@@ -341,7 +342,9 @@ def choose_ddp_schedule(world, exposed_bytes, n_buckets=2):
     else:
         wire = 0.0   # one-rank "collectives" are local copies
     exposed = wire + n_buckets * RCCL_LAUNCH_MS
-    one = exposed < DDP_DRAIN_MS
+    # the drain is MEASURED (on one GPU), the exposure is a model: the two-event schedule has to beat the one-event one by a margin
+    # before it is chosen (no schedule whose benefit was never measured as the default)
+    one = exposed < DDP_TWO_EVENT_MARGIN * DDP_DRAIN_MS
     why = "model"
     if forced in ("0", "1"):
         one, why = forced == "1", "CABINET_DDP_ONE_EVENT=" + forced

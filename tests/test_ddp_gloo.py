@@ -237,14 +237,14 @@ def test_ddp_schedule_model(monkeypatch):
     measured 0.35 ms on one GPU; dropping it exposes the backbone's buckets behind the spatial branch's backward instead.  The
     choice comes from a ring all-reduce model over the point-to-point xGMI links and is printed with the bench line; the
     environment overrides it for a node that can measure both."""
-    from cabinet_amd.train import DDP_DRAIN_MS, choose_ddp_schedule
+    from cabinet_amd.train import DDP_DRAIN_MS, DDP_TWO_EVENT_MARGIN, choose_ddp_schedule
 
     monkeypatch.delenv("CABINET_DDP_ONE_EVENT", raising=False)
     mb = 12.6 * 2 ** 20
     s8, s2, s1 = choose_ddp_schedule(8, mb), choose_ddp_schedule(2, mb), choose_ddp_schedule(1, mb)
     assert s8["one_event"] and s8["rings"] == 7 and s8["exposed_ms_model"] < DDP_DRAIN_MS and s8["decided_by"] == "model"
     assert s2["rings"] == 1 and s2["exposed_ms_model"] > s8["exposed_ms_model"]   # one link between two GPUs
-    assert s2["one_event"] == (s2["exposed_ms_model"] < DDP_DRAIN_MS)
+    assert s2["one_event"] == (s2["exposed_ms_model"] < DDP_TWO_EVENT_MARGIN * DDP_DRAIN_MS)
     assert s1["one_event"] and s1["exposed_ms_model"] < 0.1   # one-rank collectives move nothing
     assert not choose_ddp_schedule(8, 400 * 2 ** 20)["one_event"]   # a large exposed volume keeps the two-event schedule
     monkeypatch.setenv("CABINET_DDP_ONE_EVENT", "0")
